@@ -1,0 +1,184 @@
+"""numpy-facing wrapper around oracle/liboracle.so (cpm_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  The product package never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "cpm_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = ctypes.CDLL(build())
+        _LIB.orc_ml_nms.restype = ctypes.c_int64
+        _LIB.orc_nms.restype = ctypes.c_int64
+    return _LIB
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def roi_align_forward(inp, rois, scale, ph, pw, sampling_ratio, aligned=False, interp=0):
+    inp, rois = _f32(inp), _f32(rois).reshape(-1, 5)
+    B, C, H, W = inp.shape
+    K = rois.shape[0]
+    out = np.zeros((K, C, ph, pw), np.float32)
+    rc = lib().orc_roi_align_forward(_p(inp), _p(rois), K, B, C, H, W, ctypes.c_float(scale), ph, pw,
+                                     sampling_ratio, int(aligned), interp, _p(out))
+    if rc:
+        raise RuntimeError("orc_roi_align_forward failed: %d" % rc)
+    return out
+
+
+def roi_align_backward(grad, rois, scale, ph, pw, B, C, H, W, sampling_ratio, aligned=False, interp=0):
+    grad, rois = _f32(grad), _f32(rois).reshape(-1, 5)
+    K = rois.shape[0]
+    gin = np.zeros((B, C, H, W), np.float32)
+    rc = lib().orc_roi_align_backward(_p(grad), _p(rois), K, B, C, H, W, ctypes.c_float(scale), ph, pw,
+                                      sampling_ratio, int(aligned), interp, _p(gin))
+    if rc:
+        raise RuntimeError("orc_roi_align_backward failed: %d" % rc)
+    return gin
+
+
+def ml_nms(boxes, scores, labels, thr, topk=0):
+    boxes, scores = _f32(boxes).reshape(-1, 4), _f32(scores)
+    labels = np.ascontiguousarray(labels, dtype=np.int64)
+    n = boxes.shape[0]
+    keep = np.zeros(max(n, 1), np.int64)
+    nk = lib().orc_ml_nms(_p(boxes), _p(scores), _p(labels), ctypes.c_int64(n), ctypes.c_float(thr),
+                          ctypes.c_int64(topk), _p(keep))
+    return keep[:nk].copy()
+
+
+def nms(boxes, scores, thr):
+    boxes, scores = _f32(boxes).reshape(-1, 4), _f32(scores)
+    n = boxes.shape[0]
+    keep = np.zeros(max(n, 1), np.int64)
+    nk = lib().orc_nms(_p(boxes), _p(scores), ctypes.c_int64(n), ctypes.c_float(thr), _p(keep))
+    return keep[:nk].copy()
+
+
+def box_iou(boxes, query):
+    boxes, query = _f32(boxes).reshape(-1, 4), _f32(query).reshape(-1, 4)
+    out = np.zeros((boxes.shape[0], query.shape[0]), np.float32)
+    lib().orc_box_iou(_p(boxes), ctypes.c_int64(boxes.shape[0]), _p(query), ctypes.c_int64(query.shape[0]), _p(out))
+    return out
+
+
+def boxlist_iou(b1, b2):
+    b1, b2 = _f32(b1).reshape(-1, 4), _f32(b2).reshape(-1, 4)
+    out = np.zeros((b1.shape[0], b2.shape[0]), np.float32)
+    lib().orc_boxlist_iou(_p(b1), ctypes.c_int64(b1.shape[0]), _p(b2), ctypes.c_int64(b2.shape[0]), _p(out))
+    return out
+
+
+def pool_points_interp_forward(inp, pts, scale):
+    inp, pts = _f32(inp), _f32(pts).reshape(-1, 3)
+    B, C, H, W = inp.shape
+    out = np.zeros((pts.shape[0], C), np.float32)
+    lib().orc_pool_points_interp_forward(_p(inp), _p(pts), pts.shape[0], C, H, W, ctypes.c_float(scale), _p(out))
+    return out
+
+
+def pool_points_interp_backward(grad, pts, scale, B, C, H, W):
+    grad, pts = _f32(grad), _f32(pts).reshape(-1, 3)
+    gin = np.zeros((B, C, H, W), np.float32)
+    lib().orc_pool_points_interp_backward(_p(grad), _p(pts), pts.shape[0], B, C, H, W, ctypes.c_float(scale), _p(gin))
+    return gin
+
+
+def level_map(boxes, k_min=2, k_max=5, s0=224, lvl0=4, eps=1e-6):
+    boxes = _f32(boxes).reshape(-1, 4)
+    out = np.zeros(boxes.shape[0], np.int64)
+    lib().orc_level_map(_p(boxes), ctypes.c_int64(boxes.shape[0]), ctypes.c_float(k_min), ctypes.c_float(k_max),
+                        ctypes.c_float(s0), ctypes.c_float(lvl0), ctypes.c_float(eps), _p(out))
+    return out
+
+
+def box_decode(codes, boxes, weights=(1., 1., 1., 1.), clip=float(np.log(1000. / 16))):
+    codes, boxes = _f32(codes).reshape(-1, 4), _f32(boxes).reshape(-1, 4)
+    out = np.zeros_like(codes)
+    w = [ctypes.c_float(x) for x in weights]
+    lib().orc_box_decode(_p(codes), _p(boxes), ctypes.c_int64(codes.shape[0]), *w, ctypes.c_float(clip), _p(out))
+    return out
+
+
+def box_encode(ref, prop, weights=(1., 1., 1., 1.)):
+    ref, prop = _f32(ref).reshape(-1, 4), _f32(prop).reshape(-1, 4)
+    out = np.zeros_like(ref)
+    w = [ctypes.c_float(x) for x in weights]
+    lib().orc_box_encode(_p(ref), _p(prop), ctypes.c_int64(ref.shape[0]), *w, _p(out))
+    return out
+
+
+def matcher(q, high, low, allow_low_quality=False):
+    q = _f32(q)
+    M, N = q.shape
+    out = np.zeros(N, np.int64)
+    lib().orc_matcher(_p(q), ctypes.c_int64(M), ctypes.c_int64(N), ctypes.c_float(high), ctypes.c_float(low),
+                      int(allow_low_quality), _p(out))
+    return out
+
+
+def sub_regions(grid_points=9, grid_size=3, map_size=56):
+    out = np.zeros((grid_points, 4), np.int32)
+    lib().orc_sub_regions(grid_points, grid_size, map_size, _p(out))
+    return out
+
+
+def grid_targets(boxes, gt, grid_points=9, map_size=56, radius=1, mapping_ratio=1.0):
+    boxes, gt = _f32(boxes).reshape(-1, 4), _f32(gt).reshape(-1, 4)
+    R = boxes.shape[0]
+    half = map_size // 4 * 2
+    out = np.zeros((R, grid_points, half, half), np.float32)
+    lib().orc_grid_targets(_p(boxes), _p(gt), ctypes.c_int64(R), grid_points, map_size, radius,
+                           ctypes.c_float(mapping_ratio), _p(out))
+    return out
+
+
+def grid_decode(boxes, prob, grid_points=9, map_size=56, mapping_ratio=1.0):
+    boxes, prob = _f32(boxes).reshape(-1, 4), _f32(prob)
+    R = boxes.shape[0]
+    out = np.zeros((R, 4), np.float32)
+    lib().orc_grid_decode(_p(boxes), _p(prob), ctypes.c_int64(R), grid_points, map_size,
+                          ctypes.c_float(mapping_ratio), _p(out))
+    return out
+
+
+def cell_anchors(stride, sizes, ratios):
+    sizes = np.ascontiguousarray(sizes, np.float64)
+    ratios = np.ascontiguousarray(ratios, np.float64)
+    out = np.zeros((len(ratios) * len(sizes), 4), np.float64)
+    lib().orc_cell_anchors(ctypes.c_double(stride), _p(sizes), len(sizes), _p(ratios), len(ratios), _p(out))
+    return out.astype(np.float32)
+
+
+def grid_anchors(grid_hw, stride, cell):
+    """anchor_generator.py:73-95: shifts (x,y,x,y) + cell anchors, row-major over (y, x), then A."""
+    gh, gw = grid_hw
+    sx = np.arange(0, gw * stride, stride, dtype=np.float32)
+    sy = np.arange(0, gh * stride, stride, dtype=np.float32)
+    yy, xx = np.meshgrid(sy, sx, indexing="ij")
+    shifts = np.stack([xx.ravel(), yy.ravel(), xx.ravel(), yy.ravel()], 1)
+    return (shifts[:, None, :] + cell[None, :, :]).reshape(-1, 4)

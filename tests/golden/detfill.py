@@ -1,0 +1,40 @@
+"""Deterministic, name-keyed parameter fill shared by the golden generator and the tests.
+
+Every tensor is filled from a numpy RandomState seeded by crc32(name), so two
+module trees with the same state-dict keys (the reference's and ours) get
+bit-identical weights regardless of construction order.
+"""
+import zlib
+
+import numpy as np
+import torch
+
+
+def det_tensor(name, shape, kind):
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    shape = tuple(shape)
+    if kind == "weight":
+        fan_in = int(np.prod(shape[1:])) if len(shape) > 1 else 1
+        a = rs.standard_normal(shape).astype(np.float32) * np.float32(1.0 / np.sqrt(max(fan_in, 1)))
+    elif kind == "scale":      # affine / norm gammas
+        a = rs.uniform(0.5, 1.5, shape).astype(np.float32)
+    else:                      # biases
+        a = rs.uniform(-0.1, 0.1, shape).astype(np.float32)
+    return torch.from_numpy(a)
+
+
+def kind_of(name, tensor):
+    if name.endswith("bias"):
+        return "bias"
+    if tensor.dim() == 1:
+        return "scale"
+    return "weight"
+
+
+def det_fill_(module):
+    with torch.no_grad():
+        for name, p in module.state_dict().items():
+            if not torch.is_floating_point(p):
+                continue
+            p.copy_(det_tensor(name, p.shape, kind_of(name, p)))
+    return module

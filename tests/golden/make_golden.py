@@ -1,0 +1,328 @@
+"""Generate the committed golden vectors by running the REFERENCE here.
+
+Runs only in the build container (needs /root/reference and oracle/_ref).  The
+GPU box never runs this; it only reads the .npz/.json files it wrote.
+
+How the reference is driven (nothing from it is copied into the repo):
+  * RoIAlign: oracle/_ref = the reference's own ROIAlign_cpu.cpp compiled by
+    oracle/build_ref.py.
+  * Python modules are imported from /root/reference.  Third-party packages the
+    image lacks are replaced IN THIS PROCESS ONLY by inert stand-ins:
+      apex.amp.float_function -> identity decorator
+      torchvision.ops.nms / cv2 / pycocotools -> placeholders that raise if called
+      pet.lib.ops._C -> the compiled reference RoIAlign; every other symbol raises
+    np.float (removed in numpy 2) is aliased to float, torch.Tensor.cuda is bound
+    to identity while the grid target/decoder run (they hard-code .cuda()).
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+REF = "/root/reference"
+
+from detfill import det_fill_  # noqa: E402
+from oracle.build_ref import build as build_ref  # noqa: E402
+
+
+def install_standins(ref_ext):
+    np.float = float  # noqa: anchor_generator.py:230
+
+    apex = types.ModuleType("apex")
+    amp = types.ModuleType("apex.amp")
+    amp.float_function = lambda f: f
+    apex.amp = amp
+    sys.modules["apex"] = apex
+    sys.modules["apex.amp"] = amp
+
+    def _absent(*a, **k):
+        raise RuntimeError("third-party op absent in this container")
+
+    tv = types.ModuleType("torchvision")
+    tvo = types.ModuleType("torchvision.ops")
+    tvo.nms = _absent
+    tv.ops = tvo
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.ops"] = tvo
+    for name in ("cv2", "pycocotools", "pycocotools.mask", "pycocotools.coco", "pycocotools.cocoeval"):
+        sys.modules[name] = types.ModuleType(name)
+
+    class _C(types.ModuleType):
+        def __getattr__(self, item):
+            return _absent
+    c = _C("pet.lib.ops._C")
+    c.roi_align_forward = ref_ext.roi_align_forward
+    c.roi_align_backward = ref_ext.roi_align_backward
+    sys.modules["pet.lib.ops._C"] = c
+    sys.path.insert(0, REF)
+
+
+def load_cfg(yaml_rel):
+    import yaml
+    from pet.rcnn.core import config
+    from pet.utils.collections import AttrDict
+    with open(os.path.join(REF, yaml_rel)) as f:
+        y = AttrDict(yaml.safe_load(f))
+    config._merge_a_into_b(y, config.cfg)
+    return config.cfg
+
+
+def gen_ops(ref_ext, out):
+    rng = np.random.default_rng(20240)
+    # ---- RoIAlign: (7|14) x scales, edge RoIs ------------------------------------------------
+    for ph, scale, H, W in [(7, 0.25, 24, 40), (14, 0.25, 24, 40), (7, 0.125, 12, 20), (14, 0.125, 12, 20),
+                            (7, 1 / 16., 6, 10), (14, 1 / 16., 6, 10), (7, 1 / 32., 3, 5), (14, 1 / 32., 3, 5)]:
+        C, B, K = 6, 2, 24
+        x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        b = rng.integers(0, B, K).astype(np.float32)
+        iw, ih = W / scale, H / scale
+        x1 = rng.uniform(-0.2 * iw, iw, K)
+        y1 = rng.uniform(-0.2 * ih, ih, K)
+        w = rng.uniform(0.05, 0.9 * iw, K)
+        h = rng.uniform(0.05, 0.9 * ih, K)
+        rois = np.stack([b, x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+        # hand-made edge cases: outside the map, sub-pixel, integer aligned, border straddling
+        rois[0] = [0, -500, -500, -400, -400]
+        rois[1] = [1, iw + 50, ih + 50, iw + 90, ih + 120]
+        rois[2] = [0, 10.25, 7.5, 10.5, 7.75]
+        rois[3] = [1, 0, 0, 4 / scale, 4 / scale]
+        rois[4] = [0, iw - 9, ih - 9, iw + 30, ih + 30]
+        rois[5] = [1, -13, 5, 17, 31]
+        key = "roi_%d_%d" % (ph, int(round(1 / scale)))
+        for interp in (0, 1):
+            for aligned in (False, True):
+                y = ref_ext.roi_align_forward(torch.from_numpy(x), torch.from_numpy(rois), scale, ph, ph, 2,
+                                              aligned, interp)
+                g = rng.standard_normal(tuple(y.shape)).astype(np.float32)
+                gi = ref_ext.roi_align_backward(torch.from_numpy(g), torch.from_numpy(rois), scale, ph, ph, B, C, H,
+                                                W, 2, aligned, interp)
+                sfx = "_i%d_a%d" % (interp, int(aligned))
+                out[key + sfx + "_y"] = y.numpy()
+                out[key + sfx + "_g"] = g
+                out[key + sfx + "_gi"] = gi.numpy()
+        out[key + "_x"] = x
+        out[key + "_rois"] = rois
+    # adaptive sampling ratio (sampling_ratio=0)
+    x = rng.standard_normal((1, 3, 16, 16)).astype(np.float32)
+    rois = np.array([[0, 3, 2, 40, 50], [0, 0, 0, 63, 63], [0, 20, 20, 22, 21]], np.float32)
+    out["roi_adapt_x"], out["roi_adapt_rois"] = x, rois
+    out["roi_adapt_y"] = ref_ext.roi_align_forward(torch.from_numpy(x), torch.from_numpy(rois), 0.25, 7, 7, 0,
+                                                   False, 0).numpy()
+
+    # ---- LevelMapper (poolers.py:9-40) -------------------------------------------------------
+    from pet.rcnn.utils.poolers import LevelMapper
+    from pet.utils.data.structures.bounding_box import BoxList
+    n = 4096
+    x1 = rng.uniform(0, 1000, n)
+    y1 = rng.uniform(0, 600, n)
+    w = np.exp(rng.uniform(np.log(2), np.log(1200), n))
+    h = np.exp(rng.uniform(np.log(2), np.log(800), n))
+    boxes = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    k = 0
+    for s in (56, 112, 224, 448, 896):       # exact level boundaries: area+1 = s^2
+        for d in (-1, 0, 1):
+            boxes[k] = [10, 10, 10 + s - 1 + d, 10 + s - 1]
+            k += 1
+    lm = LevelMapper(2, 5)
+    out["lvl_boxes"] = boxes
+    out["lvl_out"] = lm([BoxList(torch.from_numpy(boxes), (1333, 800))]).numpy()
+
+    # ---- anchors (anchor_generator.py) -------------------------------------------------------
+    from pet.rcnn.modeling.rpn.anchor_generator import generate_anchors, AnchorGenerator
+    out["anchors_matlab_table"] = generate_anchors(16, (128, 256, 512), (0.5, 1, 2)).float().numpy()
+    ag = AnchorGenerator(sizes=(32, 64, 128, 256, 512), aspect_ratios=(0.5, 1.0, 2.0),
+                         anchor_strides=(4, 8, 16, 32, 64), straddle_thresh=0)
+    for i, ca in enumerate(ag.cell_anchors):
+        out["cell_anchors_%d" % i] = ca.numpy()
+    grids = ag.grid_anchors([(5, 7), (3, 4), (2, 2), (1, 2), (1, 1)])
+    for i, g in enumerate(grids):
+        out["grid_anchors_%d" % i] = g.numpy()
+    bl = BoxList(grids[0], (28, 20), mode="xyxy")
+    ag.add_visibility_to(bl)
+    out["grid_anchors_0_visibility"] = bl.get_field("visibility").numpy()
+
+    # ---- BoxCoder ----------------------------------------------------------------------------
+    from pet.rcnn.utils.box_coder import BoxCoder
+    bc = BoxCoder((1., 1., 1., 1.))
+    n = 512
+    pb = boxes[:n].copy()
+    codes = (rng.standard_normal((n, 4)) * np.array([0.3, 0.3, 1.5, 1.5])).astype(np.float32)
+    codes[:8, 2:] = 6.0  # exercises the log(1000/16) clip
+    out["bc_boxes"], out["bc_codes"] = pb, codes
+    out["bc_decode"] = bc.decode(torch.from_numpy(codes), torch.from_numpy(pb)).numpy()
+    gt = boxes[n:2 * n].copy()
+    out["bc_gt"] = gt
+    out["bc_encode"] = bc.encode(torch.from_numpy(gt), torch.from_numpy(pb)).numpy()
+
+    # ---- boxlist_iou (+1) and Matcher --------------------------------------------------------
+    from pet.utils.data.structures.boxlist_ops import boxlist_iou
+    from pet.rcnn.utils.matcher import Matcher
+    g16 = boxes[100:116]
+    # proposals that overlap the gts: jittered copies + randoms + exact copies (ties)
+    props = np.concatenate([g16 + rng.uniform(-15, 15, g16.shape).astype(np.float32), boxes[200:400], g16,
+                            g16[:4]], 0).astype(np.float32)
+    iou = boxlist_iou(BoxList(torch.from_numpy(g16), (1333, 800)), BoxList(torch.from_numpy(props), (1333, 800)))
+    out["iou_gt"], out["iou_props"], out["iou_out"] = g16, props, iou.numpy()
+    out["match_rpn"] = Matcher(0.7, 0.3, allow_low_quality_matches=True)(iou.clone()).numpy()
+    out["match_cls"] = Matcher(0.5, 0.5, allow_low_quality_matches=False)(iou.clone()).numpy()
+    out["match_g2"] = Matcher(0.7, 0.7, allow_low_quality_matches=False)(iou.clone()).numpy()
+
+    # ---- losses ------------------------------------------------------------------------------
+    from pet.lib.ops import smooth_l1_loss, l2_loss
+    a = rng.standard_normal((64, 4)).astype(np.float32)
+    b = rng.standard_normal((64, 4)).astype(np.float32) * 0.3
+    out["sl1_a"], out["sl1_b"] = a, b
+    out["sl1_out"] = smooth_l1_loss(torch.from_numpy(a), torch.from_numpy(b), beta=1. / 9, reduction="sum").numpy()
+    t = np.abs(rng.standard_normal((32, 2))).astype(np.float32)
+    t[::3] = 0
+    lg = rng.standard_normal((32, 2)).astype(np.float32)
+    out["l2_x"], out["l2_t"] = lg, t
+    out["l2_out"] = l2_loss(torch.from_numpy(lg), torch.from_numpy(t)).numpy()
+
+
+def gen_grid(out):
+    """GridLossComputation.prepare_target and GridPostProcessor.get_boxes (per stage ratio)."""
+    from pet.rcnn.modeling.grid_cascade_rcnn.loss import loss_evaluator, calc_sub_regions
+    from pet.rcnn.modeling.grid_cascade_rcnn.inference import post_processor
+    from pet.utils.data.structures.bounding_box import BoxList
+    rng = np.random.default_rng(777)
+    out["sub_regions"] = np.array(calc_sub_regions(9, 3, 56), np.int32)
+    R = 20
+    x1 = rng.uniform(0, 900, R)
+    y1 = rng.uniform(0, 500, R)
+    w = rng.uniform(8, 400, R)
+    h = rng.uniform(8, 300, R)
+    gt = np.stack([x1, y1, x1 + w, y1 + h], 1).astype(np.float32)
+    jit = rng.uniform(-0.2, 0.2, (R, 4)) * np.stack([w, h, w, h], 1)
+    boxes = (gt + jit).astype(np.float32)
+    boxes[0] = [100, 100, 102, 150]        # width <= grid_size -> skipped (loss.py:215-217)
+    boxes[1] = gt[1]                        # RoI == gt
+    gt[2] = [boxes[2][0] - 300, boxes[2][1] - 200, boxes[2][0] - 10, boxes[2][1] - 5]   # points fall outside
+    out["grid_boxes"], out["grid_gt"] = boxes, gt
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    orig_get_device = torch.Tensor.get_device
+    try:
+        for stage in range(3):
+            ev = loss_evaluator(stage=stage, type="grid")
+            ev.pos_result = (torch.from_numpy(boxes.copy()), torch.from_numpy(gt.copy()))
+            out["grid_targets_s%d" % stage] = ev.prepare_target(None, None).numpy()
+            pp = post_processor(stage=stage, type="grid")
+            logits = (rng.standard_normal((R, 9, 28, 28)) * 2).astype(np.float32)
+            logits[3, 4] = 0.0                        # a flat map: argmax tie -> first index
+            logits[5, :, 10, 11] = 25.0               # saturating sigmoid
+            bl = BoxList(torch.from_numpy(boxes.copy()), (1333, 800))
+            res = pp.get_boxes(bl, torch.from_numpy(logits), False)
+            out["grid_logits_s%d" % stage] = logits
+            out["grid_decode_s%d" % stage] = res.numpy()
+    finally:
+        torch.Tensor.cuda = saved_cuda
+        torch.Tensor.get_device = orig_get_device
+
+
+def gen_model(out, meta):
+    """Structural golden: the reference module tree with name-keyed deterministic weights."""
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    from pet.utils.data.structures.bounding_box import BoxList
+    from pet.utils.data.structures.image_list import to_image_list
+    torch.manual_seed(0)
+    model = Generalized_RCNN(is_train=True)
+    model = convert_bn2affine_model(model, merge=True)
+    meta["state_dict"] = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    meta["trainable"] = [k for k, p in model.named_parameters() if p.requires_grad]
+    det_fill_(model)
+    model.eval()
+    rng = np.random.default_rng(5)
+    img = (rng.uniform(0, 255, (1, 3, 64, 96)) - np.array([102.9801, 115.9465, 122.7717]).reshape(1, 3, 1, 1))
+    img = img.astype(np.float32)
+    out["m_img"] = img
+    with torch.no_grad():
+        x = torch.from_numpy(img)
+        c = model.Conv_Body(x)
+        for i, t in enumerate(c):
+            out["m_c%d" % (i + 2)] = t.numpy()[:, ::8]           # every 8th channel
+        p = model.Conv_Body_FPN(c)
+        for i, t in enumerate(p):
+            out["m_p%d" % (i + 2)] = t.numpy()[:, ::8]
+        logits, breg = model.RPN.head(p)
+        for i, (a, b) in enumerate(zip(logits, breg)):
+            out["m_rpn_logits_%d" % i] = a.numpy()
+            out["m_rpn_bbox_%d" % i] = b.numpy()
+        rois = np.array([[2, 3, 60, 40], [10, 5, 90, 60], [0, 0, 95, 63], [30, 20, 50, 45], [5, 30, 25, 62],
+                         [40, 2, 70, 20]], np.float32)
+        out["m_rois"] = rois
+        boxes = [BoxList(torch.from_numpy(rois), (96, 64))]
+        g = model.Grid_Cascade_RCNN
+        f = g.Head_cls(p, boxes)
+        out["m_cls_feat"] = f.numpy()
+        out["m_cls_logits"] = g.Output_cls(f).numpy()
+        f = g.Head_rescore(p, boxes)
+        out["m_rescore_logits"] = g.Output_rescore(f).numpy()
+        for s in range(3):
+            head = getattr(g, "Head_grid_%d" % s)
+            outp = getattr(g, "Output_grid_%d" % s)
+            outp.train()            # "unfused" branch is the training branch (outputs.py:66)
+            xg, xso = head(p, boxes)
+            hm, iou = outp(xg, xso)
+            out["m_grid_feat_%d" % s] = xg.numpy()[:, ::16]
+            out["m_grid_heat_%d" % s] = hm["unfused"].numpy()
+            if iou is not None:
+                out["m_grid_iou_%d" % s] = iou.numpy()
+    # gradient golden for the grid stage 2 + cls head (small): d(sum of squares)/d(weights) checksums
+    model.train()
+    for q in model.parameters():
+        if q.grad is not None:
+            q.grad = None
+    x = torch.from_numpy(img)
+    c = model.Conv_Body(x)
+    p = model.Conv_Body_FPN(c)
+    xg, xso = g.Head_grid_2(p, boxes)
+    hm, iou = g.Output_grid_2(xg, xso)
+    loss = (hm["unfused"] ** 2).mean() + (iou ** 2).mean() + (g.Output_cls(g.Head_cls(p, boxes)) ** 2).mean()
+    lo, br = model.RPN.head(p)
+    loss = loss + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)
+    loss.backward()
+    out["m_loss"] = loss.detach().numpy()
+    grads = {}
+    for k, q in model.named_parameters():
+        if q.grad is not None:
+            gsum = q.grad.double()
+            grads[k] = [float(gsum.sum()), float(gsum.abs().sum()), float((gsum ** 2).sum())]
+    meta["grad_stats"] = grads
+    for k in ("Conv_Body.layer2.0.conv1.weight", "Conv_Body.layer4.2.conv3.weight", "Conv_Body_FPN.fpn_out.2.weight",
+              "RPN.head.conv.weight", "Grid_Cascade_RCNN.Head_grid_2.convs.0.0.weight",
+              "Grid_Cascade_RCNN.Head_grid_2.convs.7.1.weight", "Grid_Cascade_RCNN.Output_grid_2.deconv_1.weight",
+              "Grid_Cascade_RCNN.Output_grid_2.deconv_2.weight", "Grid_Cascade_RCNN.Output_grid_2.norm1.weight",
+              "Grid_Cascade_RCNN.Output_grid_2.iou_pred.weight", "Grid_Cascade_RCNN.Output_cls.cls_score.weight"):
+        gq = dict(model.named_parameters())[k].grad
+        out["m_grad::" + k] = gq.numpy().reshape(-1)[::max(1, gq.numel() // 4096)]
+
+
+def main():
+    ref_ext = build_ref()
+    assert ref_ext is not None, "needs /root/reference"
+    install_standins(ref_ext)
+    cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
+    cfg.DEVICE = "cpu"
+    ops = {}
+    gen_ops(ref_ext, ops)
+    gen_grid(ops)
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **ops)
+    model, meta = {}, {}
+    gen_model(model, meta)
+    np.savez_compressed(os.path.join(HERE, "model_r50.npz"), **model)
+    with open(os.path.join(HERE, "model_r50_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("ops:", len(ops), "arrays; model:", len(model), "arrays")
+
+
+if __name__ == "__main__":
+    main()
