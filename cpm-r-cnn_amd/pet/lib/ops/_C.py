@@ -1,0 +1,170 @@
+"""Host-side mirror of the reference's pybind module `pet.lib.ops._C`
+(pet/lib/ops/csrc/vision.cpp:20-48): same function names, argument order and error behaviour,
+implemented over the C ABI in include/cpmrcnn_hip.h.  Tensors must live on the GPU.
+
+Layout note: inputs are accepted in either memory format.  A channels_last (NHWC) input takes
+the coalesced NHWC kernels and produces a channels_last result; a contiguous NCHW input takes
+the NCHW kernels (the reference's layout).  Logical shapes are always [N,C,H,W].
+"""
+import ctypes
+
+import torch
+
+from . import _hip as H
+
+
+def _is_nhwc(t):
+    # when both hold (C == 1 or H == W == 1) the two layouts are the same bytes: call it NCHW
+    return t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last) and not t.is_contiguous()
+
+
+def _check_same(a, b, what):
+    if a.dtype != b.dtype or a.device != b.device:
+        raise RuntimeError("%s: expected tensors of the same type and device" % what)   # checkAllSameType/GPU
+
+
+def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, sampling_ratio, aligned,
+                      interpolation_method):
+    """ROIAlign.h:57-95.  Returns a freshly allocated [K,C,PH,PW] tensor (caller owns)."""
+    H.require_gpu(input, rois)
+    _check_same(input, rois, "ROIAlign_forward")
+    if interpolation_method not in (0, 1):
+        raise RuntimeError("interpolation must be bilinear or nearest")
+    if rois.dim() != 2 or rois.size(1) != 5:
+        raise RuntimeError("rois must be [K,5]")
+    B, C, Hh, W = input.shape
+    K = rois.size(0)
+    nhwc = _is_nhwc(input)
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    x = input if nhwc else input.contiguous()
+    out = torch.empty((K, C, pooled_height, pooled_width), dtype=input.dtype, device=input.device, memory_format=fmt)
+    if K == 0:
+        return out
+    r = rois.contiguous()
+    with torch.cuda.device(input.device):
+        rc = H.lib().cpm_roi_align_forward(H.ptr(x), H.ptr(r), K, B, C, Hh, W, H.f(spatial_scale),
+                                           int(pooled_height), int(pooled_width), int(sampling_ratio),
+                                           int(bool(aligned)), int(interpolation_method), 1 if nhwc else 0,
+                                           H.ptr(out), H.stream())
+    H.check(rc, "roi_align_forward")
+    return out
+
+
+def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, batch_size, channels, height, width,
+                       sampling_ratio, aligned, interpolation_method):
+    """ROIAlign.h:97-146.  Returns grad_input [B,C,H,W] in grad's memory format."""
+    H.require_gpu(grad, rois)
+    _check_same(grad, rois, "ROIAlign_backward")
+    if interpolation_method not in (0, 1):
+        raise RuntimeError("interpolation must be bilinear or nearest")
+    nhwc = _is_nhwc(grad)
+    fmt = torch.channels_last if nhwc else torch.contiguous_format
+    g = grad if nhwc else grad.contiguous()      # (reference quirk 5: it mixes strides; we always densify)
+    gin = torch.empty((batch_size, channels, height, width), dtype=grad.dtype, device=grad.device,
+                      memory_format=fmt).zero_()
+    K = rois.size(0)
+    if K == 0 or grad.numel() == 0:
+        return gin
+    r = rois.contiguous()
+    with torch.cuda.device(grad.device):
+        rc = H.lib().cpm_roi_align_backward(H.ptr(g), H.ptr(r), K, int(batch_size), int(channels), int(height),
+                                            int(width), H.f(spatial_scale), int(pooled_height), int(pooled_width),
+                                            int(sampling_ratio), int(bool(aligned)), int(interpolation_method),
+                                            1 if nhwc else 0, H.ptr(gin), H.stream())
+    H.check(rc, "roi_align_backward")
+    return gin
+
+
+def nms_segments(boxes, scores, labels, offsets, iou_threshold, topk=0):
+    """Batched device NMS over segments (host list `offsets`, len P+1).  Returns (keep, counts):
+    keep int64 [N] (segment-relative indices, valid in [off[p], off[p]+counts[p])), counts int32 [P] on device."""
+    H.require_gpu(boxes, scores, labels)
+    P = len(offsets) - 1
+    N = int(offsets[-1])
+    b = boxes.contiguous()
+    s = scores.contiguous()
+    lab = labels.contiguous() if labels is not None else None
+    if lab is not None and lab.dtype != torch.int64:
+        lab = lab.to(torch.int64)
+    off = (ctypes.c_int32 * (P + 1))(*[int(o) for o in offsets])
+    keep = torch.empty((max(N, 1),), dtype=torch.int64, device=boxes.device)
+    counts = torch.empty((P,), dtype=torch.int32, device=boxes.device)
+    with torch.cuda.device(boxes.device):
+        nbytes = H.lib().cpm_nms_workspace_bytes(off, P)
+        ws = H.workspace(nbytes, boxes.device)
+        rc = H.lib().cpm_nms_batched(H.ptr(b), H.ptr(s), H.ptr(lab), off, P, H.f(iou_threshold), int(topk),
+                                     H.ptr(keep), H.ptr(counts), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+    H.check(rc, "nms_batched")
+    return keep, counts
+
+
+def ml_nms(dets, scores, labels, iou_threshold, topk=0):
+    """ml_nms.h:16-39: indices into the input order, by descending score; N == 0 -> empty long."""
+    H.require_gpu(dets, scores, labels)
+    n = dets.size(0)
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dets.device)
+    keep, counts = nms_segments(dets, scores, labels, [0, n], iou_threshold, topk)
+    return keep[: int(counts.item())]
+
+
+def nms(dets, scores, iou_threshold):
+    """torchvision.ops.nms semantics (bound at pet/lib/ops/nms.py:2,10)."""
+    H.require_gpu(dets, scores)
+    n = dets.size(0)
+    if n == 0:
+        return torch.empty((0,), dtype=torch.int64, device=dets.device)
+    keep, counts = nms_segments(dets, scores, None, [0, n], iou_threshold, 0)
+    return keep[: int(counts.item())]
+
+
+def box_iou(boxes, query_boxes):
+    """box_iou.h:13-30: dense [N,K] IoU, areas without +1."""
+    H.require_gpu(boxes, query_boxes)
+    N, K = boxes.size(0), query_boxes.size(0)
+    out = torch.empty((N, K), dtype=torch.float32, device=boxes.device)
+    with torch.cuda.device(boxes.device):
+        rc = H.lib().cpm_box_iou(H.ptr(boxes.contiguous()), N, H.ptr(query_boxes.contiguous()), K, H.ptr(out),
+                                 H.stream())
+    H.check(rc, "box_iou")
+    return out
+
+
+def pool_points_interp_forward(input, rois, spatial_scale):
+    """PoolPointsInterp.h:23-40: [B,C,H,W] sampled at K (idx,x,y) points -> [K,C]."""
+    H.require_gpu(input, rois)
+    B, C, Hh, W = input.shape
+    K = rois.size(0)
+    out = torch.empty((K, C), dtype=torch.float32, device=input.device)
+    with torch.cuda.device(input.device):
+        rc = H.lib().cpm_pool_points_interp_forward(H.ptr(input.contiguous()), H.ptr(rois.contiguous()), K, B, C, Hh,
+                                                    W, H.f(spatial_scale), H.ptr(out), H.stream())
+    H.check(rc, "pool_points_interp_forward")
+    return out
+
+
+def pool_points_interp_backward(grad, rois, spatial_scale, batch_size, channels, height, width):
+    """PoolPointsInterp.h:42-62."""
+    H.require_gpu(grad, rois)
+    K = rois.size(0)
+    gin = torch.zeros((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
+    with torch.cuda.device(grad.device):
+        rc = H.lib().cpm_pool_points_interp_backward(H.ptr(grad.contiguous()), H.ptr(rois.contiguous()), K,
+                                                     int(batch_size), int(channels), int(height), int(width),
+                                                     H.f(spatial_scale), H.ptr(gin), H.stream())
+    H.check(rc, "pool_points_interp_backward")
+    return gin
+
+
+def _not_on_hot_path(name):
+    def fn(*a, **k):
+        raise RuntimeError("_C.%s is outside the CPM R-CNN hot path and is not provided by cpm-r-cnn_amd" % name)
+    fn.__name__ = name
+    return fn
+
+
+# names bound by vision.cpp:21-47 that no BASELINE config reaches (out of scope)
+for _n in ("soft_nms", "ml_soft_nms", "nms_rotated", "poly_nms", "box_voting", "box_ml_voting", "box_iou_rotated",
+           "roi_align_rotated_forward", "roi_align_rotated_backward", "roi_pool_forward", "roi_pool_backward",
+           "sigmoid_focalloss_forward", "sigmoid_focalloss_backward"):
+    globals()[_n] = _not_on_hot_path(_n)

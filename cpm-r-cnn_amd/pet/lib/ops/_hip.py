@@ -1,0 +1,85 @@
+"""ctypes binding of libcpmrcnn_hip.so -- the only bridge between Python and the HIP kernels.
+
+There is deliberately no CPU fallback: if the library is missing, or a tensor is not resident on
+an MI355X, every op raises RuntimeError (the reference's AT_ASSERTM behaviour).
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libcpmrcnn_hip.so")
+_lib = None
+_lock = threading.Lock()
+
+c_int, c_float, c_void_p, c_size_t, c_int64 = ctypes.c_int, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, \
+    ctypes.c_int64
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "C", "K", "R", "S", "stride", "pad", "dilation", "groups", "P",
+                                     "Q")]
+
+
+def lib():
+    """Load (once) and return the C-ABI library; raises if it was not built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError("libcpmrcnn_hip.so not built: run `python cpm-r-cnn_amd/build.py` "
+                                       "(or __graft_entry__.build()); there is no CPU fallback")
+                # make sure the HIP runtime torch already loaded is the one we bind to
+                tl = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+                if os.path.exists(tl):
+                    ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
+                L = ctypes.CDLL(LIB_PATH)
+                L.cpm_last_error.restype = ctypes.c_char_p
+                for name in ("cpm_nms_workspace_bytes", "cpm_conv2d_workspace_bytes", "cpm_stem_workspace_bytes"):
+                    getattr(L, name).restype = c_size_t
+                _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().cpm_last_error().decode()))
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("cpm-r-cnn_amd ops run on MI355X only: got a %s tensor (no CPU fallback)" % t.device)
+        if t.dtype not in (torch.float32, torch.int64, torch.int32):
+            raise RuntimeError("unsupported dtype %s (ops are fp32-only, like the reference's amp.float_function)"
+                               % t.dtype)
+
+
+def ptr(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def f(x):
+    return c_float(float(x))
+
+
+_ws = {}
+
+
+def workspace(nbytes, device):
+    """A grow-only scratch buffer per (device, stream); callers never hold it across ops."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

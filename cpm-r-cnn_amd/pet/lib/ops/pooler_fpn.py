@@ -1,0 +1,82 @@
+"""Fused multi-level RoIAlign: LevelMapper + per-level RoIAlign + scatter in ONE launch.
+
+Replaces the loop in Pooler.forward (pet/rcnn/utils/poolers.py:113-132: 4 `nonzero` syncs, 4 gathers,
+4 RoIAlign launches, 4 scatters) with cpm_roi_align_fpn_{forward,backward}.  Feature maps are NHWC.
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip as H
+
+
+def _tables(feats, scales):
+    n = len(feats)
+    hs = (ctypes.c_int * n)(*[int(f.shape[2]) for f in feats])
+    ws = (ctypes.c_int * n)(*[int(f.shape[3]) for f in feats])
+    sc = (ctypes.c_float * n)(*[float(s) for s in scales])
+    return hs, ws, sc
+
+
+def _nhwc(t):
+    return t if (t.is_contiguous(memory_format=torch.channels_last)) else t.contiguous(
+        memory_format=torch.channels_last)
+
+
+class _RoIAlignFPN(Function):
+    @staticmethod
+    def forward(ctx, rois, output_size, scales, sampling_ratio, lvl_min, lvl_max, canonical, *feats):
+        H.require_gpu(rois, *feats)
+        feats = [_nhwc(f) for f in feats]
+        B, C = feats[0].shape[:2]
+        K = rois.shape[0]
+        ph, pw = output_size
+        out = torch.empty((K, C, ph, pw), dtype=torch.float32, device=rois.device,
+                          memory_format=torch.channels_last)
+        levels = torch.empty((max(K, 1),), dtype=torch.int32, device=rois.device)
+        r = rois.contiguous().float()
+        n = len(feats)
+        hs, ws, sc = _tables(feats, scales)
+        ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
+        s0, l0, eps = canonical
+        with torch.cuda.device(rois.device):
+            rc = H.lib().cpm_roi_align_fpn_forward(ptrs, hs, ws, sc, n, H.ptr(r), K, int(B), int(C), ph, pw,
+                                                   int(sampling_ratio), H.f(lvl_min), H.f(lvl_max), H.f(s0),
+                                                   H.f(l0), H.f(eps), H.ptr(out), H.ptr(levels), H.stream())
+        H.check(rc, "roi_align_fpn_forward")
+        ctx.save_for_backward(r)
+        ctx.meta = (output_size, tuple(float(s) for s in scales), int(sampling_ratio), lvl_min, lvl_max, canonical,
+                    [tuple(f.shape) for f in feats])
+        ctx.mark_non_differentiable(levels)
+        return out, levels[:K]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_out, _):
+        r, = ctx.saved_tensors
+        (ph, pw), scales, ratio, lvl_min, lvl_max, (s0, l0, eps), shapes = ctx.meta
+        g = _nhwc(grad_out)
+        grads = [torch.empty(s, dtype=torch.float32, device=g.device, memory_format=torch.channels_last).zero_()
+                 for s in shapes]
+        n = len(grads)
+        hs, ws, sc = _tables(grads, scales)
+        ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
+        K = r.shape[0]
+        with torch.cuda.device(g.device):
+            rc = H.lib().cpm_roi_align_fpn_backward(H.ptr(g), ptrs, hs, ws, sc, n, H.ptr(r), K, int(shapes[0][0]),
+                                                    int(shapes[0][1]), ph, pw, ratio, H.f(lvl_min), H.f(lvl_max),
+                                                    H.f(s0), H.f(l0), H.f(eps), H.stream())
+        H.check(rc, "roi_align_fpn_backward")
+        return (None, None, None, None, None, None, None) + tuple(grads)
+
+
+def roi_align_fpn(feats, rois, output_size, scales, sampling_ratio, canonical_scale=224, canonical_level=4,
+                  eps=1e-6, return_levels=False):
+    """feats: list of [B,C,H_l,W_l]; rois [K,5].  Level range follows poolers.py:84-88 (-log2 of the scales)."""
+    lvl_min = -float(torch.log2(torch.tensor(float(scales[0]), dtype=torch.float32)))
+    lvl_max = -float(torch.log2(torch.tensor(float(scales[len(feats) - 1]), dtype=torch.float32)))
+    out, levels = _RoIAlignFPN.apply(rois, tuple(output_size), tuple(scales), sampling_ratio, lvl_min, lvl_max,
+                                     (float(canonical_scale), float(canonical_level), float(eps)), *feats)
+    return (out, levels) if return_levels else out

@@ -1,0 +1,174 @@
+/*
+ * cpmrcnn_hip.h -- C ABI of libcpmrcnn_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary for the reference's native extension
+ * `pet.lib.ops._C` (pybind module: pet/lib/ops/csrc/vision.cpp:20-48) and for the
+ * ATen/cuDNN calls the reference's Python modules make on the hot path.  Every
+ * entry point takes plain device pointers, sizes and a HIP stream; there are no
+ * torch types.  All functions return 0 on success, a negative CPM_E* code on an
+ * argument error (the host wrapper raises RuntimeError, as AT_ASSERTM did) and
+ * never synchronise the device.  `stream` is a hipStream_t passed as void*.
+ *
+ * Tensor layouts: "NCHW" is the reference's; "NHWC" is our resident layout
+ * (torch channels_last: same logical shape, C fastest in memory).
+ */
+#ifndef CPMRCNN_HIP_H
+#define CPMRCNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPM_OK 0
+#define CPM_EINVAL (-1)      /* bad argument (shape, enum, null pointer) */
+#define CPM_EWORKSPACE (-2)  /* workspace too small */
+#define CPM_ELAUNCH (-3)     /* hipLaunch failed (see cpm_last_error) */
+
+#define CPM_LAYOUT_NCHW 0
+#define CPM_LAYOUT_NHWC 1
+
+/* library / device info ---------------------------------------------------- */
+int cpm_abi_version(void);
+const char* cpm_last_error(void);
+
+/* ---- RoIAlign ------------------------------------------------------------
+ * Replaces _C.roi_align_forward / _C.roi_align_backward
+ * (pet/lib/ops/csrc/ROIAlign/ROIAlign.h:57-146, ROIAlign_cuda.cu:178-487).
+ * input [B,C,H,W], rois [K,5]=(batch,x1,y1,x2,y2), output [K,C,PH,PW] in `layout`.
+ * interp: 0 bilinear, 1 nearest.  backward ACCUMULATES into grad_input (caller
+ * zeroes it; the reference allocates zeros, ROIAlign_cuda.cu:447).            */
+int cpm_roi_align_forward(const float* input, const float* rois, int K, int B, int C, int H, int W,
+                          float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                          int interp, int layout, float* output, void* stream);
+int cpm_roi_align_backward(const float* grad_output, const float* rois, int K, int B, int C, int H, int W,
+                           float spatial_scale, int pooled_h, int pooled_w, int sampling_ratio, int aligned,
+                           int interp, int layout, float* grad_input, void* stream);
+
+/* Fused multi-level pooler: replaces Pooler.forward + LevelMapper
+ * (pet/rcnn/utils/poolers.py:9-40,90-132): one launch for all FPN levels, the
+ * level of each RoI computed in-kernel, result written in RoI order (NHWC).
+ * feats/grad_feats: host array of `num_levels` device pointers [B,H_l,W_l,C];
+ * hs/ws/scales: host arrays.  levels_out (device int32 [K], may be NULL).    */
+int cpm_roi_align_fpn_forward(const float* const* feats, const int* hs, const int* ws, const float* scales,
+                              int num_levels, const float* rois, int K, int B, int C, int pooled_h, int pooled_w,
+                              int sampling_ratio, float k_min, float k_max, float canonical_scale,
+                              float canonical_level, float eps, float* output, int32_t* levels_out, void* stream);
+int cpm_roi_align_fpn_backward(const float* grad_output, float* const* grad_feats, const int* hs, const int* ws,
+                               const float* scales, int num_levels, const float* rois, int K, int B, int C,
+                               int pooled_h, int pooled_w, int sampling_ratio, float k_min, float k_max,
+                               float canonical_scale, float canonical_level, float eps, void* stream);
+
+/* ---- NMS -------------------------------------------------------------------
+ * Replaces torchvision.ops.nms as bound at pet/lib/ops/nms.py:2,10 (labels ==
+ * NULL) and _C.ml_nms (pet/lib/ops/csrc/NMS/ml_nms.h:16-39, ml_nms.cu:11-146).
+ * Batched over P independent segments (e.g. image x FPN level): segment p covers
+ * rows [h_offsets[p], h_offsets[p+1]) of boxes/scores/labels (h_offsets is a
+ * HOST array).  Per segment: stable sort by score descending, greedy suppression
+ * of same-label boxes with IoU > thr (areas without +1), at most `topk` kept
+ * (0 = unlimited).  keep [total] receives, for segment p at keep+h_offsets[p],
+ * the kept row indices RELATIVE to the segment start in descending-score order;
+ * keep_count [P] (device) the number kept.  Sort + mask + sweep all run on the
+ * device (no D2H mask copy as in ml_nms.cu:117).                               */
+size_t cpm_nms_workspace_bytes(const int32_t* h_offsets, int P);
+int cpm_nms_batched(const float* boxes, const float* scores, const int64_t* labels, const int32_t* h_offsets,
+                    int P, float iou_threshold, int topk, int64_t* keep, int32_t* keep_count, void* workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* box_iou: replaces _C.box_iou (pet/lib/ops/csrc/Box_ops/box_iou.h:13-30). out [N,K], no +1 */
+int cpm_box_iou(const float* boxes, int N, const float* query, int K, float* out, void* stream);
+
+/* PoolPointsInterp: replaces _C.pool_points_interp_{forward,backward}
+ * (pet/lib/ops/csrc/PoolPointsInterp/PoolPointsInterp.h:23-62); NCHW, pts [K,3],
+ * batch index = k / 196 as in PoolPointsInterp_cuda.cu:74.  backward accumulates. */
+int cpm_pool_points_interp_forward(const float* input, const float* pts, int K, int B, int C, int H, int W,
+                                   float spatial_scale, float* output, void* stream);
+int cpm_pool_points_interp_backward(const float* grad_output, const float* pts, int K, int B, int C, int H, int W,
+                                    float spatial_scale, float* grad_input, void* stream);
+
+/* ---- Convolution (implicit GEMM on fp32 MFMA) ------------------------------
+ * Replaces the ATen/cuDNN conv2d / conv_transpose2d / linear calls made by
+ * nn.Conv2d, nn.Linear and nn.ConvTranspose2d in pet/models/imagenet/resnet.py:71-136,
+ * pet/rcnn/modeling/fpn/FPN.py:96-121, rpn/rpn.py:34-41, grid_rcnn/heads/{grid,cls}_heads.py,
+ * grid_rcnn/outputs.py:49-104.  All tensors NHWC fp32; weights KRSC
+ * ([K][R][S][C/groups], i.e. torch [K,C/g,R,S] in channels_last).
+ *
+ * cpm_conv2d_forward: y = epilogue(conv(x, w)), epilogue(v)[k] =
+ *     relu?( v*scale[k] + shift[k] + residual[m,k] )      (scale/shift/residual may be NULL)
+ *   covers conv+bias, conv+frozen AffineChannel2d (pet/lib/ops/affine.py:15-17),
+ *   +residual add +ReLU of Bottleneck.forward.
+ *   res_mode 0: residual has y's shape; 1: residual is [N,ceil(P/2),ceil(Q/2),K]
+ *   and is read at (p/2,q/2) (FPN nearest-2x top-down add, FPN.py:104-106).
+ * cpm_conv2d_backward_data: dx = conv^T(dy, w)  (also used as the forward of
+ *   nn.ConvTranspose2d); accumulate!=0 adds into dx.
+ * cpm_conv2d_backward_weight: dw += x (*) dy   (always accumulates: dw is a
+ *   slice of the flat gradient buffer zeroed once per step).
+ * split_k <= 0 lets the library choose.  Workspace: cpm_conv2d_workspace_bytes. */
+typedef struct {
+  int N, H, W, C;        /* input  [N,H,W,C]  */
+  int K, R, S;           /* weight [K,R,S,C/groups] */
+  int stride, pad, dilation, groups;
+  int P, Q;              /* output [N,P,Q,K]  */
+} cpm_conv_desc;
+
+size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d);
+int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,
+                       const float* shift, const float* residual, int res_mode, int relu, float* y,
+                       void* workspace, size_t workspace_bytes, void* stream);
+int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                             void* workspace, size_t workspace_bytes, void* stream);
+int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* dpre = dy * (y > 0 if relu) * scale[k]; optional dshift[k] += sum_m(dy*mask) (bias grads),
+ * optional dres = dy*mask (residual branch).  Elementwise helper of the fused epilogue's backward. */
+int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, int relu, int64_t M, int K,
+                          float* dpre, float* dshift, void* stream);
+
+/* 7x7/s2 stem on 3 channels + 3x3/s2 max-pool (ResNet.forward, backbone/ResNet.py:123-135): frozen, fwd only */
+int cpm_stem_forward(const float* x_nchw_or_nhwc, int layout, int N, int H, int W, const float* w_krsc,
+                     const float* scale, const float* shift, float* y_conv, float* y_pool, void* workspace,
+                     size_t workspace_bytes, void* stream);
+size_t cpm_stem_workspace_bytes(int N, int H, int W);
+int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, float* y, void* stream);
+
+/* ---- GroupNorm (+ReLU), NHWC ----------------------------------------------
+ * Replaces nn.GroupNorm + nn.ReLU in grid_heads.py:47-55 and outputs.py:23,68.
+ * x [N,HW,C]; mean/rstd [N,G] saved for backward.                              */
+int cpm_groupnorm_forward(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G,
+                          float eps, int relu, float* y, float* mean, float* rstd, void* stream);
+int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, const float* gamma, const float* mean,
+                           const float* rstd, int N, int HW, int C, int G, int relu, float* dx, float* dgamma,
+                           float* dbeta, void* stream);
+
+/* ---- Grouped ConvTranspose2d k4 s2 p1 (outputs.py:24-37), NHWC, direct ------
+ * x [N,H,W,Cin], w torch layout [Cin][Cout/groups][4][4], y [N,2H,2W,Cout].     */
+int cpm_deconv4x4s2_forward(const float* x, const float* w, const float* bias, int N, int H, int W, int Cin,
+                            int Cout, int groups, float* y, void* stream);
+int cpm_deconv4x4s2_backward_data(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout,
+                                  int groups, float* dx, void* stream);
+int cpm_deconv4x4s2_backward_weight(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout,
+                                    int groups, float* dw, float* dbias, void* stream);
+
+/* ---- misc elementwise ------------------------------------------------------ */
+/* y[n,2p+a,2q+b,c] (clipped to [P,Q]) += x[n,p,q,c]  (FPN top-down backward) and forward add */
+int cpm_upsample2x_add(const float* top, const float* lateral, int N, int P, int Q, int C, float* y, void* stream);
+int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, void* stream);
+/* NCHW <-> NHWC */
+int cpm_permute_nchw_nhwc(const float* x, int N, int C, int H, int W, int to_nhwc, float* y, void* stream);
+
+/* ---- fused SGD with momentum over a flat parameter buffer -------------------
+ * Replaces torch.optim.SGD.step as built by pet/utils/optimizer.py:40-65 (3 param
+ * groups: weights / biases (lr x2, no wd) / GN).  seg_* are device arrays of
+ * `nseg` segments: [begin,end) element ranges with per-segment lr and weight decay.
+ * p -= lr * (mom = momentum*mom + (g*grad_scale + wd*p)).                        */
+int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int64_t* seg_begin,
+                 const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg, int64_t total,
+                 float momentum, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPMRCNN_HIP_H */
