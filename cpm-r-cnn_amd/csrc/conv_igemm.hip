@@ -1,0 +1,662 @@
+// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NHWC, gfx950.
+//
+// One kernel family serves conv2d forward, its data gradient (also = ConvTranspose2d forward) and
+// nn.Linear (a 1x1 conv on a 1x1 image); a second one serves the weight gradient.
+//
+//   out[m][oc] = sum_{tap=(r,s)} sum_{c} in[gather(m, tap)][c] * Wm[oc][tap][c]
+//
+//   * GEMM rows m = (n, oh, ow) output pixels, columns oc output channels, reduction (tap, c).
+//   * gather, FWD  : ih = oh*stride - pad + r*dil            (zero outside the image)
+//     gather, DGRAD: th = oh + pad - r*dil, ih = th/stride   (zero unless stride | th, in range)
+//     DGRAD uses the weight re-laid as Wm[c][r][s][k] (transform kernel below), so that both modes
+//     read the B operand as "row = output channel, 32 consecutive reduction elements".
+//   * workgroup = 256 threads = 4 waves (one per SIMD), tile BM x BN x 32, waves in a WM x WN grid,
+//     each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  fp32 in / fp32 accumulate: results are
+//     an exact-fp32 fmaf chain per output (north_star tolerance 1e-3 holds with large margin).
+//   * LDS: A[2][BM][36], B[2][BN][36] floats; the 36-float row pitch (144 B) makes every
+//     ds_read_b128 of a 16-lane group hit 16 distinct 16-B slots (bank = dword mod 64).
+//     A lane reads 4 consecutive k for its row with ONE ds_read_b128 and feeds 4 MFMAs with them:
+//     the MFMA's two k-slots (lane>>5) therefore hold k = {j, 4+j} -- a permutation of the
+//     reduction order applied identically to A and B, which leaves the sum unchanged.
+//   * global->LDS through registers, issued one k-step ahead (loads for step t+1 are in flight while
+//     step t's 16..64 MFMAs run), one barrier per k-step, 2 workgroups per CU.
+//   * epilogue fused: per-channel scale/shift (bias or frozen AffineChannel2d), residual add
+//     (same-shape or nearest-2x-upsampled, the FPN top-down path) and ReLU.
+//   * split-K (grid.z) for skinny problems (FC layers, small RoI counts): partial sums are added with
+//     float atomics into a zeroed output and the epilogue runs as a second tiny kernel.
+//
+// Reference call sites replaced: see include/cpmrcnn_hip.h (conv section).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDP = 36;  // LDS row pitch in floats
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1 };
+
+struct IgemmArgs {
+  const float* in;     // [N][IH][IW][Ctot]
+  const float* wm;     // [OCtot][R][S][CgR]
+  float* out;          // [M][OCtot]
+  const float* scale;  // [OCtot] or null
+  const float* shift;  // [OCtot] or null
+  const float* res;    // residual or null
+  int N, IH, IW, Ctot;
+  int OH, OW, OCtot;
+  int R, S, stride, pad, dil;
+  int groups, CgR, OCg;
+  int M;               // N*OH*OW
+  int ksteps_per_tap;  // ceil(CgR/32)
+  int ksteps;          // R*S*ksteps_per_tap
+  int split_k;         // >= 1
+  int res_mode, relu;
+  int atomic_out;      // 1: atomicAdd raw accumulators (split-K)
+};
+
+template <int BM, int BN, int WM, int WN, int MODE, bool VEC>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;   // MFMA tiles per wave
+  constexpr int AP = BM / 32, BP = BN / 32;     // load passes (32 rows per pass)
+  static_assert(WM * WN == 4 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.OCg + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int g = blockIdx.y;
+  const int split = blockIdx.z;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread load geometry --------------------------------------------------------------
+  const int lrow = tid >> 3;        // 0..31
+  const int lcol = (tid & 7) * 4;   // 0,4,..,28
+  int a_base[AP], a_h[AP], a_w[AP];
+  bool a_ok[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + i * 32 + lrow;
+    a_ok[i] = m < a.M;
+    const int mm = a_ok[i] ? m : 0;
+    const int ow = mm % a.OW, t = mm / a.OW;
+    const int oh = t % a.OH, n = t / a.OH;
+    if (MODE == MODE_FWD) {
+      a_h[i] = oh * a.stride - a.pad;
+      a_w[i] = ow * a.stride - a.pad;
+      a_base[i] = ((n * a.IH + a_h[i]) * a.IW + a_w[i]) * a.Ctot + g * a.CgR;
+    } else {
+      a_h[i] = oh + a.pad;
+      a_w[i] = ow + a.pad;
+      a_base[i] = n * a.IH * a.IW * a.Ctot + g * a.CgR;
+    }
+  }
+  int b_base[BP];
+  bool b_ok[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int oc = n0 + i * 32 + lrow;
+    b_ok[i] = oc < a.OCg;
+    b_base[i] = (g * a.OCg + (b_ok[i] ? oc : 0)) * a.R * a.S * a.CgR;
+  }
+
+  // k-step range of this split
+  const int per = (a.ksteps + a.split_k - 1) / a.split_k;
+  const int k_begin = split * per;
+  const int k_end = min(a.ksteps, k_begin + per);
+  const int nk = k_end - k_begin;
+
+  float4 ra[AP], rb[BP];
+
+  auto load_tile = [&](int kt) {
+    const int tap = kt / a.ksteps_per_tap;
+    const int c0 = (kt - tap * a.ksteps_per_tap) * BK + lcol;
+    const int r = tap / a.S, s = tap - r * a.S;
+    const bool c_ok = c0 < a.CgR;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      bool ok = a_ok[i] && c_ok;
+      int off;
+      if (MODE == MODE_FWD) {
+        const int ih = a_h[i] + r * a.dil, iw = a_w[i] + s * a.dil;
+        ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+        off = a_base[i] + (r * a.dil * a.IW + s * a.dil) * a.Ctot + c0;
+      } else {
+        const int th = a_h[i] - r * a.dil, tw = a_w[i] - s * a.dil;
+        int ih = th, iw = tw;
+        if (a.stride > 1) {
+          ok = ok && th >= 0 && tw >= 0 && (th % a.stride) == 0 && (tw % a.stride) == 0;
+          ih = th / a.stride; iw = tw / a.stride;
+        }
+        ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+        off = a_base[i] + (ih * a.IW + iw) * a.Ctot + c0;
+      }
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        if (VEC) {
+          v = *(const float4*)(a.in + off);
+        } else {
+          v.x = a.in[off];
+          if (c0 + 1 < a.CgR) v.y = a.in[off + 1];
+          if (c0 + 2 < a.CgR) v.z = a.in[off + 2];
+          if (c0 + 3 < a.CgR) v.w = a.in[off + 3];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (b_ok[i] && c_ok) {
+        const int off = b_base[i] + tap * a.CgR + c0;
+        if (VEC) {
+          v = *(const float4*)(a.wm + off);
+        } else {
+          v.x = a.wm[off];
+          if (c0 + 1 < a.CgR) v.y = a.wm[off + 1];
+          if (c0 + 2 < a.CgR) v.z = a.wm[off + 2];
+          if (c0 + 3 < a.CgR) v.w = a.wm[off + 3];
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *(float4*)&As[buf][i * 32 + lrow][lcol] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *(float4*)&Bs[buf][i * 32 + lrow][lcol] = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nk > 0) {
+    load_tile(k_begin);
+    store_tile(0);
+  }
+  __syncthreads();
+
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  int cur = 0;
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) load_tile(k_begin + it + 1);
+#pragma unroll
+    for (int kb = 0; kb < BK / 8; ++kb) {
+      float4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *(const float4*)&As[cur][wm * WTM + i * 32 + frow][kb * 8 + fk];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = *(const float4*)&Bs[cur][wn * WTN + j * 32 + frow][kb * 8 + fk];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].x, fb[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].y, fb[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (it + 1 < nk) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ocl = n0 + wn * WTN + j * 32 + ecol;
+    if (ocl >= a.OCg) continue;
+    const int oc = g * a.OCg + ocl;
+    const float sc = (!a.atomic_out && a.scale) ? a.scale[oc] : 1.f;
+    const float sh = (!a.atomic_out && a.shift) ? a.shift[oc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+        if (m >= a.M) continue;
+        float v = acc[i][j][e];
+        float* dst = a.out + (size_t)m * a.OCtot + oc;
+        if (a.atomic_out) {
+          atomicAdd(dst, v);
+        } else {
+          v = v * sc + sh;
+          if (a.res) {
+            if (a.res_mode == 0) {
+              v += a.res[(size_t)m * a.OCtot + oc];
+            } else {
+              const int ow = m % a.OW, t = m / a.OW;
+              const int oh = t % a.OH, n = t / a.OH;
+              const int rh = (a.OH + 1) / 2, rw = (a.OW + 1) / 2;
+              v += a.res[((size_t)(n * rh + oh / 2) * rw + ow / 2) * a.OCtot + oc];
+            }
+          }
+          if (a.relu) v = fmaxf(v, 0.f);
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
+// epilogue as a separate pass (after split-K atomics)
+__global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ res, int64_t M, int OC,
+                                int OH, int OW, int res_mode, int relu) {
+  const int64_t total = M * OC;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int oc = idx % OC;
+    const int64_t m = idx / OC;
+    float v = out[idx];
+    v = v * (scale ? scale[oc] : 1.f) + (shift ? shift[oc] : 0.f);
+    if (res) {
+      if (res_mode == 0) {
+        v += res[idx];
+      } else {
+        const int ow = m % OW;
+        const int64_t t = m / OW;
+        const int oh = t % OH;
+        const int64_t n = t / OH;
+        const int rh = (OH + 1) / 2, rw = (OW + 1) / 2;
+        v += res[((n * rh + oh / 2) * rw + ow / 2) * OC + oc];
+      }
+    }
+    if (relu) v = fmaxf(v, 0.f);
+    out[idx] = v;
+  }
+}
+
+// KRSC [K][R][S][Cg] (K = groups*Kg)  ->  DGRAD operand [groups*Cg][R][S][Kg]
+__global__ void weight_to_dgrad(const float* __restrict__ w, int groups, int Kg, int RS, int Cg,
+                                float* __restrict__ wt) {
+  const int64_t total = (int64_t)groups * Kg * RS * Cg;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    // idx enumerates the destination: (((g*Cg + c)*RS + t)*Kg + k)
+    const int k = idx % Kg;
+    int64_t r = idx / Kg;
+    const int t = r % RS;
+    r /= RS;
+    const int c = r % Cg;
+    const int g = r / Cg;
+    wt[idx] = w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c];
+  }
+}
+
+// ---- weight gradient ---------------------------------------------------------------------------------
+// dw[oc][tap][c] += sum_m dy[m][oc] * x[gather(m, tap)][c]
+// tile: BM output channels x BN input channels for ONE tap; reduction over pixels in chunks of 32.
+// LDS holds the two operands pixel-major ([32][BM+4], [32][BN+4]); a lane's MFMA operand is one
+// ds_read_b32 at [pixel = 2*s + (lane>>5)][channel = lane & 31] (conflict-free: consecutive lanes,
+// consecutive dwords).
+struct WgradArgs {
+  const float* x;   // [N][IH][IW][Ctot]
+  const float* dy;  // [M][OCtot]
+  float* dw;        // [OCtot][R][S][Cg]
+  int N, IH, IW, Ctot, OH, OW, OCtot;
+  int R, S, stride, pad, dil, groups, Cg, OCg, M;
+  int split_k, chunks;  // chunks = ceil(M/32)
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int PA = BM + 4, PB = BN + 4;
+  constexpr int AV = BM / 4, BV = BN / 4;             // float4 per pixel row
+  constexpr int APASS = (32 * AV + 255) / 256, BPASS = (32 * BV + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float As[2][32][PA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][32][PB];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.Cg + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int tap = blockIdx.y;
+  const int r = tap / a.S, s = tap - r * a.S;
+  const int g = blockIdx.z / a.split_k, split = blockIdx.z % a.split_k;
+  const int oc0 = tile_m * BM, c0 = tile_n * BN;
+
+  const int per = (a.chunks + a.split_k - 1) / a.split_k;
+  const int ch_begin = split * per, ch_end = min(a.chunks, ch_begin + per);
+  const int nk = ch_end - ch_begin;
+
+  float4 ra[APASS], rb[BPASS];
+  const bool vec_a = (a.OCtot & 3) == 0 && (a.OCg & 3) == 0;
+  const bool vec_b = (a.Ctot & 3) == 0 && (a.Cg & 3) == 0;
+
+  auto load_chunk = [&](int ch) {
+    const int mbase = ch * 32;
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int id = tid + i * 256;
+      const int pr = id / AV, cv = (id % AV) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int m = mbase + pr;
+      if (pr < 32 && m < a.M) {
+        const int ocl = oc0 + cv;
+        const size_t off = (size_t)m * a.OCtot + g * a.OCg + ocl;
+        if (vec_a && ocl + 3 < a.OCg) {
+          v = *(const float4*)(a.dy + off);
+        } else {
+          if (ocl < a.OCg) v.x = a.dy[off];
+          if (ocl + 1 < a.OCg) v.y = a.dy[off + 1];
+          if (ocl + 2 < a.OCg) v.z = a.dy[off + 2];
+          if (ocl + 3 < a.OCg) v.w = a.dy[off + 3];
+        }
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int id = tid + i * 256;
+      const int pr = id / BV, cv = (id % BV) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const int m = mbase + pr;
+      if (pr < 32 && m < a.M) {
+        const int ow = m % a.OW, t = m / a.OW;
+        const int oh = t % a.OH, n = t / a.OH;
+        const int ih = oh * a.stride - a.pad + r * a.dil, iw = ow * a.stride - a.pad + s * a.dil;
+        if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
+          const int cl = c0 + cv;
+          const size_t off = ((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g * a.Cg + cl;
+          if (vec_b && cl + 3 < a.Cg) {
+            v = *(const float4*)(a.x + off);
+          } else {
+            if (cl < a.Cg) v.x = a.x[off];
+            if (cl + 1 < a.Cg) v.y = a.x[off + 1];
+            if (cl + 2 < a.Cg) v.z = a.x[off + 2];
+            if (cl + 3 < a.Cg) v.w = a.x[off + 3];
+          }
+        }
+      }
+      rb[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < APASS; ++i) {
+      const int id = tid + i * 256;
+      const int pr = id / AV, cv = (id % AV) * 4;
+      if (pr < 32) *(float4*)&As[buf][pr][cv] = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BPASS; ++i) {
+      const int id = tid + i * 256;
+      const int pr = id / BV, cv = (id % BV) * 4;
+      if (pr < 32) *(float4*)&Bs[buf][pr][cv] = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (nk > 0) {
+    load_chunk(ch_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  const int fc = lane & 31, fh = lane >> 5;
+  int cur = 0;
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) load_chunk(ch_begin + it + 1);
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      float fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = As[cur][2 * ks + fh][wm * WTM + i * 32 + fc];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = Bs[cur][2 * ks + fh][wn * WTN + j * 32 + fc];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    if (it + 1 < nk) store_chunk(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int cl = c0 + wn * WTN + j * 32 + ecol;
+    if (cl >= a.Cg) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int ocl = oc0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+        if (ocl >= a.OCg) continue;
+        atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl, acc[i][j][e]);
+      }
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+int num_cus() { return 256; }
+
+template <int MODE>
+int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+  const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
+                   (((uintptr_t)a.wm & 15) == 0);
+  auto tiles = [&](int bm, int bn) { return (int64_t)cpm::cdiv(a.M, bm) * cpm::cdiv(a.OCg, bn) * a.groups; };
+#define LAUNCH(BM, BN, WM, WN)                                                                                 \
+  do {                                                                                                         \
+    dim3 grid((unsigned)(cpm::cdiv(a.M, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);                     \
+    if (vec)                                                                                                   \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), 0, s, a);                \
+    else                                                                                                       \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), 0, s, a);               \
+  } while (0)
+  // tile choice: widest N tile that divides the channel count well, smaller M tile when the grid is thin
+  if (a.OCg <= 32) {
+    LAUNCH(128, 32, 4, 1);
+  } else if (a.OCg <= 64 || (a.OCg % 128 != 0 && a.OCg % 64 == 0)) {
+    if (tiles(128, 64) >= 2 * num_cus()) LAUNCH(128, 64, 2, 2);
+    else LAUNCH(64, 64, 2, 2);
+  } else {
+    if (tiles(128, 128) >= num_cus()) LAUNCH(128, 128, 2, 2);
+    else if (tiles(128, 64) >= num_cus()) LAUNCH(128, 64, 2, 2);
+    else LAUNCH(64, 64, 2, 2);
+  }
+#undef LAUNCH
+  return cpm::check_launch("conv igemm");
+}
+
+int pick_split_k(int64_t tiles, int ksteps) {
+  if (tiles >= 192 || ksteps < 32) return 1;
+  int want = (int)((2 * 256 + tiles - 1) / tiles);
+  int maxs = ksteps / 16;
+  int sk = want < maxs ? want : maxs;
+  if (sk < 1) sk = 1;
+  if (sk > 64) sk = 64;
+  return sk;
+}
+
+int validate(const cpm_conv_desc* d) {
+  if (!d) return CPM_EINVAL;
+  if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->R <= 0 || d->S <= 0) return CPM_EINVAL;
+  if (d->stride <= 0 || d->pad < 0 || d->dilation <= 0 || d->groups <= 0) return CPM_EINVAL;
+  if (d->C % d->groups || d->K % d->groups) return CPM_EINVAL;
+  const int P = (d->H + 2 * d->pad - d->dilation * (d->R - 1) - 1) / d->stride + 1;
+  const int Q = (d->W + 2 * d->pad - d->dilation * (d->S - 1) - 1) / d->stride + 1;
+  if (P != d->P || Q != d->Q) return CPM_EINVAL;
+  if ((int64_t)d->N * d->H * d->W * d->C >= (1ll << 31) || (int64_t)d->N * d->P * d->Q * d->K >= (1ll << 31) ||
+      (int64_t)d->K * d->R * d->S * (d->C / d->groups) >= (1ll << 31))
+    return CPM_EINVAL;
+  return CPM_OK;
+}
+
+size_t dgrad_weight_bytes(const cpm_conv_desc* d) {
+  return ((size_t)d->K * d->R * d->S * (d->C / d->groups) * sizeof(float) + 255) / 256 * 256;
+}
+
+}  // namespace
+
+CPM_EXPORT size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d) {
+  if (validate(d) != CPM_OK) return 0;
+  return dgrad_weight_bytes(d) + 256;
+}
+
+CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,
+                                  const float* shift, const float* residual, int res_mode, int relu, float* y,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && w && y, "null pointer");
+  CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
+  hipStream_t s = (hipStream_t)stream;
+  IgemmArgs a = {};
+  a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
+  a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C;
+  a.OH = d->P; a.OW = d->Q; a.OCtot = d->K;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dilation;
+  a.groups = d->groups; a.CgR = d->C / d->groups; a.OCg = d->K / d->groups;
+  a.M = d->N * d->P * d->Q;
+  a.ksteps_per_tap = cpm::cdiv(a.CgR, BK);
+  a.ksteps = d->R * d->S * a.ksteps_per_tap;
+  a.res_mode = res_mode; a.relu = relu;
+  const int64_t tiles = (int64_t)cpm::cdiv(a.M, 64) * cpm::cdiv(a.OCg, 64) * a.groups;
+  a.split_k = pick_split_k(tiles, a.ksteps);
+  a.atomic_out = a.split_k > 1;
+  if (a.atomic_out) {
+    if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
+  }
+  int rc = launch_igemm<MODE_FWD>(a, s);
+  if (rc != CPM_OK) return rc;
+  if (a.atomic_out && (scale || shift || residual || relu)) {
+    const int64_t total = (int64_t)a.M * a.OCtot;
+    int64_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, y, scale, shift,
+                       residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode, relu);
+    rc = cpm::check_launch("conv epilogue");
+  }
+  return rc;
+}
+
+static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
+                     const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
+                     const char* who) {
+  const size_t need = dgrad_weight_bytes(d);
+  if (!workspace || workspace_bytes < need) {
+    cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
+    return CPM_EWORKSPACE;
+  }
+  float* wt = (float*)workspace;
+  const int Cg = d->C / d->groups, Kg = d->K / d->groups;
+  {
+    const int64_t total = (int64_t)d->K * d->R * d->S * Cg;
+    int64_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(weight_to_dgrad, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, s, w, d->groups, Kg,
+                       d->R * d->S, Cg, wt);
+  }
+  IgemmArgs a = {};
+  a.in = dy; a.wm = wt; a.out = dx; a.shift = shift; a.relu = relu;
+  a.N = d->N; a.IH = d->P; a.IW = d->Q; a.Ctot = d->K;      // the GEMM's "input" is dy
+  a.OH = d->H; a.OW = d->W; a.OCtot = d->C;                 // its "output" is dx
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = 1;
+  a.groups = d->groups; a.CgR = Kg; a.OCg = Cg;
+  a.M = d->N * d->H * d->W;
+  a.ksteps_per_tap = cpm::cdiv(a.CgR, BK);
+  a.ksteps = d->R * d->S * a.ksteps_per_tap;
+  const int64_t tiles = (int64_t)cpm::cdiv(a.M, 64) * cpm::cdiv(a.OCg, 64) * a.groups;
+  a.split_k = pick_split_k(tiles, a.ksteps);
+  a.atomic_out = (a.split_k > 1) || accumulate;
+  if (a.atomic_out && !accumulate) {
+    if (hipMemsetAsync(dx, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
+  }
+  int rc = launch_igemm<MODE_DGRAD>(a, s);
+  if (rc != CPM_OK) return rc;
+  if (a.atomic_out && (shift || relu)) {
+    const int64_t total = (int64_t)a.M * a.OCtot;
+    int64_t b = (total + 255) / 256;
+    hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, dx,
+                       (const float*)nullptr, shift, (const float*)nullptr, (int64_t)a.M, a.OCtot, a.OH, a.OW, 0,
+                       relu);
+    rc = cpm::check_launch("dgrad epilogue");
+  }
+  return rc;
+}
+
+CPM_EXPORT int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy, const float* w, float* dx,
+                                        int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(dy && w && dx, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
+  return run_dgrad(d, dy, w, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
+                   "cpm_conv2d_backward_data");
+}
+
+CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float* x, const float* w,
+                                            const float* bias, int relu, float* y, void* workspace,
+                                            size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && w && y, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated transposed conv not implemented");
+  return run_dgrad(d, x, w, y, 0, bias, relu, workspace, workspace_bytes, (hipStream_t)stream,
+                   "cpm_conv_transpose2d_forward");
+}
+
+CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && dy && dw, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  WgradArgs a = {};
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C; a.OH = d->P; a.OW = d->Q; a.OCtot = d->K;
+  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dilation;
+  a.groups = d->groups; a.Cg = d->C / d->groups; a.OCg = d->K / d->groups;
+  a.M = d->N * d->P * d->Q;
+  a.chunks = cpm::cdiv(a.M, 32);
+  const int taps = d->R * d->S;
+  auto blocks = [&](int bm, int bn) {
+    return (int64_t)cpm::cdiv(a.OCg, bm) * cpm::cdiv(a.Cg, bn) * taps * a.groups;
+  };
+  auto split_for = [&](int64_t nb) {
+    int sk = (int)((3 * 256 + nb - 1) / nb);
+    const int maxs = a.chunks / 8 > 0 ? a.chunks / 8 : 1;
+    if (sk > maxs) sk = maxs;
+    if (sk < 1) sk = 1;
+    if (sk > 256) sk = 256;
+    return sk;
+  };
+#define WLAUNCH(BM, BN, WM, WN)                                                                      \
+  do {                                                                                               \
+    a.split_k = split_for(blocks(BM, BN));                                                           \
+    dim3 grid((unsigned)(cpm::cdiv(a.OCg, BM) * cpm::cdiv(a.Cg, BN)), taps, a.groups * a.split_k);  \
+    hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);                    \
+  } while (0)
+  if (a.OCg <= 32 || a.Cg <= 32) {
+    if (a.OCg <= 32 && a.Cg > 32) WLAUNCH(32, 128, 1, 4);
+    else if (a.Cg <= 32 && a.OCg > 32) WLAUNCH(128, 32, 4, 1);
+    else WLAUNCH(64, 64, 2, 2);
+  } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && blocks(128, 128) >= 128) {
+    WLAUNCH(128, 128, 2, 2);
+  } else {
+    WLAUNCH(64, 64, 2, 2);
+  }
+#undef WLAUNCH
+  return cpm::check_launch("conv wgrad");
+}

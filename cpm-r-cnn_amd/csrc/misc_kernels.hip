@@ -1,0 +1,315 @@
+// HBM-bound helper kernels of the conv/GN stacks: epilogue backward, im2col for the stem,
+// max-pool, GroupNorm(+ReLU) forward/backward, FPN top-down backward, fused SGD.  NHWC, fp32, gfx950.
+#include "common.h"
+
+namespace {
+
+int grid_for(int64_t total, int per_block = 256, int cap = 4096) {
+  int64_t b = (total + per_block - 1) / per_block;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- backward of the fused conv epilogue ---------------------------------------------------------------
+// y = relu?(conv*scale + shift [+ residual]).  dpre = dy * [y>0] * scale ; dshift[k] += sum_m dy*[y>0].
+// grid (ceil(K/64), slabs); block 256 = 4 waves; lane = channel, waves split the slab's rows.
+__global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                           const float* __restrict__ scale, int relu, int64_t M,
+                                                           int K, int rows_per_slab, float* __restrict__ dpre,
+                                                           float* __restrict__ dres, float* __restrict__ dshift) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int k = blockIdx.x * 64 + lane;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r1 = r0 + rows_per_slab < M ? r0 + rows_per_slab : M;
+  float acc = 0.f;
+  if (k < K) {
+    const float sc = scale ? scale[k] : 1.f;
+    for (int64_t m = r0 + wave; m < r1; m += 4) {
+      const int64_t idx = m * K + k;
+      float g = dy[idx];
+      if (relu && !(y[idx] > 0.f)) g = 0.f;
+      acc += g;
+      if (dres) dres[idx] = g;
+      if (dpre) dpre[idx] = g * sc;
+    }
+  }
+  if (dshift) {
+    part[wave][lane] = acc;
+    __syncthreads();
+    if (wave == 0 && k < K) atomicAdd(dshift + k, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+  }
+}
+
+// ---- im2col (thin-channel stem) --------------------------------------------------------------------------
+__global__ void im2col_kernel(const float* __restrict__ x, int layout, int N, int C, int H, int W, int R, int S,
+                              int stride, int pad, int P, int Q, int Kpad, float* __restrict__ out) {
+  const int64_t total = (int64_t)N * P * Q * Kpad;
+  const int K = R * S * C;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int col = idx % Kpad;
+    const int64_t m = idx / Kpad;
+    float v = 0.f;
+    if (col < K) {
+      const int c = col % C, t = col / C;
+      const int s = t % S, r = t / S;
+      const int q = m % Q;
+      const int64_t t2 = m / Q;
+      const int p = t2 % P, n = t2 / P;
+      const int ih = p * stride - pad + r, iw = q * stride - pad + s;
+      if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        v = layout == CPM_LAYOUT_NHWC ? x[(((int64_t)n * H + ih) * W + iw) * C + c]
+                                      : x[(((int64_t)n * C + c) * H + ih) * W + iw];
+    }
+    out[idx] = v;
+  }
+}
+
+// ---- 3x3 / stride 2 / pad 1 max-pool, NHWC (4 channels per thread) ---------------------------------------
+__global__ void maxpool_kernel(const float* __restrict__ x, int N, int H, int W, int C, int P, int Q,
+                               float* __restrict__ y) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * P * Q * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (idx % C4) * 4;
+    int64_t t = idx / C4;
+    const int q = t % Q; t /= Q;
+    const int p = t % P;
+    const int n = t / P;
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int r = 0; r < 3; ++r) {
+      const int ih = p * 2 - 1 + r;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int s = 0; s < 3; ++s) {
+        const int iw = q * 2 - 1 + s;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        const float4 v = *(const float4*)(x + (((int64_t)n * H + ih) * W + iw) * C + c);
+        m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+      }
+    }
+    *(float4*)(y + (((int64_t)n * P + p) * Q + q) * C + c) = m;
+  }
+}
+
+// ---- GroupNorm (+ReLU) ------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  // 256 threads
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 0) red[wave] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// grid (G, N), block 256: one workgroup per (sample, group); two-pass moments like a careful CPU loop
+__global__ __launch_bounds__(256) void gn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, int HW, int C, int G, float eps,
+                                                     int relu, float* __restrict__ y, float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out) {
+  __shared__ float red[4];
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int Cg = C / G;
+  const int cnt = HW * Cg;
+  const float* xb = x + (size_t)n * HW * C + g * Cg;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) s += xb[(size_t)(i / Cg) * C + (i % Cg)];
+  const float mean = block_sum(s, red) / (float)cnt;
+  float v = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const float d = xb[(size_t)(i / Cg) * C + (i % Cg)] - mean;
+    v += d * d;
+  }
+  const float var = block_sum(v, red) / (float)cnt;
+  const float rstd = 1.f / sqrtf(var + eps);
+  if (threadIdx.x == 0) {
+    mean_out[n * G + g] = mean;
+    rstd_out[n * G + g] = rstd;
+  }
+  float* yb = y + (size_t)n * HW * C + g * Cg;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int c = i % Cg;
+    const size_t off = (size_t)(i / Cg) * C + c;
+    float o = (xb[off] - mean) * rstd * gamma[g * Cg + c] + beta[g * Cg + c];
+    if (relu) o = fmaxf(o, 0.f);
+    yb[off] = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ y, const float* __restrict__ gamma,
+                                                     const float* __restrict__ mean_in,
+                                                     const float* __restrict__ rstd_in, int HW, int C, int G,
+                                                     int relu, float* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  __shared__ float red[4];
+  __shared__ float sg[256], sb[256];      // per-channel partials (Cg <= 256)
+  const int g = blockIdx.x, n = blockIdx.y;
+  const int Cg = C / G;
+  const int cnt = HW * Cg;
+  const size_t base = (size_t)n * HW * C + g * Cg;
+  const float mean = mean_in[n * G + g], rstd = rstd_in[n * G + g];
+  for (int i = threadIdx.x; i < Cg; i += 256) { sg[i] = 0.f; sb[i] = 0.f; }
+  __syncthreads();
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int c = i % Cg;
+    const size_t off = base + (size_t)(i / Cg) * C + c;
+    float go = dy[off];
+    if (relu && !(y[off] > 0.f)) go = 0.f;
+    const float xh = (x[off] - mean) * rstd;
+    const float dxh = go * gamma[g * Cg + c];
+    s1 += dxh;
+    s2 += dxh * xh;
+    atomicAdd(&sg[c], go * xh);
+    atomicAdd(&sb[c], go);
+  }
+  const float m1 = block_sum(s1, red) / (float)cnt;
+  const float m2 = block_sum(s2, red) / (float)cnt;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int c = i % Cg;
+    const size_t off = base + (size_t)(i / Cg) * C + c;
+    float go = dy[off];
+    if (relu && !(y[off] > 0.f)) go = 0.f;
+    const float xh = (x[off] - mean) * rstd;
+    dx[off] = rstd * (go * gamma[g * Cg + c] - m1 - xh * m2);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < Cg; i += 256) {
+    if (dgamma) atomicAdd(dgamma + g * Cg + i, sg[i]);
+    if (dbeta) atomicAdd(dbeta + g * Cg + i, sb[i]);
+  }
+}
+
+// ---- FPN top-down backward -----------------------------------------------------------------------------------
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, int Q, int C, int accumulate,
+                                    float* __restrict__ dtop) {
+  const int TP = (P + 1) / 2, TQ = (Q + 1) / 2, C4 = C >> 2;
+  const int64_t total = (int64_t)N * TP * TQ * C4;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (idx % C4) * 4;
+    int64_t t = idx / C4;
+    const int q = t % TQ; t /= TQ;
+    const int p = t % TP;
+    const int n = t / TP;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b) {
+        const int hh = 2 * p + a, ww = 2 * q + b;
+        if (hh < P && ww < Q) {
+          const float4 v = *(const float4*)(dy + (((int64_t)n * P + hh) * Q + ww) * C + c);
+          s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+      }
+    float4* d = (float4*)(dtop + (((int64_t)n * TP + p) * TQ + q) * C + c);
+    if (accumulate) { float4 o = *d; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+    *d = s;
+  }
+}
+
+// ---- fused SGD ------------------------------------------------------------------------------------------------
+__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                           const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end,
+                           const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int nseg,
+                           int64_t total, float momentum, float grad_scale, int first_step) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    // binary search of the segment holding element i (segments sorted, may leave gaps)
+    int lo = 0, hi = nseg - 1, sidx = -1;
+    while (lo <= hi) {
+      const int mid = (lo + hi) >> 1;
+      if (i < seg_begin[mid]) hi = mid - 1;
+      else if (i >= seg_end[mid]) lo = mid + 1;
+      else { sidx = mid; break; }
+    }
+    if (sidx < 0) continue;
+    const float lr = seg_lr[sidx], wd = seg_wd[sidx];
+    const float pv = p[i];
+    float d = g[i] * grad_scale;
+    if (wd != 0.f) d = d + wd * pv;
+    float b = first_step ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    p[i] = pv - lr * b;
+  }
+}
+
+}  // namespace
+
+CPM_EXPORT int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, int relu, int64_t M,
+                                     int K, float* dpre, float* dres, float* dshift, void* stream) {
+  CPM_REQUIRE(M >= 0 && K > 0, "bad shape");
+  if (M == 0) return CPM_OK;
+  CPM_REQUIRE(dy && (!relu || y), "null pointer");
+  int slabs = (int)((M + 511) / 512);
+  if (slabs > 2048) slabs = 2048;
+  const int rows = (int)((M + slabs - 1) / slabs);
+  slabs = (int)((M + rows - 1) / rows);
+  hipLaunchKernelGGL(epilogue_bwd_kernel, dim3(cpm::cdiv(K, 64), slabs), dim3(256), 0, (hipStream_t)stream, dy, y,
+                     scale, relu, M, K, rows, dpre, dres, dshift);
+  return cpm::check_launch("epilogue_backward");
+}
+
+CPM_EXPORT int cpm_im2col(const float* x, int layout, int N, int C, int H, int W, int R, int S, int stride, int pad,
+                          int P, int Q, int Kpad, float* out, void* stream) {
+  CPM_REQUIRE(x && out, "null pointer");
+  CPM_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && R > 0 && S > 0 && stride > 0 && Kpad >= R * S * C, "bad shape");
+  CPM_REQUIRE(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1, "bad output size");
+  const int64_t total = (int64_t)N * P * Q * Kpad;
+  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, layout, N,
+                     C, H, W, R, S, stride, pad, P, Q, Kpad, out);
+  return cpm::check_launch("im2col");
+}
+
+CPM_EXPORT int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, int P, int Q, float* y,
+                                        void* stream) {
+  CPM_REQUIRE(x && y, "null pointer");
+  CPM_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
+  CPM_REQUIRE(P == (H + 2 - 3) / 2 + 1 && Q == (W + 2 - 3) / 2 + 1, "bad output size");
+  const int64_t total = (int64_t)N * P * Q * (C / 4);
+  hipLaunchKernelGGL(maxpool_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, N, H, W,
+                     C, P, Q, y);
+  return cpm::check_launch("maxpool");
+}
+
+CPM_EXPORT int cpm_groupnorm_forward(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
+                                     int G, float eps, int relu, float* y, float* mean, float* rstd, void* stream) {
+  CPM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "bad shape");
+  if (N == 0) return CPM_OK;
+  CPM_REQUIRE(x && gamma && beta && y && mean && rstd, "null pointer");
+  hipLaunchKernelGGL(gn_fwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, HW, C, G, eps, relu,
+                     y, mean, rstd);
+  return cpm::check_launch("groupnorm_forward");
+}
+
+CPM_EXPORT int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, const float* gamma,
+                                      const float* mean, const float* rstd, int N, int HW, int C, int G, int relu,
+                                      float* dx, float* dgamma, float* dbeta, void* stream) {
+  CPM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C / G <= 256, "bad shape");
+  if (N == 0) return CPM_OK;
+  CPM_REQUIRE(dy && x && gamma && mean && rstd && dx && (!relu || y), "null pointer");
+  hipLaunchKernelGGL(gn_bwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, dy, x, y, gamma, mean, rstd, HW, C,
+                     G, relu, dx, dgamma, dbeta);
+  return cpm::check_launch("groupnorm_backward");
+}
+
+CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,
+                                           void* stream) {
+  CPM_REQUIRE(dy && dtop, "null pointer");
+  CPM_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
+  const int64_t total = (int64_t)N * ((P + 1) / 2) * ((Q + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, N, P, Q, C,
+                     accumulate, dtop);
+  return cpm::check_launch("upsample2x_add_backward");
+}
+
+CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int64_t* seg_begin,
+                            const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
+                            int64_t total, float momentum, float grad_scale, int first_step, void* stream) {
+  CPM_REQUIRE(params && grads && momentum_buf && seg_begin && seg_end && seg_lr && seg_wd, "null pointer");
+  CPM_REQUIRE(nseg > 0 && total > 0, "bad shape");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, params, grads,
+                     momentum_buf, seg_begin, seg_end, seg_lr, seg_wd, nseg, total, momentum, grad_scale, first_step);
+  return cpm::check_launch("sgd_step");
+}

@@ -1,0 +1,294 @@
+"""Convolution / linear / transposed-conv / GroupNorm operators over the implicit-GEMM HIP kernels.
+
+These replace the ATen (cuDNN/cuBLAS in the reference) calls behind nn.Conv2d, nn.Linear,
+nn.ConvTranspose2d and nn.GroupNorm on the hot path.  Activations are
+NHWC in memory (torch channels_last, logical shape stays [N,C,H,W]); weights are KRSC in memory
+(torch [K,C/g,R,S] channels_last).  Everything is fp32; autograd is wired with explicit backward
+kernels (data gradient, weight gradient, fused-epilogue gradient).
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip as H
+
+CL = torch.channels_last
+
+
+def nhwc(t):
+    """Return `t` with NHWC memory (no copy when it already is)."""
+    if t.dim() != 4:
+        raise RuntimeError("expected a 4-D tensor")
+    return t if t.is_contiguous(memory_format=CL) else t.contiguous(memory_format=CL)
+
+
+def empty_nhwc(shape, like):
+    return torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=CL)
+
+
+def out_size(h, k, stride, pad, dil=1):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def make_desc(n, c, h, w, k, r, s, stride, pad, dil, groups):
+    d = H.ConvDesc()
+    d.N, d.H, d.W, d.C, d.K, d.R, d.S = int(n), int(h), int(w), int(c), int(k), int(r), int(s)
+    d.stride, d.pad, d.dilation, d.groups = int(stride), int(pad), int(dil), int(groups)
+    d.P, d.Q = out_size(h, r, stride, pad, dil), out_size(w, s, stride, pad, dil)
+    return d
+
+
+def _ws(desc, device):
+    nbytes = H.lib().cpm_conv2d_workspace_bytes(H.ctypes.byref(desc))
+    if nbytes == 0:
+        raise RuntimeError("invalid convolution descriptor: %s" % H.lib().cpm_last_error().decode())
+    return H.workspace(nbytes, device)
+
+
+def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, dil, groups):
+    n, c, h, wd = x.shape
+    k, _, r, s = w.shape
+    d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
+    y = empty_nhwc((n, k, d.P, d.Q), x)
+    if y.numel() == 0:
+        return y
+    ws = _ws(d, x.device)
+    with torch.cuda.device(x.device):
+        rc = H.lib().cpm_conv2d_forward(H.ctypes.byref(d), H.ptr(x), H.ptr(w), H.ptr(scale), H.ptr(shift),
+                                        H.ptr(residual), int(res_mode), int(bool(relu)), H.ptr(y), H.ptr(ws),
+                                        H.c_size_t(ws.numel()), H.stream())
+    H.check(rc, "conv2d_forward")
+    return y
+
+
+def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups):
+    n, c, h, wd = x_shape
+    k, _, r, s = w.shape
+    d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
+    dx = empty_nhwc((n, c, h, wd), dy)
+    if dx.numel() == 0:
+        return dx
+    if dy.numel() == 0:
+        return dx.zero_()
+    ws = _ws(d, dy.device)
+    with torch.cuda.device(dy.device):
+        rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), 0, H.ptr(ws),
+                                              H.c_size_t(ws.numel()), H.stream())
+    H.check(rc, "conv2d_backward_data")
+    return dx
+
+
+def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None):
+    """dw (+)= x (*) dy.  `out` (same strides as the weight) is accumulated into when given."""
+    n, c, h, wd = x.shape
+    k, _, r, s = w_like.shape
+    d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
+    dw = out if out is not None else torch.zeros_like(w_like)
+    if x.numel() == 0 or dy.numel() == 0:
+        return dw
+    ws = _ws(d, x.device)
+    with torch.cuda.device(x.device):
+        rc = H.lib().cpm_conv2d_backward_weight(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(ws),
+                                                H.c_size_t(ws.numel()), H.stream())
+    H.check(rc, "conv2d_backward_weight")
+    return dw
+
+
+def epilogue_backward(dy, y, scale, relu, want_dpre=True, want_dres=False, want_dshift=False):
+    """Backward of relu?(v*scale+shift+res): returns (dpre, dres, dshift)."""
+    k = dy.shape[1]
+    m = dy.numel() // max(k, 1)
+    dpre = torch.empty_like(dy) if want_dpre else None
+    dres = torch.empty_like(dy) if want_dres else None
+    dshift = torch.zeros((k,), dtype=torch.float32, device=dy.device) if want_dshift else None
+    if dy.numel():
+        with torch.cuda.device(dy.device):
+            rc = H.lib().cpm_epilogue_backward(H.ptr(dy), H.ptr(y), H.ptr(scale), int(bool(relu)), H.c_int64(m), k,
+                                               H.ptr(dpre), H.ptr(dres), H.ptr(dshift), H.stream())
+        H.check(rc, "epilogue_backward")
+    return dpre, dres, dshift
+
+
+def _wmem(w):
+    """weights must be KRSC in memory"""
+    return w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
+
+
+class _ConvFn(Function):
+    """y = relu?( conv(x, w) * scale + shift + residual )   (scale/shift/residual optional).
+    scale is a frozen per-channel factor (AffineChannel2d) and never receives a gradient; shift receives one
+    only when it is a trainable bias."""
+
+    @staticmethod
+    def forward(ctx, x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode):
+        H.require_gpu(x, w, scale, shift, residual)
+        x = nhwc(x)
+        w = _wmem(w)
+        res = nhwc(residual) if residual is not None else None
+        y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
+        ctx.cfg = (stride, pad, dil, groups, relu, res_mode, tuple(x.shape),
+                   None if residual is None else tuple(residual.shape))
+        ctx.has = (scale is not None, shift is not None, residual is not None)
+        ctx.save_for_backward(x, w, scale, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, scale, y = ctx.saved_tensors
+        stride, pad, dil, groups, relu, res_mode, x_shape, res_shape = ctx.cfg
+        has_scale, has_shift, has_res = ctx.has
+        need_x, need_w, _, need_shift, need_res = ctx.needs_input_grad[:5]
+        dy = nhwc(dy)
+        # g = dy * [y > 0]  (gradient at the pre-activation sum);  dpre = g * scale;  dres = g;  dshift = sum g
+        masked = relu or has_scale
+        want_shift = has_shift and need_shift
+        want_res = has_res and need_res
+        dpre, g, dshift = dy, dy, None
+        if masked or want_shift:
+            split_res = want_res and has_scale          # g and g*scale are both needed
+            dpre_k, dres_k, dshift = epilogue_backward(dy, y, scale, relu, want_dpre=masked, want_dres=split_res,
+                                                       want_dshift=want_shift)
+            if masked:
+                dpre = dpre_k
+                g = dres_k if split_res else (dpre_k if not has_scale else None)
+        gres = None
+        if want_res:
+            gres = g if res_mode == 0 else upsample2x_add_backward(g, res_shape)
+        dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups) if need_x else None
+        dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups) if need_w else None
+        return dx, dw, None, dshift, gres, None, None, None, None, None, None
+
+
+def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, groups=1, relu=False, res_mode=0):
+    return _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode)
+
+
+def linear(x, w, bias=None, relu=False):
+    """nn.Linear as a 1x1 conv on a 1x1 image: x [R, C], w [K, C]."""
+    r, c = x.shape
+    y = conv2d(x.reshape(r, c, 1, 1), w.reshape(w.shape[0], c, 1, 1), None, bias, None, relu=relu)
+    return y.reshape(r, w.shape[0])
+
+
+def upsample2x_add_backward(dy, top_shape):
+    n, c, p, q = dy.shape
+    assert tuple(top_shape) == (n, c, (p + 1) // 2, (q + 1) // 2), "top-down sizes must be 2x apart"
+    dtop = empty_nhwc(top_shape, dy)
+    with torch.cuda.device(dy.device):
+        rc = H.lib().cpm_upsample2x_add_backward(H.ptr(nhwc(dy)), n, p, q, c, H.ptr(dtop), 0, H.stream())
+    H.check(rc, "upsample2x_add_backward")
+    return dtop
+
+
+class _ConvTransposeFn(Function):
+    """nn.ConvTranspose2d (+bias, +ReLU).  w: torch layout [Cin, Cout/groups, R, S], KRSC memory."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, pad, groups, relu):
+        H.require_gpu(x, w, bias)
+        x = nhwc(x)
+        w = _wmem(w)
+        n, cin, p, q = x.shape
+        _, cog, r, s = w.shape
+        cout = cog * groups
+        hh, ww = (p - 1) * stride - 2 * pad + r, (q - 1) * stride - 2 * pad + s
+        d = make_desc(n, cout, hh, ww, cin, r, s, stride, pad, 1, groups)
+        assert d.P == p and d.Q == q
+        y = empty_nhwc((n, cout, hh, ww), x)
+        if y.numel():
+            ws = _ws(d, x.device)
+            with torch.cuda.device(x.device):
+                rc = H.lib().cpm_conv_transpose2d_forward(H.ctypes.byref(d), H.ptr(x), H.ptr(w), H.ptr(bias),
+                                                          int(bool(relu)), H.ptr(y), H.ptr(ws),
+                                                          H.c_size_t(ws.numel()), H.stream())
+            H.check(rc, "conv_transpose2d_forward")
+        ctx.cfg = (stride, pad, groups, relu, bias is not None)
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, pad, groups, relu, has_bias = ctx.cfg
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dy = nhwc(dy)
+        dbias = None
+        if relu or (has_bias and need_b):
+            dpre, _, dbias = epilogue_backward(dy, y, None, relu, want_dpre=relu, want_dshift=has_bias and need_b)
+            dy = dpre if dpre is not None else dy
+        # the transposed conv's data gradient is the plain conv; its weight gradient swaps the operands
+        dx = conv2d_forward(dy, w, None, None, None, 0, False, stride, pad, 1, groups) if need_x else None
+        dw = conv2d_backward_weight(dy, x, w, stride, pad, 1, groups) if need_w else None
+        return dx, dw, dbias, None, None, None, None
+
+
+def conv_transpose2d(x, w, bias=None, stride=2, pad=1, groups=1, relu=False):
+    return _ConvTransposeFn.apply(x, w, bias, stride, pad, groups, relu)
+
+
+class _GroupNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, relu):
+        H.require_gpu(x, gamma, beta)
+        x = nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        if n:
+            with torch.cuda.device(x.device):
+                rc = H.lib().cpm_groupnorm_forward(H.ptr(x), H.ptr(gamma), H.ptr(beta), n, h * w, c, int(groups),
+                                                   H.f(eps), int(bool(relu)), H.ptr(y), H.ptr(mean), H.ptr(rstd),
+                                                   H.stream())
+            H.check(rc, "groupnorm_forward")
+        ctx.cfg = (groups, relu)
+        ctx.save_for_backward(x, y, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        groups, relu = ctx.cfg
+        dy = nhwc(dy)
+        n, c, h, w = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.zeros_like(gamma)
+        dbeta = torch.zeros_like(gamma)
+        if n:
+            with torch.cuda.device(x.device):
+                rc = H.lib().cpm_groupnorm_backward(H.ptr(dy), H.ptr(x), H.ptr(y), H.ptr(gamma), H.ptr(mean),
+                                                    H.ptr(rstd), n, h * w, c, int(groups), int(bool(relu)),
+                                                    H.ptr(dx), H.ptr(dgamma), H.ptr(dbeta), H.stream())
+            H.check(rc, "groupnorm_backward")
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
+    return _GroupNormFn.apply(x, gamma, beta, groups, eps, relu)
+
+
+def stem_forward(x, w_pad, scale, shift, r=7, s=7, stride=2, pad=3):
+    """ResNet stem (backbone/ResNet.py:123-136): 7x7/s2 conv on 3 channels as im2col + 1x1 MFMA GEMM with the
+    frozen affine + ReLU fused, then the 3x3/s2 max-pool.  Frozen stage: forward only.
+    w_pad: [K, Kpad, 1, 1] = conv1.weight in (r,s,c) column order, zero padded to a multiple of 32."""
+    H.require_gpu(x, w_pad, scale, shift)
+    n, c, h, w = x.shape
+    is_nhwc = x.is_contiguous(memory_format=CL) and not x.is_contiguous()
+    xin = x if (is_nhwc or x.is_contiguous()) else x.contiguous()
+    p, q = out_size(h, r, stride, pad), out_size(w, s, stride, pad)
+    kpad = w_pad.shape[1]
+    cols = torch.empty((n * p * q, kpad), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        rc = H.lib().cpm_im2col(H.ptr(xin), 1 if is_nhwc else 0, n, c, h, w, r, s, stride, pad, p, q, kpad,
+                                H.ptr(cols), H.stream())
+    H.check(rc, "im2col")
+    y = conv2d_forward(cols.view(n, p, q, kpad).permute(0, 3, 1, 2), w_pad, scale, shift, None, 0, True, 1, 0, 1, 1)
+    pp, pq = out_size(p, 3, 2, 1), out_size(q, 3, 2, 1)
+    out = empty_nhwc((n, y.shape[1], pp, pq), x)
+    with torch.cuda.device(x.device):
+        rc = H.lib().cpm_maxpool3x3s2_forward(H.ptr(y), n, p, q, y.shape[1], pp, pq, H.ptr(out), H.stream())
+    H.check(rc, "maxpool")
+    return out

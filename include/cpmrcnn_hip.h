@@ -122,51 +122,51 @@ int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy, const floa
 int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
                                void* workspace, size_t workspace_bytes, void* stream);
 
-/* dpre = dy * (y > 0 if relu) * scale[k]; optional dshift[k] += sum_m(dy*mask) (bias grads),
- * optional dres = dy*mask (residual branch).  Elementwise helper of the fused epilogue's backward. */
-int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, int relu, int64_t M, int K,
-                          float* dpre, float* dshift, void* stream);
+/* nn.ConvTranspose2d forward (grid_rcnn/outputs.py:24-37,66-71) = the data gradient of the conv
+ * described by `d` with a fused bias(+ReLU) epilogue: x [N,P,Q,K] -> y [N,H,W,C], w as for `d`
+ * (torch's ConvTranspose2d weight [Cin=K][Cout/groups=C/g][R][S] permuted to KRSC).  Its own
+ * backward is cpm_conv2d_forward (data) and cpm_conv2d_backward_weight with the roles of x and
+ * dy swapped. */
+int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* bias,
+                                 int relu, float* y, void* workspace, size_t workspace_bytes, void* stream);
 
-/* 7x7/s2 stem on 3 channels + 3x3/s2 max-pool (ResNet.forward, backbone/ResNet.py:123-135): frozen, fwd only */
-int cpm_stem_forward(const float* x_nchw_or_nhwc, int layout, int N, int H, int W, const float* w_krsc,
-                     const float* scale, const float* shift, float* y_conv, float* y_pool, void* workspace,
-                     size_t workspace_bytes, void* stream);
-size_t cpm_stem_workspace_bytes(int N, int H, int W);
-int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, float* y, void* stream);
+/* Backward of the fused epilogue: dpre = dy * (y > 0 if relu) * scale[k] (in place allowed),
+ * dres = dy * mask (gradient of the residual branch; may be NULL), dshift[k] += sum_m dy*mask
+ * (bias gradient; may be NULL).  M rows of K channels. */
+int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, int relu, int64_t M, int K,
+                          float* dpre, float* dres, float* dshift, void* stream);
+
+/* im2col for thin-channel stems (ResNet conv1 7x7/s2 on 3 channels, backbone/ResNet.py:123-126):
+ * out [N*P*Q][Kpad], column (r*S+s)*C+c, zero for columns >= R*S*C.  The stem then runs as a
+ * 1x1 cpm_conv2d_forward over Kpad channels with its affine+ReLU epilogue.  layout = x's layout. */
+int cpm_im2col(const float* x, int layout, int N, int C, int H, int W, int R, int S, int stride, int pad,
+               int P, int Q, int Kpad, float* out, void* stream);
+/* nn.MaxPool2d(3, 2, 1) of the stem (backbone/ResNet.py:136), NHWC, forward only (frozen stage) */
+int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, int P, int Q, float* y, void* stream);
 
 /* ---- GroupNorm (+ReLU), NHWC ----------------------------------------------
  * Replaces nn.GroupNorm + nn.ReLU in grid_heads.py:47-55 and outputs.py:23,68.
- * x [N,HW,C]; mean/rstd [N,G] saved for backward.                              */
+ * x [N,HW,C]; mean/rstd [N,G] saved for backward; dgamma/dbeta accumulate.      */
 int cpm_groupnorm_forward(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G,
                           float eps, int relu, float* y, float* mean, float* rstd, void* stream);
 int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, const float* gamma, const float* mean,
                            const float* rstd, int N, int HW, int C, int G, int relu, float* dx, float* dgamma,
                            float* dbeta, void* stream);
 
-/* ---- Grouped ConvTranspose2d k4 s2 p1 (outputs.py:24-37), NHWC, direct ------
- * x [N,H,W,Cin], w torch layout [Cin][Cout/groups][4][4], y [N,2H,2W,Cout].     */
-int cpm_deconv4x4s2_forward(const float* x, const float* w, const float* bias, int N, int H, int W, int Cin,
-                            int Cout, int groups, float* y, void* stream);
-int cpm_deconv4x4s2_backward_data(const float* dy, const float* w, int N, int H, int W, int Cin, int Cout,
-                                  int groups, float* dx, void* stream);
-int cpm_deconv4x4s2_backward_weight(const float* x, const float* dy, int N, int H, int W, int Cin, int Cout,
-                                    int groups, float* dw, float* dbias, void* stream);
-
-/* ---- misc elementwise ------------------------------------------------------ */
-/* y[n,2p+a,2q+b,c] (clipped to [P,Q]) += x[n,p,q,c]  (FPN top-down backward) and forward add */
-int cpm_upsample2x_add(const float* top, const float* lateral, int N, int P, int Q, int C, float* y, void* stream);
-int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, void* stream);
-/* NCHW <-> NHWC */
-int cpm_permute_nchw_nhwc(const float* x, int N, int C, int H, int W, int to_nhwc, float* y, void* stream);
+/* FPN top-down backward (FPN.py:104-106): dtop[n,p,q,c] += sum of dy over the 2x2 block it was
+ * upsampled to.  dy [N,P,Q,C], dtop [N,ceil(P/2),ceil(Q/2),C]. */
+int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,
+                                void* stream);
 
 /* ---- fused SGD with momentum over a flat parameter buffer -------------------
  * Replaces torch.optim.SGD.step as built by pet/utils/optimizer.py:40-65 (3 param
  * groups: weights / biases (lr x2, no wd) / GN).  seg_* are device arrays of
- * `nseg` segments: [begin,end) element ranges with per-segment lr and weight decay.
- * p -= lr * (mom = momentum*mom + (g*grad_scale + wd*p)).                        */
+ * `nseg` segments sorted by begin: [begin,end) element ranges with per-segment lr
+ * and weight decay.  d = g*grad_scale + wd*p; buf = momentum*buf + d; p -= lr*buf
+ * (torch.optim.SGD with dampening 0, first step buf = d when first_step != 0).   */
 int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int64_t* seg_begin,
                  const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg, int64_t total,
-                 float momentum, float grad_scale, void* stream);
+                 float momentum, float grad_scale, int first_step, void* stream);
 
 #ifdef __cplusplus
 }

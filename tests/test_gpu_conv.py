@@ -1,0 +1,184 @@
+"""GPU parity for the implicit-GEMM conv family (fp32 MFMA) against torch-CPU fp32 on identical inputs
+(conv/GN/deconv/linear arithmetic is torch's; tolerance 1e-3 per north_star -- we assert 1e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+TOL = 1e-4
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CASES = [
+    # name, N, C, H, W, K, R, stride, pad, groups
+    ("1x1", 2, 64, 9, 13, 256, 1, 1, 0, 1),
+    ("1x1_s2", 2, 256, 10, 14, 128, 1, 2, 0, 1),
+    ("3x3", 2, 64, 11, 7, 64, 3, 1, 1, 1),
+    ("3x3_wide", 1, 128, 40, 37, 128, 3, 1, 1, 1),
+    ("3x3_s2_grid0", 5, 256, 14, 14, 576, 3, 2, 1, 1),
+    ("3x3_grid", 3, 576, 7, 7, 576, 3, 1, 1, 1),
+    ("rpn_pred", 2, 256, 6, 10, 15, 1, 1, 0, 1),
+    ("fc_as_7x7", 9, 256, 7, 7, 1024, 7, 1, 0, 1),
+    ("cls_score", 37, 1024, 1, 1, 81, 1, 1, 0, 1),
+    ("iou_pred", 5, 1024, 1, 1, 2, 1, 1, 0, 1),
+    ("grouped", 2, 64, 8, 8, 128, 3, 1, 1, 4),
+    ("odd_c", 2, 36, 5, 6, 20, 3, 1, 1, 1),
+    ("7x7_s2", 1, 32, 20, 24, 64, 7, 2, 3, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("epi", ["plain", "bias_relu", "affine_res_relu"])
+def test_conv_fwd_bwd(case, epi):
+    from pet.lib.ops import conv as ops
+    name, N, C, H, W, K, R, stride, pad, groups = case
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(K, C // groups, R, R, seed=2, scale=1.0 / np.sqrt(C // groups * R * R))
+    P, Q = ops.out_size(H, R, stride, pad), ops.out_size(W, R, stride, pad)
+    scale = shift = res = None
+    relu = False
+    if epi == "bias_relu":
+        shift, relu = rnd(K, seed=3, scale=0.1), True
+    elif epi == "affine_res_relu":
+        scale = torch.rand(K, generator=torch.Generator().manual_seed(4)) + 0.5
+        shift, relu = rnd(K, seed=3, scale=0.1), True
+        res = rnd(N, K, P, Q, seed=5)
+    # reference: torch CPU fp32
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    sr = shift.clone().requires_grad_(True) if shift is not None else None
+    rr = res.clone().requires_grad_(True) if res is not None else None
+    yr = F.conv2d(xr, wr, None, stride, pad, 1, groups)
+    if scale is not None:
+        yr = yr * scale.view(1, -1, 1, 1)
+    if sr is not None:
+        yr = yr + sr.view(1, -1, 1, 1)
+    if rr is not None:
+        yr = yr + rr
+    go = rnd(*yr.shape, seed=6)
+    if relu:
+        # a pre-activation within rounding distance of 0 may flip its ReLU mask between CPU and GPU:
+        # take those (measure-zero) positions out of the gradient comparison
+        go = go * (yr.detach().abs() > 1e-4).float()
+        yr = F.relu(yr)
+    yr.backward(go)
+    # ours
+    xd = x.cuda().contiguous(memory_format=CL).requires_grad_(True)
+    wd = w.cuda().contiguous(memory_format=CL).requires_grad_(True)
+    sd = shift.cuda().requires_grad_(True) if shift is not None else None
+    rd = res.cuda().contiguous(memory_format=CL).requires_grad_(True) if res is not None else None
+    y = ops.conv2d(xd, wd, scale.cuda() if scale is not None else None, sd, rd, stride, pad, 1, groups, relu, 0)
+    assert y.shape == yr.shape
+    assert relerr(y, yr) < TOL, "forward"
+    y.backward(go.cuda().contiguous(memory_format=CL))
+    assert relerr(xd.grad, xr.grad) < TOL, "dgrad"
+    assert relerr(wd.grad, wr.grad) < TOL, "wgrad"
+    if sd is not None:
+        assert relerr(sd.grad, sr.grad) < TOL, "bias grad"
+    if rd is not None:
+        assert relerr(rd.grad, rr.grad) < TOL, "residual grad"
+
+
+def test_fpn_topdown_residual():
+    """lateral 1x1 conv + nearest-2x upsampled top (FPN.py:100-106) fused through res_mode=1."""
+    from pet.lib.ops import conv as ops
+    N, C, K, P, Q = 2, 128, 256, 6, 10
+    x, w, b = rnd(N, C, 2 * P, 2 * Q, seed=1), rnd(K, C, 1, 1, seed=2, scale=0.1), rnd(K, seed=3)
+    top = rnd(N, K, P, Q, seed=4)
+    xr, wr, br, tr = [t.clone().requires_grad_(True) for t in (x, w, b, top)]
+    yr = F.conv2d(xr, wr, br) + F.interpolate(tr, scale_factor=2, mode="nearest")
+    go = rnd(*yr.shape, seed=5)
+    yr.backward(go)
+    xd, wd, td = [t.cuda().contiguous(memory_format=CL).requires_grad_(True) for t in (x, w, top)]
+    bd = b.cuda().requires_grad_(True)
+    y = ops.conv2d(xd, wd, None, bd, td, res_mode=1)
+    assert relerr(y, yr) < TOL
+    y.backward(go.cuda())
+    for a, r in ((xd.grad, xr.grad), (wd.grad, wr.grad), (bd.grad, br.grad), (td.grad, tr.grad)):
+        assert relerr(a, r) < TOL
+
+
+def test_linear_and_splitk():
+    from pet.lib.ops import conv as ops
+    for R, Cin, Cout in ((192, 28224, 1024), (1024, 1024, 1024), (7, 1024, 81)):
+        x, w, b = rnd(R, Cin, seed=1), rnd(Cout, Cin, seed=2, scale=1 / np.sqrt(Cin)), rnd(Cout, seed=3)
+        xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+        pre = F.linear(xr, wr, br)
+        go = rnd(*pre.shape, seed=4) * (pre.detach().abs() > 1e-4).float()
+        yr = F.relu(pre)
+        yr.backward(go)
+        xd, wd, bd = [t.cuda().requires_grad_(True) for t in (x, w, b)]
+        y = ops.linear(xd, wd, bd, relu=True)
+        assert relerr(y, yr) < TOL
+        y.backward(go.cuda())
+        assert relerr(xd.grad, xr.grad) < TOL and relerr(wd.grad, wr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize("cin,cout,groups,hw,n", [(576, 576, 9, 7, 6), (576, 9, 9, 14, 6), (64, 32, 1, 5, 2)])
+def test_conv_transpose(cin, cout, groups, hw, n):
+    """grouped ConvTranspose2d k4 s2 p1 (grid_rcnn/outputs.py:24-37) through the DGRAD-mode kernel."""
+    from pet.lib.ops import conv as ops
+    x = rnd(n, cin, hw, hw, seed=1)
+    w = rnd(cin, cout // groups, 4, 4, seed=2, scale=0.05)
+    b = rnd(cout, seed=3)
+    xr, wr, br = [t.clone().requires_grad_(True) for t in (x, w, b)]
+    yr = F.conv_transpose2d(xr, wr, br, stride=2, padding=1, groups=groups)
+    go = rnd(*yr.shape, seed=4)
+    yr.backward(go)
+    xd, wd = [t.cuda().contiguous(memory_format=CL).requires_grad_(True) for t in (x, w)]
+    bd = b.cuda().requires_grad_(True)
+    y = ops.conv_transpose2d(xd, wd, bd, 2, 1, groups, False)
+    assert y.shape == yr.shape and relerr(y, yr) < TOL
+    y.backward(go.cuda())
+    assert relerr(xd.grad, xr.grad) < TOL and relerr(wd.grad, wr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
+
+
+@pytest.mark.parametrize("n,c,hw,g,relu", [(5, 576, 7, 36, True), (4, 576, 14, 9, True), (3, 64, 5, 32, False)])
+def test_group_norm(n, c, hw, g, relu):
+    from pet.lib.ops import conv as ops
+    x, gm, bt = rnd(n, c, hw, hw, seed=1) * 2 + 0.3, rnd(c, seed=2) * 0.2 + 1, rnd(c, seed=3) * 0.2
+    xr, gr, br = [t.clone().requires_grad_(True) for t in (x, gm, bt)]
+    yr = F.group_norm(xr, g, gr, br, 1e-5)
+    go = rnd(*yr.shape, seed=4)
+    if relu:
+        go = go * (yr.detach().abs() > 1e-4).float()
+        yr = F.relu(yr)
+    yr.backward(go)
+    xd = x.cuda().contiguous(memory_format=CL).requires_grad_(True)
+    gd, bd = gm.cuda().requires_grad_(True), bt.cuda().requires_grad_(True)
+    y = ops.group_norm(xd, gd, bd, g, 1e-5, relu)
+    assert relerr(y, yr) < TOL
+    y.backward(go.cuda())
+    assert relerr(xd.grad, xr.grad) < TOL and relerr(gd.grad, gr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
+
+
+def test_stem():
+    from pet.lib.ops import conv as ops
+    N, H, W = 2, 64, 96
+    x = rnd(N, 3, H, W, seed=1) * 50
+    w = rnd(64, 3, 7, 7, seed=2, scale=0.05)
+    sc, sh = torch.rand(64) + 0.5, rnd(64, seed=3)
+    yr = F.max_pool2d(F.relu(F.conv2d(x, w, None, 2, 3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
+    wp = torch.zeros(64, 160)
+    wp[:, :147] = w.permute(0, 2, 3, 1).reshape(64, 147)
+    for xin in (x.cuda(), x.cuda().contiguous(memory_format=CL)):
+        y = ops.stem_forward(xin, wp.cuda().view(64, 160, 1, 1), sc.cuda(), sh.cuda())
+        assert y.shape == yr.shape and relerr(y, yr) < TOL
+
+
+def test_conv_errors():
+    from pet.lib.ops import conv as ops
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1))          # CPU tensors: no fallback
+    e = ops.conv2d(torch.zeros(0, 64, 7, 7, device="cuda"), torch.zeros(64, 64, 3, 3, device="cuda"), pad=1)
+    assert e.shape == (0, 64, 7, 7)
