@@ -1,2 +1,10 @@
+"""Operator surface of the hot path (counterpart of pet/lib/ops/__init__.py:1-30, hot-path names only)."""
 from .nms import nms, ml_nms, nms_segments
 from .roi_align import roi_align, ROIAlign
+from .pooler_fpn import roi_align_fpn
+from .affine import AffineChannel2d
+from .losses import smooth_l1_loss, l2_loss
+from .modules import Conv2d, Linear, ConvTranspose2d, GroupNorm, ReLU
+from .conv import conv2d, linear, conv_transpose2d, group_norm, stem_forward
+from .pool_points_interp import pool_points_interp, PoolPointsInterp
+from .boxes import box_iou

@@ -1,0 +1,29 @@
+"""BoxList NMS helpers of pet/lib/ops/boxlist_ops.py:15-67,289-315 (TO_REMOVE = 0 conventions)."""
+import torch
+
+from pet.lib.ops.nms import nms as _box_nms, ml_nms as _box_ml_nms
+from pet.utils.data.structures.boxlist_ops import cat_boxlist  # noqa: F401  (re-export, boxlist_ops.py:289)
+
+
+def boxlist_nms(boxlist, nms_thresh, topk=0, score_field="scores", idxs=None):
+    if nms_thresh <= 0:
+        return boxlist
+    mode = boxlist.mode
+    boxlist = boxlist.convert("xyxy")
+    boxes = boxlist.bbox
+    if idxs is not None:      # batched NMS by per-class coordinate offset (boxlist_ops.py:34-38)
+        offsets = idxs.to(boxes) * (boxes.max() + torch.tensor(1).to(boxes))
+        boxes = boxes + offsets[:, None]
+    keep = _box_nms(boxes, boxlist.get_field(score_field), nms_thresh)
+    if keep.size(0) > topk > 0:
+        keep = keep[:topk]
+    return boxlist[keep].convert(mode)
+
+
+def boxlist_ml_nms(boxlist, nms_thresh, topk=0, score_field="scores", label_field="labels"):
+    if nms_thresh <= 0:
+        return boxlist
+    mode = boxlist.mode
+    boxlist = boxlist.convert("xyxy")
+    keep = _box_ml_nms(boxlist.bbox, boxlist.get_field(score_field), boxlist.get_field(label_field), nms_thresh, topk)
+    return boxlist[keep].convert(mode)

@@ -1,0 +1,138 @@
+"""CPM head = CMM cascade + ISM + RSM (counterpart of
+pet/rcnn/modeling/grid_cascade_rcnn/grid_cascade_rcnn.py:15-309).
+
+Training: sample 512 RoIs/img -> cls head -> CE; keep <= 96 positives/img -> for each of the N stages: match at
+the stage's IoU, pool 14x14, 8 convs, 2 deconvs -> BCE against rasterised point targets (last stage: ISM l2
+loss), decode refined boxes (no_grad) and append gts for the next stage; RSM: cls negatives + refined positives
+-> second cls head -> CE.  Testing: cls head -> ml_nms -> the stages refine the kept detections -> ISM / RSM
+re-scoring."""
+import torch
+from torch import nn
+
+from pet.rcnn.core.config import cfg
+from pet.rcnn.modeling import registry
+from pet.rcnn.modeling.grid_cascade_rcnn.inference import post_processor
+from pet.rcnn.modeling.grid_cascade_rcnn.loss import loss_evaluator
+from pet.rcnn.modeling.grid_rcnn import heads, outputs  # noqa: F401  (populate the registries)
+from pet.rcnn.utils.misc import keep_only_positive_boxes
+from pet.utils.data.structures.boxlist_ops import cat_boxlist
+
+
+class GridCascadeRCNN(nn.Module):
+    def __init__(self, dim_in, spatial_scale):
+        super().__init__()
+        G, M = cfg.GRID_RCNN, cfg.GRID_RCNN.CASCADE_MAPPING_OPTION
+        if G.ENHANCE_FEATURES or G.EXTEND_ROI or G.RANDOM_JITTER:
+            raise ValueError("ENHANCE_FEATURES / EXTEND_ROI / RANDOM_JITTER are outside the hot path")
+        self.Head_cls = registry.ROI_CLS_HEADS[G.ROI_CLS_HEAD](dim_in, spatial_scale)
+        self.Output_cls = registry.ROI_CLS_OUTPUTS[G.ROI_CLS_OUTPUT](self.Head_cls.dim_out)
+        self.cls_post_processor = post_processor(type="cls")
+        self.cls_loss_evaluator = loss_evaluator(type="cls")
+        self.max_sample_num_grid = G.MAX_SAMPLE_NUM_GRID
+        self.test_ensemble, self.stage_num, self.test_stage = M.TEST_ENSEMBLE, M.STAGE_NUM, M.TEST_STAGE
+        self.stage_loss_weight = M.STAGE_WEIGHTS
+        head_grid = registry.ROI_GRID_HEADS[G.ROI_GRID_HEAD]
+        output_grid = registry.ROI_GRID_OUTPUTS[G.ROI_GRID_OUTPUT]
+        self.grid_loss_evaluators, self.grid_post_processors = [], []
+        for s in range(self.stage_num):
+            setattr(self, "Head_grid_%d" % s, head_grid(dim_in, spatial_scale, s))
+            setattr(self, "Output_grid_%d" % s, output_grid(getattr(self, "Head_grid_%d" % s).dim_out, s))
+            self.grid_loss_evaluators.append(loss_evaluator(stage=s, type="grid"))
+            self.grid_post_processors.append(post_processor(stage=s, type="grid"))
+        if G.RESCORE_ON:
+            self.Head_rescore = registry.ROI_CLS_HEADS[G.ROI_CLS_HEAD](dim_in, spatial_scale)
+            self.Output_rescore = registry.ROI_CLS_OUTPUTS[G.ROI_CLS_OUTPUT](self.Head_rescore.dim_out)
+            self.rescore_loss_evaluator = loss_evaluator(type="cls")
+        self.last_counts = {}
+
+    def forward(self, features, proposals, targets=None):
+        if self.training:
+            loss = {}
+            proposals, loss_cls = self._forward_train_cls(features, proposals, targets)
+            x, result, loss_grid = self._forward_train_cascade(features, proposals, targets)
+            if cfg.GRID_RCNN.RESCORE_ON:
+                result, loss_rescore = self._forward_train_rescore(features, proposals, result, targets)
+                loss.update(loss_rescore)
+            loss.update(loss_cls)
+            loss.update(loss_grid)
+            return x, result, loss
+        proposals = self._forward_test_cls(features, proposals)
+        if len(proposals[0]) == 0:
+            return features, proposals, {}
+        x, result = self._forward_test_cascade(features, proposals)
+        if cfg.GRID_RCNN.RESCORE_ON:
+            result = self._forward_test_rescore(features, result)
+        return x, result, {}
+
+    # ---- training ----------------------------------------------------------------------------------------
+    def _forward_train_cls(self, features, proposals, targets):
+        with torch.no_grad():
+            proposals = self.cls_loss_evaluator.subsample(proposals, targets)
+        self.last_counts["cls"] = sum(len(p) for p in proposals)
+        logits = self.Output_cls(self.Head_cls(features, proposals))
+        return proposals, dict(loss_classifier=self.cls_loss_evaluator([logits]))
+
+    def _forward_train_cascade(self, features, proposals, targets):
+        G = cfg.GRID_RCNN
+        losses, x = {}, None
+        for s in range(self.stage_num):
+            ev = self.grid_loss_evaluators[s]
+            if s == 0:
+                proposals = keep_only_positive_boxes(proposals, roi_batch_size=self.max_sample_num_grid,
+                                                     across_sample=G.ACROSS_SAMPLE)
+            with torch.no_grad():
+                proposals = ev.subsample(proposals, targets)
+            self.last_counts["grid_%d" % s] = sum(len(p) for p in proposals)
+            x, _ = getattr(self, "Head_grid_%d" % s)(features, proposals)
+            grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
+            loss_grid, loss_iou = ev(proposals, grid_logits, iou_logits, targets)
+            loss_grid = loss_grid * self.stage_loss_weight[s]
+            if G.IOU_HELPER and s == self.stage_num - 1:
+                losses["loss_iou_%d" % (s + 1)] = loss_iou * G.IOU_LOSS_WEIGHT
+            losses["loss_grid_%d" % (s + 1)] = loss_grid
+            if s < self.stage_num - 1:
+                with torch.no_grad():
+                    proposals = self.grid_post_processors[s](grid_logits, proposals, targets=targets, is_train=True)
+        return x, proposals, losses
+
+    def _forward_train_rescore(self, features, cls_proposals, grid_proposals, targets):
+        with torch.no_grad():
+            proposals = get_full_sample_boxes(cls_proposals, grid_proposals)
+            proposals = self.rescore_loss_evaluator.subsample(proposals, targets)
+        self.last_counts["rescore"] = sum(len(p) for p in proposals)
+        logits = self.Output_rescore(self.Head_rescore(features, proposals))
+        return proposals, dict(loss_rescore=self.rescore_loss_evaluator([logits]) * cfg.GRID_RCNN.RESCORE_LOSS_WEIGHT)
+
+    # ---- testing -----------------------------------------------------------------------------------------
+    def _forward_test_cls(self, features, proposals):
+        logits = self.Output_cls(self.Head_cls(features, proposals))
+        return self.cls_post_processor(logits, proposals)
+
+    def _forward_test_cascade(self, features, proposals):
+        x = None
+        for s in range(self.stage_num):
+            x, _ = getattr(self, "Head_grid_%d" % s)(features, proposals)
+            grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
+            if s == self.stage_num - 1 and self.test_ensemble:
+                raise Exception("unsupported operation!")
+            proposals = self.grid_post_processors[s](grid_logits, proposals, iou_logits)
+            if s < self.stage_num - 1 and s == self.test_stage - 1:
+                break
+        return x, proposals
+
+    def _forward_test_rescore(self, features, proposals):
+        logits = self.Output_rescore(self.Head_rescore(features, proposals))
+        return self.cls_post_processor(logits, proposals, rescore=True)
+
+
+def get_full_sample_boxes(cls_proposals, grid_proposals):
+    """RSM sample = negatives of the cls sample + the refined positives (grid_cascade_rcnn.py:231-245)."""
+    out = []
+    for c, g in zip(cls_proposals, grid_proposals):
+        inds = (c.get_field("labels") <= 0).nonzero().squeeze(1)
+        if cfg.GRID_RCNN.RESCORE_OPTION.KEEP_RATIO:
+            neg_num = g.bbox.shape[0] * 3
+            if neg_num <= inds.shape[0]:
+                inds = inds[torch.randperm(inds.shape[0], device=inds.device)[:neg_num]]
+        out.append(cat_boxlist((c[inds], g)))
+    return out

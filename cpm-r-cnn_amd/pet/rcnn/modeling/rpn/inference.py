@@ -1,0 +1,111 @@
+"""RPN proposal selection (counterpart of pet/rcnn/modeling/rpn/inference.py:12-196).
+
+Same pipeline -- per level: sigmoid, top-k, BoxCoder.decode, clip, min-size filter, NMS, post-NMS top-n; then the
+cross-level top-k (per batch in training, per image in testing) and the GT append -- but the reference's
+N_images x N_levels separate NMS calls (each with a device->host mask copy) become ONE batched device NMS
+(cpm_nms_batched) over all (image, level) segments."""
+import torch
+
+from pet.lib.ops import nms_segments
+from pet.rcnn.core.config import cfg
+from pet.rcnn.utils.box_coder import BoxCoder
+from pet.rcnn.utils.misc import permute_and_flatten
+from pet.utils.data.structures.bounding_box import BoxList
+from pet.utils.data.structures.boxlist_ops import cat_boxlist
+
+
+class RPNPostProcessor(torch.nn.Module):
+    def __init__(self, pre_nms_top_n, post_nms_top_n, nms_thresh, min_size, box_coder=None, fpn_post_nms_top_n=None,
+                 fpn_post_nms_per_batch=True):
+        super().__init__()
+        self.pre_nms_top_n, self.post_nms_top_n = pre_nms_top_n, post_nms_top_n
+        self.nms_thresh, self.min_size = nms_thresh, min_size
+        self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
+        self.fpn_post_nms_per_batch = fpn_post_nms_per_batch
+
+    def add_gt_proposals(self, proposals, targets):
+        device = proposals[0].bbox.device
+        out = []
+        for p, t in zip(proposals, targets):
+            gt = t.copy_with_fields([])
+            gt.add_field("objectness", torch.ones(len(gt), device=device))
+            out.append(cat_boxlist((p, gt)))
+        return out
+
+    def _candidates(self, anchors, objectness, box_regression):
+        """One level: [N, k] scores and [N, k, 4] decoded + clipped boxes (inference.py:67-99)."""
+        N, A, H, W = objectness.shape
+        scores = permute_and_flatten(objectness, N, A, 1, H, W).view(N, -1).sigmoid()
+        reg = permute_and_flatten(box_regression, N, A, 4, H, W)
+        k = min(self.pre_nms_top_n, A * H * W)
+        scores, idx = scores.topk(k, dim=1, sorted=True)
+        bidx = torch.arange(N, device=scores.device)[:, None]
+        reg = reg[bidx, idx]
+        anc = torch.cat([a.bbox for a in anchors], dim=0).reshape(N, -1, 4)[bidx, idx]
+        boxes = self.box_coder.decode(reg.reshape(-1, 4), anc.reshape(-1, 4)).view(N, k, 4)
+        for n, a in enumerate(anchors):                       # clip_to_image(remove_empty=False)
+            w, h = a.size
+            boxes[n, :, 0].clamp_(min=0, max=w - 1)
+            boxes[n, :, 1].clamp_(min=0, max=h - 1)
+            boxes[n, :, 2].clamp_(min=0, max=w - 1)
+            boxes[n, :, 3].clamp_(min=0, max=h - 1)
+        return scores, boxes
+
+    def forward(self, anchors, objectness, box_regression, targets=None):
+        num_levels, N = len(objectness), objectness[0].shape[0]
+        per_level_anchors = list(zip(*anchors))
+        seg_boxes, seg_scores, offsets, owner = [], [], [0], []
+        for lvl, (a, o, b) in enumerate(zip(per_level_anchors, objectness, box_regression)):
+            scores, boxes = self._candidates(a, o, b)
+            for n in range(N):
+                sb, ss = boxes[n], scores[n]
+                if self.min_size > 0:       # remove_small_boxes; with MIN_SIZE = 0 every decoded box passes
+                    keep = ((sb[:, 2] - sb[:, 0] + 1 >= self.min_size) & (sb[:, 3] - sb[:, 1] + 1 >= self.min_size))
+                    sb, ss = sb[keep], ss[keep]
+                seg_boxes.append(sb)
+                seg_scores.append(ss)
+                offsets.append(offsets[-1] + sb.shape[0])
+                owner.append(n)
+        all_boxes, all_scores = torch.cat(seg_boxes, 0).contiguous(), torch.cat(seg_scores, 0).contiguous()
+        keep, counts = nms_segments(all_boxes, all_scores, None, offsets, self.nms_thresh, 0)
+        counts = counts.tolist()                               # the one host sync of the proposal stage
+        per_image = [[] for _ in range(N)]
+        for s, n in enumerate(owner):
+            c = counts[s] if self.post_nms_top_n <= 0 else min(counts[s], self.post_nms_top_n)
+            sel = keep[offsets[s]: offsets[s] + c] + offsets[s]
+            bl = BoxList(all_boxes[sel], anchors[n][0].size, mode="xyxy")
+            bl.add_field("objectness", all_scores[sel])
+            per_image[n].append(bl)
+        boxlists = [cat_boxlist(b) for b in per_image]
+        if num_levels > 1:
+            boxlists = self.select_over_all_levels(boxlists)
+        if self.training and targets is not None:
+            boxlists = self.add_gt_proposals(boxlists, targets)
+        return boxlists
+
+    def select_over_all_levels(self, boxlists):
+        if self.training and self.fpn_post_nms_per_batch:
+            obj = torch.cat([b.get_field("objectness") for b in boxlists], dim=0)
+            sizes = [len(b) for b in boxlists]
+            k = min(self.fpn_post_nms_top_n, len(obj))
+            _, inds = torch.topk(obj, k, dim=0, sorted=True)
+            mask = torch.zeros_like(obj, dtype=torch.bool)
+            mask[inds] = True
+            return [b[m] for b, m in zip(boxlists, mask.split(sizes))]
+        out = []
+        for b in boxlists:
+            obj = b.get_field("objectness")
+            _, inds = torch.topk(obj, min(self.fpn_post_nms_top_n, len(obj)), dim=0, sorted=True)
+            out.append(b[inds])
+        return out
+
+
+def make_rpn_postprocessor(rpn_box_coder, is_train):
+    R = cfg.RPN
+    return RPNPostProcessor(
+        pre_nms_top_n=R.PRE_NMS_TOP_N_TRAIN if is_train else R.PRE_NMS_TOP_N_TEST,
+        post_nms_top_n=R.POST_NMS_TOP_N_TRAIN if is_train else R.POST_NMS_TOP_N_TEST,
+        nms_thresh=R.NMS_THRESH, min_size=R.MIN_SIZE, box_coder=rpn_box_coder,
+        fpn_post_nms_top_n=R.FPN_POST_NMS_TOP_N_TRAIN if is_train else R.FPN_POST_NMS_TOP_N_TEST,
+        fpn_post_nms_per_batch=R.FPN_POST_NMS_PER_BATCH)

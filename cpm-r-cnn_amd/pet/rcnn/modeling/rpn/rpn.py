@@ -1,0 +1,68 @@
+"""RPN module (counterpart of pet/rcnn/modeling/rpn/rpn.py:12-136): shared 3x3 conv (+ReLU fused) and the
+1x1 objectness / box-delta convs on every FPN level, proposal selection under no_grad, loss."""
+import torch
+from torch import nn
+
+import pet.lib.ops as ops
+from pet.rcnn.core.config import cfg
+from pet.rcnn.modeling.rpn.anchor_generator import make_anchor_generator
+from pet.rcnn.modeling.rpn.inference import make_rpn_postprocessor
+from pet.rcnn.modeling.rpn.loss import make_rpn_loss_evaluator
+from pet.rcnn.utils.box_coder import BoxCoder
+
+
+class RPNHead(nn.Module):
+    def __init__(self, dim_in, num_anchors):
+        super().__init__()
+        self.dim_in = dim_in[-1]
+        self.conv = ops.Conv2d(self.dim_in, self.dim_in, kernel_size=3, stride=1, padding=1)
+        self.cls_logits = ops.Conv2d(self.dim_in, num_anchors, kernel_size=1, stride=1)
+        self.bbox_pred = ops.Conv2d(self.dim_in, num_anchors * 4, kernel_size=1, stride=1)
+        for l in (self.conv, self.cls_logits, self.bbox_pred):
+            nn.init.normal_(l.weight, std=0.01)
+            nn.init.constant_(l.bias, 0)
+
+    def forward(self, x):
+        logits, bbox_reg = [], []
+        for feature in x:
+            t = self.conv(feature, relu=True)
+            logits.append(self.cls_logits(t))
+            bbox_reg.append(self.bbox_pred(t))
+        return logits, bbox_reg
+
+
+class RPNModule(nn.Module):
+    def __init__(self, dim_in):
+        super().__init__()
+        self.anchor_generator = make_anchor_generator()
+        self.head = RPNHead(dim_in, self.anchor_generator.num_anchors_per_location()[0])
+        coder = BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
+        self.box_selector_train = make_rpn_postprocessor(coder, is_train=True)
+        self.box_selector_test = make_rpn_postprocessor(coder, is_train=False)
+        self.loss_evaluator = make_rpn_loss_evaluator(coder)
+
+    def forward(self, images, features, targets=None):
+        objectness, rpn_box_regression = self.head(features)
+        anchors = self.anchor_generator(images, features)
+        if self.training:
+            return self._forward_train(anchors, objectness, rpn_box_regression, targets)
+        return self._forward_test(anchors, objectness, rpn_box_regression)
+
+    def _forward_train(self, anchors, objectness, rpn_box_regression, targets):
+        if cfg.MODEL.RPN_ONLY:
+            boxes = anchors
+        else:
+            with torch.no_grad():
+                boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+        loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+        return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
+
+    def _forward_test(self, anchors, objectness, rpn_box_regression):
+        boxes = self.box_selector_test(anchors, objectness, rpn_box_regression)
+        if cfg.MODEL.RPN_ONLY:
+            boxes = [b[b.get_field("objectness").sort(descending=True)[1]] for b in boxes]
+        return boxes, {}
+
+
+def build_rpn(dim_in):
+    return RPNModule(dim_in)

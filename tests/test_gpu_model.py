@@ -1,0 +1,167 @@
+"""GPU: the whole module tree (backbone, FPN, RPN head, cls / grid / rescore heads) against outputs of the
+REFERENCE model under identical name-keyed deterministic weights (tests/golden/model_r50.npz), forward and
+backward; plus a full training step on a small synthetic batch."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from test_host_logic import CPM_OPTS
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+@pytest.fixture(scope="module")
+def model():
+    from detfill import det_fill_
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS)
+    m = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+    det_fill_(m)
+    m = m.cuda().to(memory_format=CL)
+    yield m
+    config.reset_cfg()
+
+
+def test_forward_matches_reference(model, golden_model):
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_model
+    model.eval()
+    with torch.no_grad():
+        x = torch.from_numpy(g["m_img"]).cuda()
+        c = model.Conv_Body(x)
+        for i, t in enumerate(c):
+            assert rel(t[:, ::8], g["m_c%d" % (i + 2)]) < 1e-3, "C%d" % (i + 2)
+        p = model.Conv_Body_FPN(c)
+        assert len(p) == 5
+        for i, t in enumerate(p):
+            assert rel(t[:, ::8], g["m_p%d" % (i + 2)]) < 1e-3, "P%d" % (i + 2)
+        lo, br = model.RPN.head(p)
+        for i in range(5):
+            assert rel(lo[i], g["m_rpn_logits_%d" % i]) < 1e-3 and rel(br[i], g["m_rpn_bbox_%d" % i]) < 1e-3
+        boxes = [BoxList(torch.from_numpy(g["m_rois"]).cuda(), (96, 64))]
+        G = model.Grid_Cascade_RCNN
+        f = G.Head_cls(p, boxes)
+        assert rel(f, g["m_cls_feat"]) < 1e-3
+        assert rel(G.Output_cls(f), g["m_cls_logits"]) < 1e-3
+        assert rel(G.Output_rescore(G.Head_rescore(p, boxes)), g["m_rescore_logits"]) < 1e-3
+        for s in range(3):
+            xg, _ = getattr(G, "Head_grid_%d" % s)(p, boxes)
+            assert rel(xg[:, ::16], g["m_grid_feat_%d" % s]) < 1e-3
+            hm, iou = getattr(G, "Output_grid_%d" % s)(xg, None)
+            assert hm["unfused"].shape == (6, 9, 28, 28)
+            assert rel(hm["unfused"], g["m_grid_heat_%d" % s]) < 1e-3
+            if s == 2:
+                assert rel(iou, g["m_grid_iou_2"]) < 1e-3
+            else:
+                assert iou is None
+
+
+def test_backward_matches_reference(model, golden_model):
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_model
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_r50_meta.json")))
+    model.train()
+    model.zero_grad(set_to_none=True)
+    x = torch.from_numpy(g["m_img"]).cuda()
+    boxes = [BoxList(torch.from_numpy(g["m_rois"]).cuda(), (96, 64))]
+    G = model.Grid_Cascade_RCNN
+    p = model.Conv_Body_FPN(model.Conv_Body(x))
+    xg, _ = G.Head_grid_2(p, boxes)
+    hm, iou = G.Output_grid_2(xg, None)
+    loss = (hm["unfused"] ** 2).mean() + (iou ** 2).mean() + (G.Output_cls(G.Head_cls(p, boxes)) ** 2).mean()
+    lo, br = model.RPN.head(p)
+    loss = loss + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)
+    loss.backward()
+    assert abs(float(loss) - float(g["m_loss"])) / abs(float(g["m_loss"])) < 1e-3
+    params = dict(model.named_parameters())
+    worst = 0.0
+    for k, (s1, sabs, s2) in meta["grad_stats"].items():
+        gq = params[k].grad
+        assert gq is not None, k
+        gd = gq.double()
+        # compare the L2 norm (robust), and the L1 norm, of every trainable tensor's gradient
+        e2 = abs(float((gd ** 2).sum()) - s2) / (abs(s2) + 1e-30)
+        e1 = abs(float(gd.abs().sum()) - sabs) / (abs(sabs) + 1e-30)
+        worst = max(worst, e1, e2)
+        assert e1 < 2e-3 and e2 < 2e-3, (k, e1, e2)
+    for key in g.files:
+        if key.startswith("m_grad::"):
+            k = key[len("m_grad::"):]
+            gq = params[k].grad.detach().contiguous().reshape(-1)       # logical (NCHW) order
+            sub = gq[::max(1, gq.numel() // 4096)].cpu().numpy()
+            assert rel(sub, g[key]) < 2e-3, k
+    frozen = [k for k, q in params.items() if not q.requires_grad]
+    assert all(params[k].grad is None for k in frozen)
+
+
+def synthetic_batch(n, h, w, gts, seed):
+    """SURVEY 8d synthetic inputs: U(0,255) - BGR means, `gts` random boxes per image with labels in 1..80."""
+    from pet.utils.data.structures.bounding_box import BoxList
+    gen = torch.Generator().manual_seed(seed)
+    means = torch.tensor([102.9801, 115.9465, 122.7717]).view(1, 3, 1, 1)
+    images = torch.rand(n, 3, h, w, generator=gen) * 255 - means
+    targets = []
+    for _ in range(n):
+        bw = torch.rand(gts, generator=gen) * (min(400, w // 2) - 32) + 32
+        bh = torch.rand(gts, generator=gen) * (min(400, h // 2) - 32) + 32
+        x1 = torch.rand(gts, generator=gen) * (w - bw - 1)
+        y1 = torch.rand(gts, generator=gen) * (h - bh - 1)
+        t = BoxList(torch.stack([x1, y1, x1 + bw, y1 + bh], 1), (w, h), mode="xyxy")
+        t.add_field("labels", torch.randint(1, 81, (gts,), generator=gen))
+        targets.append(t)
+    return images, targets
+
+
+def test_training_step_small(model):
+    """Full train-mode forward + backward (RPN proposals, NMS, sampling, 3 grid stages, ISM, RSM)."""
+    model.train()
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(0)
+    images, targets = synthetic_batch(2, 256, 320, 6, seed=3)
+    out = model(images.cuda(), [t.to("cuda") for t in targets])
+    losses = out["losses"]
+    assert set(losses) == {"loss_objectness", "loss_rpn_box_reg", "loss_classifier", "loss_grid_1", "loss_grid_2",
+                           "loss_grid_3", "loss_iou_3", "loss_rescore"}
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    n_grad = 0
+    for k, q in model.named_parameters():
+        if q.requires_grad:
+            assert q.grad is not None and torch.isfinite(q.grad).all(), k
+            n_grad += 1
+    assert n_grad == 196
+    counts = model.Grid_Cascade_RCNN.last_counts
+    assert counts["cls"] > 0 and counts["grid_0"] >= 12          # at least the gt boxes are positives
+
+
+def test_inference_single_image(model):
+    """Test-mode forward (one image per forward): cls -> ml_nms -> 3 stages -> ISM -> RSM."""
+    from pet.rcnn.core.config import cfg
+    model.eval()
+    images, _ = synthetic_batch(1, 256, 320, 4, seed=5)
+    old = cfg.GRID_RCNN.SCORE_THRESH
+    cfg.GRID_RCNN.SCORE_THRESH = 0.0125          # random weights give ~uniform class scores (1/81)
+    try:
+        with torch.no_grad():
+            res = model(images.cuda())
+    finally:
+        cfg.GRID_RCNN.SCORE_THRESH = old
+    assert len(res) == 1
+    r = res[0]
+    assert r.bbox.shape[1] == 4 and r.has_field("scores") and r.has_field("labels")
+    if len(r):
+        assert torch.isfinite(r.bbox).all() and (r.get_field("labels") > 0).all()

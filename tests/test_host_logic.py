@@ -1,0 +1,164 @@
+"""CPU-only: the device-agnostic host logic of the pet.* mirror against vectors captured from the reference
+(tests/golden/ops.npz) and against the oracle.  No HIP kernel is launched here."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+R50_YAML = ("/root/reference/cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/"
+            "e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
+
+CPM_OPTS = ["MODEL.FPN_ON", True, "MODEL.FASTER_RCNN", False, "MODEL.GRID_ON", True, "MODEL.NUM_CLASSES", 81,
+            "MODEL.CONV1_RGB2BGR", False, "RPN.ANCHOR_STRIDE", (4, 8, 16, 32, 64), "RPN.PRE_NMS_TOP_N_TRAIN", 2000,
+            "RPN.PRE_NMS_TOP_N_TEST", 1000, "RPN.POST_NMS_TOP_N_TEST", 1000, "RPN.FPN_POST_NMS_TOP_N_TEST", 1000,
+            "GRID_RCNN.NMS", 0.3, "GRID_RCNN.SCORE_THRESH", 0.03, "GRID_RCNN.FUSED_ON", False,
+            "GRID_RCNN.IOU_HELPER", True, "GRID_RCNN.IOU_HELPER_MERGE", True, "GRID_RCNN.RESCORE_ON", True,
+            "GRID_RCNN.CASCADE_MAPPING_ON", True, "GRID_RCNN.CASCADE_MAPPING_OPTION.TEST_ENSEMBLE", False]
+
+
+@pytest.fixture()
+def cpm_cfg():
+    from pet.rcnn.core import config
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS)
+    yield config.cfg
+    config.reset_cfg()
+
+
+def test_cfg_yaml_merge(tmp_path):
+    from pet.rcnn.core import config
+    config.reset_cfg()
+    y = tmp_path / "c.yaml"
+    y.write_text("MODEL:\n  FPN_ON: True\n  NUM_CLASSES: 81\nBACKBONE:\n  RESNET:\n    LAYERS: (3, 4, 23, 3)\n"
+                 "RPN:\n  ANCHOR_STRIDE: (4, 8, 16, 32, 64)\nSOLVER:\n  STEPS: [120000, 160000]\n  BASE_LR: 0.02\n"
+                 "GRID_RCNN:\n  CASCADE_MAPPING_OPTION:\n    FG_IOU_THRESHOLD: (0.5, 0.6, 0.7)\n"
+                 "PIXEL_MEANS: [102.9801, 115.9465, 122.7717]\n")
+    config.merge_cfg_from_file(str(y))
+    c = config.cfg
+    assert c.MODEL.FPN_ON is True and c.BACKBONE.RESNET.LAYERS == (3, 4, 23, 3)
+    assert c.GRID_RCNN.CASCADE_MAPPING_OPTION.FG_IOU_THRESHOLD == [0.5, 0.6, 0.7]      # tuple -> list coercion
+    assert isinstance(c.PIXEL_MEANS, np.ndarray) and c.SOLVER.STEPS == [120000, 160000]
+    config.merge_cfg_from_list(["SOLVER.BASE_LR", "0.01", "TRAIN.SCALES", "(800,)"])
+    assert c.SOLVER.BASE_LR == 0.01 and c.TRAIN.SCALES == (800,)
+    with pytest.raises(KeyError):
+        bad = tmp_path / "bad.yaml"
+        bad.write_text("NO_SUCH_KEY: 1\n")
+        config.merge_cfg_from_file(str(bad))
+    with pytest.raises(ValueError):
+        config.merge_cfg_from_list(["SOLVER.BASE_LR", "abc"])
+    config.reset_cfg()
+
+
+@pytest.mark.skipif(not os.path.exists(R50_YAML), reason="reference tree not present on this box")
+def test_reference_yamls_parse_unchanged():
+    from pet.rcnn.core import config
+    base = os.path.dirname(R50_YAML)
+    for f in [R50_YAML, base + "/backbone/e2e_grid_cascade@567_rcnn_R-101-FPN_2x.yaml",
+              base + "/backbone/e2e_grid_cascade@567_rcnn_X-101b-64x4d-FPN-DCN_2x.yaml"]:
+        config.reset_cfg()
+        config.merge_cfg_from_file(f)
+        assert config.cfg.GRID_RCNN.CASCADE_MAPPING_ON and config.cfg.GRID_RCNN.RESCORE_ON
+    config.reset_cfg()
+    config.merge_cfg_from_file(R50_YAML)
+    ref = dict(zip(CPM_OPTS[0::2], CPM_OPTS[1::2]))
+    for k, v in ref.items():
+        node = config.cfg
+        for part in k.split("."):
+            node = node[part]
+        assert node == v, k
+    config.reset_cfg()
+
+
+def test_anchor_generator(golden_ops, cpm_cfg):
+    from pet.rcnn.modeling.rpn.anchor_generator import AnchorGenerator, generate_anchors, make_anchor_generator
+    g = golden_ops
+    assert np.array_equal(generate_anchors(16, (128, 256, 512), (0.5, 1, 2)).float().numpy(), g["anchors_matlab_table"])
+    ag = make_anchor_generator()
+    assert isinstance(ag, AnchorGenerator) and ag.num_anchors_per_location() == [3] * 5
+    for i, c in enumerate(ag.cell_anchors):
+        assert np.array_equal(c.numpy(), g["cell_anchors_%d" % i])
+    grids = ag.grid_anchors([(5, 7), (3, 4), (2, 2), (1, 2), (1, 1)])
+    for i, a in enumerate(grids):
+        assert np.array_equal(a.numpy(), g["grid_anchors_%d" % i])
+    assert np.array_equal(ag.visibility(grids[0], 28, 20).numpy(), g["grid_anchors_0_visibility"])
+    assert list(ag.state_dict().keys()) == ["cell_anchors.%d" % i for i in range(5)]
+
+
+def test_box_coder_matcher_iou_levelmapper(golden_ops):
+    from pet.rcnn.utils.box_coder import BoxCoder
+    from pet.rcnn.utils.matcher import Matcher
+    from pet.rcnn.utils.poolers import LevelMapper
+    from pet.utils.data.structures.bounding_box import BoxList
+    from pet.utils.data.structures.boxlist_ops import boxlist_iou
+    g = golden_ops
+    t = torch.from_numpy
+    bc = BoxCoder((1., 1., 1., 1.))
+    assert np.array_equal(bc.decode(t(g["bc_codes"]), t(g["bc_boxes"])).numpy(), g["bc_decode"])
+    assert np.array_equal(bc.encode(t(g["bc_gt"]), t(g["bc_boxes"])).numpy(), g["bc_encode"])
+    iou = boxlist_iou(BoxList(t(g["iou_gt"]), (1333, 800)), BoxList(t(g["iou_props"]), (1333, 800)))
+    assert np.array_equal(iou.numpy(), g["iou_out"])
+    assert np.array_equal(Matcher(0.7, 0.3, True)(iou.clone()).numpy(), g["match_rpn"])
+    assert np.array_equal(Matcher(0.5, 0.5, False)(iou.clone()).numpy(), g["match_cls"])
+    assert np.array_equal(Matcher(0.7, 0.7, False)(iou.clone()).numpy(), g["match_g2"])
+    lv = LevelMapper(2, 5)([BoxList(t(g["lvl_boxes"]), (1333, 800))])
+    assert np.array_equal(lv.numpy(), g["lvl_out"])
+    with pytest.raises(ValueError):
+        Matcher(0.5, 0.5)(torch.zeros(0, 4))
+
+
+def test_losses(golden_ops):
+    from pet.lib.ops.losses import l2_loss, smooth_l1_loss
+    g = golden_ops
+    t = torch.from_numpy
+    assert np.array_equal(smooth_l1_loss(t(g["sl1_a"]), t(g["sl1_b"]), beta=1. / 9, reduction="sum").numpy(), g["sl1_out"])
+    assert np.array_equal(l2_loss(t(g["l2_x"]), t(g["l2_t"])).numpy(), g["l2_out"])
+
+
+@pytest.mark.parametrize("stage,ratio", [(0, 1.0), (1, 0.5), (2, 0.25)])
+def test_grid_targets_and_decoder(golden_ops, cpm_cfg, stage, ratio):
+    from pet.rcnn.modeling.grid_cascade_rcnn.inference import post_processor
+    from pet.rcnn.modeling.grid_cascade_rcnn.loss import loss_evaluator
+    from pet.rcnn.modeling.grid_rcnn.loss import calc_sub_regions
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_ops
+    assert np.array_equal(np.array(calc_sub_regions(9, 3, 56), np.int32), g["sub_regions"])
+    ev = loss_evaluator(stage=stage, type="grid")
+    ev.pos_result = (torch.from_numpy(g["grid_boxes"]), torch.from_numpy(g["grid_gt"]))
+    tg = ev.prepare_target()
+    assert np.array_equal(tg.numpy(), g["grid_targets_s%d" % stage])          # bit-exact rasterisation
+    pp = post_processor(stage=stage, type="grid")
+    boxes = pp.get_boxes(BoxList(torch.from_numpy(g["grid_boxes"].copy()), (1333, 800)),
+                         torch.from_numpy(g["grid_logits_s%d" % stage]), False)
+    np.testing.assert_allclose(boxes.numpy(), g["grid_decode_s%d" % stage], rtol=1e-6, atol=1e-4)
+
+
+def test_filter_boxes_and_sampler(cpm_cfg):
+    from pet.rcnn.modeling.grid_cascade_rcnn.inference import post_processor
+    from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+    from pet.utils.data.structures.bounding_box import BoxList
+    pp = post_processor(stage=0, type="grid")
+    gt = BoxList(torch.tensor([[10., 20., 50., 60.], [0., 0., 5., 5.]]), (100, 100))
+    pr = BoxList(torch.tensor([[10., 20., 50., 60.], [10., 21., 50., 60.], [0., 0., 5., 5.], [1., 2., 3., 4.]]), (100, 100))
+    assert pp._filter_boxes(pr, gt).tolist() == [1, 3]
+    torch.manual_seed(0)
+    m = torch.tensor([1] * 10 + [0] * 500 + [-1] * 20)
+    pos, neg = BalancedPositiveNegativeSampler(64, 0.25)([m])
+    assert pos[0].dtype == torch.bool and int(pos[0].sum()) == 10 and int(neg[0].sum()) == 54
+    assert not bool((pos[0] & neg[0]).any()) and not bool(pos[0][510:].any() | neg[0][510:].any())
+
+
+def test_model_state_dict_abi(cpm_cfg):
+    """Same module tree as the reference: every state-dict key and shape, and the same trainable set
+    (tests/golden/model_r50_meta.json was dumped from the reference model)."""
+    import json
+    from conftest import ROOT
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_r50_meta.json")))
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+    got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    assert got == meta["state_dict"]
+    assert [k for k, p in model.named_parameters() if p.requires_grad] == meta["trainable"]
+    n = sum(p.numel() for p in model.parameters())
+    assert abs(n - 153.89e6) < 0.02e6
