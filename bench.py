@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training throughput (img/s) of R-50-FPN CPM R-CNN, bs = 2 per GPU, synthetic
+3x800x1333 batches (BASELINE.json configs[1]; configs[2] when launched on N GPUs).
+
+    python bench.py --gpus 1 --steps 30 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+One "step" = the reference's training iteration (tools/rcnn/train_net.py:62-78): scheduler.step, zero_grad,
+forward (backbone, FPN, RPN + proposal NMS, cls head, 3 CPM grid stages + ISM, RSM), loss sum, backward,
+gradient all-reduce (N > 1), SGD step.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line
+with the throughput, the roofline of the dominant kernel (fp32-MFMA implicit-GEMM conv, HIP-event timed) and, on
+one GPU, the CPU baseline (oracle/cpu_model.py: torch-CPU convs + C-oracle RoIAlign on the host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "cpm-r-cnn_amd"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+CPM_R50_OPTS = [  # cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml
+    "MODEL.FPN_ON", True, "MODEL.FASTER_RCNN", False, "MODEL.GRID_ON", True, "MODEL.NUM_CLASSES", 81,
+    "MODEL.CONV1_RGB2BGR", False, "BACKBONE.CONV_BODY", "resnet", "BACKBONE.RESNET.LAYERS", (3, 4, 6, 3),
+    "RPN.ANCHOR_STRIDE", (4, 8, 16, 32, 64), "RPN.PRE_NMS_TOP_N_TRAIN", 2000, "RPN.PRE_NMS_TOP_N_TEST", 1000,
+    "RPN.POST_NMS_TOP_N_TEST", 1000, "RPN.FPN_POST_NMS_TOP_N_TEST", 1000, "GRID_RCNN.NMS", 0.3,
+    "GRID_RCNN.SCORE_THRESH", 0.03, "GRID_RCNN.FUSED_ON", False, "GRID_RCNN.IOU_HELPER", True,
+    "GRID_RCNN.IOU_HELPER_MERGE", True, "GRID_RCNN.RESCORE_ON", True, "GRID_RCNN.CASCADE_MAPPING_ON", True,
+    "GRID_RCNN.CASCADE_MAPPING_OPTION.STAGE_NUM", 3, "GRID_RCNN.CASCADE_MAPPING_OPTION.TEST_STAGE", 3,
+    "GRID_RCNN.CASCADE_MAPPING_OPTION.TEST_ENSEMBLE", False,
+    "GRID_RCNN.CASCADE_MAPPING_OPTION.FG_IOU_THRESHOLD", (0.5, 0.6, 0.7),
+    "GRID_RCNN.CASCADE_MAPPING_OPTION.BG_IOU_THRESHOLD", (0.5, 0.6, 0.7),
+    "SOLVER.WEIGHT_DECAY", 0.0001, "SOLVER.BASE_LR", 0.02, "SOLVER.GAMMA", 0.1, "SOLVER.WARM_UP_ITERS", 500,
+    "SOLVER.MAX_ITER", 180000, "SOLVER.STEPS", [120000, 160000], "TRAIN.SCALES", (800,), "TRAIN.MAX_SIZE", 1333,
+    "TEST.SCALE", 800, "TEST.MAX_SIZE", 1333,
+]
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def synthetic_batch(n, h, w, gts, seed, device):
+    """U(0,255) minus the BGR pixel means; `gts` boxes per image, w,h ~ U(32,400), labels 1..80."""
+    from pet.utils.data.structures.bounding_box import BoxList
+    from pet.utils.data.structures.image_list import to_image_list
+    gen = torch.Generator().manual_seed(seed)
+    means = torch.tensor([102.9801, 115.9465, 122.7717]).view(3, 1, 1)
+    images = [torch.rand(3, h, w, generator=gen) * 255 - means for _ in range(n)]
+    targets = []
+    for _ in range(n):
+        bw = torch.rand(gts, generator=gen) * (400 - 32) + 32
+        bh = torch.rand(gts, generator=gen) * (400 - 32) + 32
+        x1 = torch.rand(gts, generator=gen) * (w - 1)
+        y1 = torch.rand(gts, generator=gen) * (h - 1)
+        box = torch.stack([x1, y1, (x1 + bw).clamp(max=w - 1), (y1 + bh).clamp(max=h - 1)], 1)
+        box[:, 0] = torch.min(box[:, 0], box[:, 2] - 16).clamp(min=0)
+        box[:, 1] = torch.min(box[:, 1], box[:, 3] - 16).clamp(min=0)
+        t = BoxList(box, (w, h), mode="xyxy")
+        t.add_field("labels", torch.randint(1, 81, (gts,), generator=gen))
+        targets.append(t.to(device))
+    il = to_image_list(images, 32)
+    il.tensors = il.tensors.to(device)
+    return il, targets
+
+
+class Trainer(object):
+    """The reference's loop body (tools/rcnn/train_net.py:62-78) over the HIP model."""
+
+    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3)):
+        from pet.rcnn.core import config
+        from pet.rcnn.modeling.model_builder import Generalized_RCNN
+        from pet.utils.lr_scheduler import LearningRateScheduler
+        from pet.utils.net import convert_bn2affine_model
+        from pet.utils.optimizer import Optimizer
+        from pet.utils.parallel import FlatGradReducer
+        config.reset_cfg()
+        config.merge_cfg_from_list(CPM_R50_OPTS)
+        config.merge_cfg_from_list(["BACKBONE.RESNET.LAYERS", tuple(layers)])
+        self.cfg = config.cfg
+        torch.manual_seed(seed_weights)                       # identical weights on every rank
+        model = Generalized_RCNN(is_train=True)
+        model = convert_bn2affine_model(model, merge=True)    # MODEL.BATCH_NORM == 'freeze'
+        self.model = model.to(device).to(memory_format=torch.channels_last)
+        self.model.train()
+        self.optimizer = Optimizer(self.model, self.cfg.SOLVER).build()
+        self.scheduler = LearningRateScheduler(self.optimizer, self.cfg.SOLVER, start_iter=0)
+        self.reducer = FlatGradReducer(self.optimizer)
+        self.last_losses = None
+
+    def step(self, images, targets):
+        self.scheduler.step()
+        self.optimizer.zero_grad()
+        self.reducer.begin_step()
+        out = self.model(images, targets)
+        loss = sum(out["losses"].values())
+        loss.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        self.last_losses = out["losses"]
+        return loss
+
+
+def conv_roofline(trainer, images, targets, steps=2):
+    """HIP-event time of every conv launch (events recorded on the launch stream inside the library) over
+    `steps` extra iterations; algorithmic flops = 2*N*P*Q*K*R*S*C/g per launch."""
+    from pet.lib.ops import _hip as H
+    L = H.lib()
+    torch.cuda.synchronize()
+    L.cpm_prof_enable(1)
+    for _ in range(steps):
+        trainer.step(images, targets)
+    torch.cuda.synchronize()
+    kinds = {}
+    for kind, name in ((0, "igemm_fwd"), (1, "igemm_dgrad"), (2, "wgrad")):
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
+        L.cpm_prof_summary(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        kinds[name] = dict(ms=ms.value / steps, gflop=fl.value / steps / 1e9, launches=n.value // steps)
+    L.cpm_prof_enable(0)
+    # dominant kernel = igemm_kernel<...> (forward-gather + data-gradient-gather instantiations of one template)
+    ms = kinds["igemm_fwd"]["ms"] + kinds["igemm_dgrad"]["ms"]
+    gf = kinds["igemm_fwd"]["gflop"] + kinds["igemm_dgrad"]["gflop"]
+    achieved = gf / ms if ms > 0 else 0.0          # GFLOP/ms == TFLOP/s
+    allms = ms + kinds["wgrad"]["ms"]
+    allgf = gf + kinds["wgrad"]["gflop"]
+    return {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad, fp32 MFMA 32x32x2)",
+            "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_F32_PEAK_TFLOPS, 4), "traffic": None,
+            "per_step": {k: {"ms": round(v["ms"], 3), "gflop": round(v["gflop"], 1), "launches": v["launches"]}
+                         for k, v in kinds.items()},
+            "all_conv_kernels": {"ms_per_step": round(allms, 3), "tflops": round(allgf / allms, 2) if allms else 0.0}}
+
+
+def cpu_baseline(trainer, h, w, seed):
+    """oracle/cpu_model.py on the host cores: forward+backward conv/FC/RoIAlign work of one training iteration
+    for ONE image (bounded sample), RoI counts = this run's per-image averages."""
+    from oracle import cpu_model as M
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))             # the GPU box's CPU share for one GPU is 16 cores
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu().contiguous().clone().requires_grad_(v.requires_grad and v.dtype.is_floating_point)
+          for k, v in trainer.model.state_dict(keep_vars=True).items() if "cell_anchors" not in k}
+    counts = trainer.model.Grid_Cascade_RCNN.last_counts
+    gen = torch.Generator().manual_seed(seed)
+    hp = (h + 31) // 32 * 32
+    wp = (w + 31) // 32 * 32
+    img = torch.rand(1, 3, hp, wp, generator=gen) * 255 - 110
+
+    def rois(k):
+        k = max(int(k), 1)
+        x1, y1 = torch.rand(k, generator=gen) * (w - 64), torch.rand(k, generator=gen) * (h - 64)
+        bw, bh = torch.rand(k, generator=gen) * 300 + 32, torch.rand(k, generator=gen) * 300 + 32
+        return torch.stack([torch.zeros(k), x1, y1, (x1 + bw).clamp(max=w - 1), (y1 + bh).clamp(max=h - 1)], 1)
+
+    per_img = {k: v / 2 for k, v in counts.items()}
+    args = (rois(per_img.get("cls", 512)), [rois(per_img.get("grid_%d" % s, 16)) for s in range(3)],
+            rois(per_img.get("rescore", 512)))
+    t0 = time.time()
+    M.train_step_compute(sd, img, *args)
+    dt = time.time() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "1 image (bs=1) forward+backward of the conv/FC/RoIAlign stacks, RoIs per image: %s; "
+                      "torch-CPU fp32 convs + C-oracle RoIAlign; one un-warmed step, %.1f s"
+                      % ({k: int(v) for k, v in per_img.items()}, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--batch", type=int, default=2, help="images per GPU")
+    ap.add_argument("--layers", type=str, default="3,4,6,3", help="ResNet depth: 3,4,6,3 (R-50) / 3,4,23,3 (R-101)")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", init_method="env://")      # "nccl" is RCCL on ROCm
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    import __graft_entry__ as entry
+    entry.ensure_built()
+    layers = tuple(int(x) for x in a.layers.split(","))
+    trainer = Trainer(device, layers=layers)
+    images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(images, targets)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        trainer.step(images, targets)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    losses = {k: float(v.detach()) for k, v in trainer.last_losses.items()}
+    counts = dict(trainer.model.Grid_Cascade_RCNN.last_counts)
+
+    roof, cpu = None, None
+    if not a.no_roofline and rank == 0:
+        roof = conv_roofline(trainer, images, targets)
+    if world > 1:
+        dist.barrier()
+    if not a.no_cpu_baseline and rank == 0 and world == 1:
+        cpu = cpu_baseline(trainer, a.height, a.width, 99)
+
+    if rank == 0:
+        n_img = a.batch * world * a.steps
+        model_name = {(3, 4, 6, 3): "R-50-FPN", (3, 4, 23, 3): "R-101-FPN"}.get(layers, "R-%s-FPN" % a.layers)
+        line = {
+            "metric": "img/sec training (R-50-FPN CPM, bs=2/GPU)", "value": round(n_img / elapsed, 3),
+            "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(1000.0 * elapsed / a.steps, 2), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s CPM R-CNN (CMM x3 + ISM + RSM) training step, %d x 3x%dx%d per GPU, "
+                                   "16 gt boxes/img, reference initialisers" % (model_name, a.batch, a.height, a.width),
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                       "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
+                                                                         for v in losses.values())},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,8 @@
 //     float atomics into a zeroed output and the epilogue runs as a second tiny kernel.
 //
 // Reference call sites replaced: see include/cpmrcnn_hip.h (conv section).
+#include <vector>
+
 #include "common.h"
 
 namespace {
@@ -457,11 +459,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // ---- host side ---------------------------------------------------------------------------------------
 int num_cus() { return 256; }
 
+// Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default:
+// the hot path pays one predictable branch.
+struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+static double g_flops_next = 0.0;
+
+struct ProfScope {
+  hipStream_t s; int kind; bool on; ProfRec r;
+  ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_), on(g_prof_on) {
+    if (on) {
+      r.kind = kind; r.flops = g_flops_next;
+      on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess &&
+           hipEventRecord(r.a, s) == hipSuccess;
+    }
+  }
+  ~ProfScope() {
+    if (on && hipEventRecord(r.b, s) == hipSuccess) g_prof.push_back(r);
+  }
+};
+
 template <int MODE>
 int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
                    (((uintptr_t)a.wm & 15) == 0);
   auto tiles = [&](int bm, int bn) { return (int64_t)cpm::cdiv(a.M, bm) * cpm::cdiv(a.OCg, bn) * a.groups; };
+  ProfScope prof_scope(s, MODE);
 #define LAUNCH(BM, BN, WM, WN)                                                                                 \
   do {                                                                                                         \
     dim3 grid((unsigned)(cpm::cdiv(a.M, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);                     \
@@ -543,6 +567,7 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
   if (a.atomic_out) {
     if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
+  g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   int rc = launch_igemm<MODE_FWD>(a, s);
   if (rc != CPM_OK) return rc;
   if (a.atomic_out && (scale || shift || residual || relu)) {
@@ -586,6 +611,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   if (a.atomic_out && !accumulate) {
     if (hipMemsetAsync(dx, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
+  g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   int rc = launch_igemm<MODE_DGRAD>(a, s);
   if (rc != CPM_OK) return rc;
   if (a.atomic_out && (shift || relu)) {
@@ -642,6 +668,8 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
     if (sk > 256) sk = 256;
     return sk;
   };
+  g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  ProfScope prof_scope(s, 2);
 #define WLAUNCH(BM, BN, WM, WN)                                                                      \
   do {                                                                                               \
     a.split_k = split_for(blocks(BM, BN));                                                           \
@@ -659,4 +687,27 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   }
 #undef WLAUNCH
   return cpm::check_launch("conv wgrad");
+}
+
+// ---- profiling hooks (bench.py roofline leg) -----------------------------------------------------------
+CPM_EXPORT int cpm_prof_enable(int on) {
+  for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return CPM_OK;
+}
+
+CPM_EXPORT int cpm_prof_summary(int kind, double* total_ms, double* total_flops, int64_t* launches) {
+  CPM_REQUIRE(total_ms && total_flops && launches, "null pointer");
+  double ms = 0.0, fl = 0.0;
+  int64_t n = 0;
+  for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) return CPM_ELAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CPM_ELAUNCH;
+    ms += t; fl += r.flops; ++n;
+  }
+  *total_ms = ms; *total_flops = fl; *launches = n;
+  return CPM_OK;
 }

@@ -1,0 +1,113 @@
+"""SGD for the CPM R-CNN schedule (counterpart of pet/utils/optimizer.py:7-78) on a flat parameter buffer.
+
+Same three parameter groups as the reference (weights: weight decay; biases: lr x2 when BIAS_DOUBLE_LR and no
+weight decay unless BIAS_WEIGHT_DECAY; GroupNorm affine: WEIGHT_DECAY_GN), each carrying `lr_scale` so that
+LearningRateScheduler drives them the same way.  What differs is the mechanics: every trainable tensor is
+re-pointed into ONE fp32 buffer (parameters), with matching flat gradient and momentum buffers, laid out in
+reverse forward order so that gradient chunks complete front-to-back during backward.  The update of all 196
+tensors is then one launch of cpm_sgd_step, and the data-parallel all-reduce works on a few large contiguous
+chunks (pet.utils.parallel) instead of per-tensor buckets."""
+import torch
+import torch.nn as nn
+
+from pet.lib.ops import _hip as H
+
+
+class FlatSGD(torch.optim.Optimizer):
+    def __init__(self, named_params, groups_cfg, momentum):
+        """named_params: list of (name, param, group_index) in flat-buffer order."""
+        params = [p for _, p, _ in named_params]
+        device = params[0].device
+        total = sum(p.numel() for p in params)
+        self.flat_param = torch.empty(total, dtype=torch.float32, device=device)
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        self.flat_mom = torch.zeros(total, dtype=torch.float32, device=device)
+        begins, ends, gidx = [], [], []
+        off = 0
+        for _, p, gi in named_params:
+            n = p.numel()
+            self._repoint(p, off, n)
+            begins.append(off)
+            ends.append(off + n)
+            gidx.append(gi)
+            off += n
+        self.names = [n for n, _, _ in named_params]
+        self.seg_begin = torch.tensor(begins, dtype=torch.int64, device=device)
+        self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)
+        self.seg_group = torch.tensor(gidx, dtype=torch.int64, device=device)
+        self.seg_lr = torch.zeros(len(begins), dtype=torch.float32, device=device)
+        self.seg_wd = torch.zeros(len(begins), dtype=torch.float32, device=device)
+        self.total, self.momentum, self._steps, self._last = total, float(momentum), 0, None
+        self.grad_scale = 1.0
+        groups = []
+        for gi, g in enumerate(groups_cfg):
+            groups.append(dict(params=[p for _, p, k in named_params if k == gi], lr=0.0,
+                               weight_decay=g["weight_decay"], lr_scale=g["lr_scale"], momentum=momentum))
+        super().__init__([g for g in groups if len(g["params"])] or groups, dict(lr=0.0, momentum=momentum,
+                                                                                weight_decay=0.0, lr_scale=1))
+        self._group_of = {}
+        for gi, g in enumerate(self.param_groups):
+            for p in g["params"]:
+                self._group_of[id(p)] = gi
+        self._seg_pg = [self._group_of[id(p)] for p in params]
+
+    def _view(self, flat, p, off, n):
+        v = flat[off:off + n]
+        if p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous():
+            k, c, r, s = p.shape
+            return v.view(k, r, s, c).permute(0, 3, 1, 2)            # KRSC bytes, logical [K,C,R,S]
+        return v.view(p.shape)
+
+    def _repoint(self, p, off, n):
+        dst = self._view(self.flat_param, p, off, n)
+        dst.copy_(p.data)
+        p.data = dst
+        p.grad = self._view(self.flat_grad, p, off, n)
+
+    def zero_grad(self, set_to_none=False):
+        self.flat_grad.zero_()                                       # one memset; .grad views stay attached
+
+    def _refresh_tables(self):
+        key = tuple((g["lr"], g["weight_decay"]) for g in self.param_groups)
+        if key != self._last:
+            lr = torch.tensor([self.param_groups[i]["lr"] for i in self._seg_pg], dtype=torch.float32)
+            wd = torch.tensor([self.param_groups[i]["weight_decay"] for i in self._seg_pg], dtype=torch.float32)
+            self.seg_lr.copy_(lr)
+            self.seg_wd.copy_(wd)
+            self._last = key
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self._refresh_tables()
+        with torch.cuda.device(self.flat_param.device):
+            rc = H.lib().cpm_sgd_step(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
+                                      H.ptr(self.seg_begin), H.ptr(self.seg_end), H.ptr(self.seg_lr),
+                                      H.ptr(self.seg_wd), len(self._seg_pg), H.c_int64(self.total),
+                                      H.f(self.momentum), H.f(self.grad_scale), int(self._steps == 0), H.stream())
+        H.check(rc, "sgd_step")
+        self._steps += 1
+
+
+class Optimizer(object):
+    def __init__(self, model, solver, local_rank=0):
+        self.model, self.solver, self.local_rank = model, solver, local_rank
+
+    def build(self):
+        S = self.solver
+        if S.OPTIMIZER != "SGD":
+            raise ValueError("only SOLVER.OPTIMIZER == 'SGD' is built (the CPM R-CNN schedule)")
+        gn_names = set()
+        for name, m in self.model.named_modules():
+            if isinstance(m, nn.GroupNorm):
+                gn_names.update((name + ".weight", name + ".bias"))
+        named = []
+        for key, p in self.model.named_parameters():
+            if not p.requires_grad:
+                continue
+            gi = 1 if "bias" in key else (2 if key in gn_names else 0)      # optimizer.py:30-38 order of tests
+            named.append((key, p, gi))
+        named.reverse()                      # reverse registration (~forward) order: backward fills front to back
+        groups = [dict(weight_decay=S.WEIGHT_DECAY, lr_scale=1),
+                  dict(weight_decay=S.WEIGHT_DECAY if S.BIAS_WEIGHT_DECAY else 0, lr_scale=S.BIAS_DOUBLE_LR + 1),
+                  dict(weight_decay=S.WEIGHT_DECAY_GN * S.WEIGHT_DECAY, lr_scale=1)]
+        return FlatSGD(named, groups, S.MOMENTUM)

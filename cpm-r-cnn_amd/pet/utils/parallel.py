@@ -1,0 +1,94 @@
+"""Data parallelism over RCCL/xGMI: one process per GPU, replicated model, flat-buffer gradient all-reduce.
+
+Counterpart of the DistributedDataParallel wrap in tools/rcnn/train_net.py:134-136 and of the per-loss
+all_reduce in pet/utils/logger.py:52-53, re-designed for the flat gradient buffer of pet.utils.optimizer:
+  * the 153.6 M-element gradient lives in one buffer ordered so that backward completes it front to back;
+  * it is cut into a few large chunks (default 8 x ~77 MB: xGMI is point-to-point, large messages amortise
+    the ring's per-link latency); a chunk's all-reduce is launched on a side stream as soon as the autograd
+    hooks have seen every tensor in it, overlapping the remaining backward;
+  * the 1/world scaling is folded into the SGD kernel (grad_scale) instead of a separate division pass;
+  * the ~9 loss scalars are reduced as ONE tensor for logging.
+Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` in the CPU tests)."""
+import torch
+import torch.distributed as dist
+
+
+def world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class FlatGradReducer(object):
+    def __init__(self, optimizer, num_chunks=8, overlap=True):
+        self.opt = optimizer
+        self.world = world()
+        self.opt.grad_scale = 1.0 / self.world
+        self.flat = optimizer.flat_grad
+        total = self.flat.numel()
+        # chunk boundaries on tensor boundaries
+        begins = optimizer.seg_begin.tolist()
+        ends = optimizer.seg_end.tolist()
+        target = (total + num_chunks - 1) // num_chunks
+        self.chunks, start, nseg = [], 0, 0
+        self.seg_chunk = []
+        for b, e in zip(begins, ends):
+            self.seg_chunk.append(len(self.chunks))
+            nseg += 1
+            if e - start >= target or e == total:
+                self.chunks.append((start, e, nseg))
+                start, nseg = e, 0
+        self.overlap = overlap and self.world > 1 and self.flat.is_cuda
+        self.stream = torch.cuda.Stream(device=self.flat.device) if self.overlap else None
+        self._pending = None
+        self._handles = []
+        if self.overlap:
+            params = [p for g in optimizer.param_groups for p in g["params"]]
+            by_id = {id(p): p for p in params}
+            order = []
+            for g in optimizer.param_groups:
+                order.extend(g["params"])
+            # map each param to its chunk through its offset in the flat buffer
+            base = self.flat.data_ptr()
+            for p in by_id.values():
+                off = (p.grad.data_ptr() - base) // 4
+                ci = next(i for i, (b, e, _) in enumerate(self.chunks) if b <= off < e)
+                p.register_post_accumulate_grad_hook(self._make_hook(ci))
+
+    def _make_hook(self, ci):
+        def hook(_):
+            self._pending[ci] -= 1
+            if self._pending[ci] == 0:
+                self._launch(ci)
+        return hook
+
+    def begin_step(self):
+        self._pending = [n for (_, _, n) in self.chunks]
+        self._handles = []
+
+    def _launch(self, ci):
+        b, e, _ = self.chunks[ci]
+        self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        with torch.cuda.stream(self.stream):
+            dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
+
+    def finish(self):
+        """Call after backward: reduce whatever is left and make the compute stream wait for the reductions."""
+        if self.world == 1:
+            return
+        if self.overlap:
+            for ci, n in enumerate(self._pending):
+                if n != 0:                      # tensors without a gradient this step (unused branch)
+                    self._launch(ci)
+            torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
+        else:
+            for b, e, _ in self.chunks:
+                dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
+
+
+def reduce_losses(losses):
+    """One collective for all logged scalars (the reference issues one blocking all_reduce per key)."""
+    keys = sorted(losses.keys())
+    vec = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+    if world() > 1:
+        dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+        vec = vec / world()
+    return dict(zip(keys, vec.tolist()))

@@ -158,6 +158,14 @@ int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, cons
 int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,
                                 void* stream);
 
+/* ---- measurement hooks (bench.py) ----------------------------------------------
+ * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and
+ * remembers the launch's ALGORITHMIC flops (2*N*P*Q*K*R*S*C/groups); cpm_prof_enable(0) stops and
+ * clears.  cpm_prof_summary sums the event durations per kernel kind: 0 = igemm forward-gather,
+ * 1 = igemm data-gradient-gather, 2 = weight gradient.  Not thread safe; off on the hot path. */
+int cpm_prof_enable(int on);
+int cpm_prof_summary(int kind, double* total_ms, double* total_flops, int64_t* launches);
+
 /* ---- fused SGD with momentum over a flat parameter buffer -------------------
  * Replaces torch.optim.SGD.step as built by pet/utils/optimizer.py:40-65 (3 param
  * groups: weights / biases (lr x2, no wd) / GN).  seg_* are device arrays of
