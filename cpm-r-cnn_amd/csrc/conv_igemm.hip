@@ -6,10 +6,9 @@
 //   out[m][oc] = sum_{tap=(r,s)} sum_{c} in[gather(m, tap)][c] * Wm[oc][tap][c]
 //
 //   * GEMM rows m = (n, oh, ow) output pixels, columns oc output channels, reduction (tap, c).
-//   * gather, FWD  : ih = oh*stride - pad + r*dil            (zero outside the image)
-//     gather, DGRAD: th = oh + pad - r*dil, ih = th/stride   (zero unless stride | th, in range)
-//     DGRAD uses the weight re-laid as Wm[c][r][s][k] (transform kernel below), so that both modes
-//     read the B operand as "row = output channel, 32 consecutive reduction elements".
+//   * gather: one parametrised description for forward and data-gradient (see IgemmArgs); the data gradient
+//     runs one launch per stride phase and uses the weight re-laid as Wm[c][r][s][k] (transform kernel below),
+//     so that both directions read the B operand as "row = output channel, 32 consecutive reduction elements".
 //   * workgroup = 256 threads = 4 waves (one per SIMD), tile BM x BN x 32, waves in a WM x WN grid,
 //     each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  fp32 in / fp32 accumulate: results are
 //     an exact-fp32 fmaf chain per output (north_star tolerance 1e-3 holds with large margin).
@@ -37,28 +36,40 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1 };
-
+// One gather description serves both directions.  GEMM row m = (n, i, j) on a (OHp x OWp) row grid:
+//   input tap  : ih = i*ihmul + ihadd + t_r*hstep,  iw = j*iwmul + iwadd + t_s*wstep   (zero outside the image)
+//   weight tap : r = r0 + t_r*rstep,                s = s0 + t_s*sstep,  t_r < nr, t_s < ns
+//   output pos : oh = i*osh + oah,                  ow = j*osw + oaw     on the full (OH x OW) output
+// forward conv   : ihmul = stride, ihadd = -pad, hstep = dil, r0 = 0, rstep = 1, nr = R, osh = 1, oah = 0
+// data gradient  : one launch per output phase (a, b) in stride x stride: rows are the outputs with
+//                  oh = i*stride + a; only the taps r = r0 + t*stride with r0 = (a + pad) % stride reach them, and
+//                  th = oh + pad - r = stride * (i + (a + pad - r0)/stride - t)  =>  ihmul = 1, hstep = -1.
+//                  No masked taps and no div/mod in the loop (a stride-2 3x3 gradient does 9/4 of the taps per
+//                  row instead of 9, a 1x1 stride-2 one runs a quarter of the rows).
 struct IgemmArgs {
   const float* in;     // [N][IH][IW][Ctot]
   const float* wm;     // [OCtot][R][S][CgR]
-  float* out;          // [M][OCtot]
+  float* out;          // [N][OH][OW][OCtot]
   const float* scale;  // [OCtot] or null
   const float* shift;  // [OCtot] or null
   const float* res;    // residual or null
   int N, IH, IW, Ctot;
-  int OH, OW, OCtot;
-  int R, S, stride, pad, dil;
+  int OH, OW, OCtot;   // full output grid
+  int OHp, OWp;        // row grid of this launch
+  int R, S;            // weight window (for the B operand pitch)
+  int ihmul, ihadd, hstep, iwmul, iwadd, wstep;
+  int r0, rstep, nr, s0, sstep, ns;
+  int osh, oah, osw, oaw;
   int groups, CgR, OCg;
-  int M;               // N*OH*OW
+  int M;               // N*OHp*OWp
   int ksteps_per_tap;  // ceil(CgR/32)
-  int ksteps;          // R*S*ksteps_per_tap
+  int ksteps;          // nr*ns*ksteps_per_tap
   int split_k;         // >= 1
   int res_mode, relu;
-  int atomic_out;      // 1: atomicAdd raw accumulators (split-K)
+  int atomic_out;      // 1: atomicAdd raw accumulators (split-K / accumulate)
 };
 
-template <int BM, int BN, int WM, int WN, int MODE, bool VEC>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;   // MFMA tiles per wave
@@ -86,17 +97,11 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     const int m = m0 + i * 32 + lrow;
     a_ok[i] = m < a.M;
     const int mm = a_ok[i] ? m : 0;
-    const int ow = mm % a.OW, t = mm / a.OW;
-    const int oh = t % a.OH, n = t / a.OH;
-    if (MODE == MODE_FWD) {
-      a_h[i] = oh * a.stride - a.pad;
-      a_w[i] = ow * a.stride - a.pad;
-      a_base[i] = ((n * a.IH + a_h[i]) * a.IW + a_w[i]) * a.Ctot + g * a.CgR;
-    } else {
-      a_h[i] = oh + a.pad;
-      a_w[i] = ow + a.pad;
-      a_base[i] = n * a.IH * a.IW * a.Ctot + g * a.CgR;
-    }
+    const int jj = mm % a.OWp, t = mm / a.OWp;
+    const int ii = t % a.OHp, n = t / a.OHp;
+    a_h[i] = ii * a.ihmul + a.ihadd;
+    a_w[i] = jj * a.iwmul + a.iwadd;
+    a_base[i] = ((n * a.IH + a_h[i]) * a.IW + a_w[i]) * a.Ctot + g * a.CgR;
   }
   int b_base[BP];
   bool b_ok[BP];
@@ -118,26 +123,16 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   auto load_tile = [&](int kt) {
     const int tap = kt / a.ksteps_per_tap;
     const int c0 = (kt - tap * a.ksteps_per_tap) * BK + lcol;
-    const int r = tap / a.S, s = tap - r * a.S;
+    const int tr = tap / a.ns, ts = tap - tr * a.ns;
+    const int dh = tr * a.hstep, dw = ts * a.wstep;
+    const int wtap = ((a.r0 + tr * a.rstep) * a.S + a.s0 + ts * a.sstep) * a.CgR;
+    const int aoff = (dh * a.IW + dw) * a.Ctot + c0;
     const bool c_ok = c0 < a.CgR;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      bool ok = a_ok[i] && c_ok;
-      int off;
-      if (MODE == MODE_FWD) {
-        const int ih = a_h[i] + r * a.dil, iw = a_w[i] + s * a.dil;
-        ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-        off = a_base[i] + (r * a.dil * a.IW + s * a.dil) * a.Ctot + c0;
-      } else {
-        const int th = a_h[i] - r * a.dil, tw = a_w[i] - s * a.dil;
-        int ih = th, iw = tw;
-        if (a.stride > 1) {
-          ok = ok && th >= 0 && tw >= 0 && (th % a.stride) == 0 && (tw % a.stride) == 0;
-          ih = th / a.stride; iw = tw / a.stride;
-        }
-        ok = ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-        off = a_base[i] + (ih * a.IW + iw) * a.Ctot + c0;
-      }
+      const int ih = a_h[i] + dh, iw = a_w[i] + dw;
+      const bool ok = a_ok[i] && c_ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+      const int off = a_base[i] + aoff;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
         if (VEC) {
@@ -155,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     for (int i = 0; i < BP; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (b_ok[i] && c_ok) {
-        const int off = b_base[i] + tap * a.CgR + c0;
+        const int off = b_base[i] + wtap + c0;
         if (VEC) {
           v = *(const float4*)(a.wm + off);
         } else {
@@ -218,31 +213,38 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   // ---- epilogue ----------------------------------------------------------------------------------
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  const bool dense_rows = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int ocl = n0 + wn * WTN + j * 32 + ecol;
-    if (ocl >= a.OCg) continue;
-    const int oc = g * a.OCg + ocl;
-    const float sc = (!a.atomic_out && a.scale) ? a.scale[oc] : 1.f;
-    const float sh = (!a.atomic_out && a.shift) ? a.shift[oc] : 0.f;
+  for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+      if (m >= a.M) continue;
+      int orow = m, oh = 0, ow = 0, n = 0;
+      if (!dense_rows || (a.res && a.res_mode == 1)) {
+        const int jj = m % a.OWp, t = m / a.OWp;
+        const int ii = t % a.OHp;
+        n = t / a.OHp;
+        oh = ii * a.osh + a.oah;
+        ow = jj * a.osw + a.oaw;
+        orow = (n * a.OH + oh) * a.OW + ow;
+      }
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
-        if (m >= a.M) continue;
+      for (int j = 0; j < TN; ++j) {
+        const int ocl = n0 + wn * WTN + j * 32 + ecol;
+        if (ocl >= a.OCg) continue;
+        const int oc = g * a.OCg + ocl;
         float v = acc[i][j][e];
-        float* dst = a.out + (size_t)m * a.OCtot + oc;
+        float* dst = a.out + (size_t)orow * a.OCtot + oc;
         if (a.atomic_out) {
           atomicAdd(dst, v);
         } else {
-          v = v * sc + sh;
+          if (a.scale) v *= a.scale[oc];
+          if (a.shift) v += a.shift[oc];
           if (a.res) {
             if (a.res_mode == 0) {
-              v += a.res[(size_t)m * a.OCtot + oc];
+              v += a.res[(size_t)orow * a.OCtot + oc];
             } else {
-              const int ow = m % a.OW, t = m / a.OW;
-              const int oh = t % a.OH, n = t / a.OH;
               const int rh = (a.OH + 1) / 2, rw = (a.OW + 1) / 2;
               v += a.res[((size_t)(n * rh + oh / 2) * rw + ow / 2) * a.OCtot + oc];
             }
@@ -480,43 +482,51 @@ struct ProfScope {
   }
 };
 
-template <int MODE>
-int launch_igemm(const IgemmArgs& a, hipStream_t s) {
-  const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
-                   (((uintptr_t)a.wm & 15) == 0);
+struct Plan { int bm, bn, split; };
+
+// tile + split-K choice: the biggest tile that still gives every CU two workgroups; thin problems take the small
+// tile and split the reduction until there are ~3 workgroups per CU (their K loops are latency bound otherwise)
+Plan plan_igemm(const IgemmArgs& a) {
   auto tiles = [&](int bm, int bn) { return (int64_t)cpm::cdiv(a.M, bm) * cpm::cdiv(a.OCg, bn) * a.groups; };
-  ProfScope prof_scope(s, MODE);
-#define LAUNCH(BM, BN, WM, WN)                                                                                 \
-  do {                                                                                                         \
-    dim3 grid((unsigned)(cpm::cdiv(a.M, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);                     \
-    if (vec)                                                                                                   \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, true>), grid, dim3(256), 0, s, a);                \
-    else                                                                                                       \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, MODE, false>), grid, dim3(256), 0, s, a);               \
-  } while (0)
-  // tile choice: widest N tile that divides the channel count well, smaller M tile when the grid is thin
-  if (a.OCg <= 32) {
-    LAUNCH(128, 32, 4, 1);
-  } else if (a.OCg <= 64 || (a.OCg % 128 != 0 && a.OCg % 64 == 0)) {
-    if (tiles(128, 64) >= 2 * num_cus()) LAUNCH(128, 64, 2, 2);
-    else LAUNCH(64, 64, 2, 2);
+  Plan p;
+  if (a.OCg <= 32) { p.bm = 128; p.bn = 32; }
+  else if (a.OCg <= 64 || (a.OCg % 128 != 0 && a.OCg % 64 == 0)) {
+    if (tiles(128, 64) >= 2 * num_cus()) { p.bm = 128; p.bn = 64; } else { p.bm = 64; p.bn = 64; }
   } else {
-    if (tiles(128, 128) >= num_cus()) LAUNCH(128, 128, 2, 2);
-    else if (tiles(128, 64) >= num_cus()) LAUNCH(128, 64, 2, 2);
-    else LAUNCH(64, 64, 2, 2);
+    if (tiles(128, 128) >= 2 * num_cus()) { p.bm = 128; p.bn = 128; }
+    else if (tiles(128, 64) >= 2 * num_cus()) { p.bm = 128; p.bn = 64; }
+    else { p.bm = 64; p.bn = 64; }
   }
-#undef LAUNCH
-  return cpm::check_launch("conv igemm");
+  const int64_t t = tiles(p.bm, p.bn);
+  p.split = 1;
+  if (t < 2 * num_cus() && a.ksteps >= 32) {
+    int want = (int)((3 * num_cus() + t - 1) / t);
+    int maxs = a.ksteps / 16;
+    p.split = want < maxs ? want : maxs;
+    if (p.split < 1) p.split = 1;
+    if (p.split > 64) p.split = 64;
+  }
+  return p;
 }
 
-int pick_split_k(int64_t tiles, int ksteps) {
-  if (tiles >= 192 || ksteps < 32) return 1;
-  int want = (int)((2 * 256 + tiles - 1) / tiles);
-  int maxs = ksteps / 16;
-  int sk = want < maxs ? want : maxs;
-  if (sk < 1) sk = 1;
-  if (sk > 64) sk = 64;
-  return sk;
+int launch_igemm(const IgemmArgs& a, const Plan& p, hipStream_t s, int prof_kind) {
+  const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
+                   (((uintptr_t)a.wm & 15) == 0);
+  ProfScope prof_scope(s, prof_kind);
+#define LAUNCH(BM, BN, WM, WN)                                                                       \
+  do {                                                                                               \
+    dim3 grid((unsigned)(cpm::cdiv(a.M, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);           \
+    if (vec)                                                                                         \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
+    else                                                                                             \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);           \
+  } while (0)
+  if (p.bm == 128 && p.bn == 128) LAUNCH(128, 128, 2, 2);
+  else if (p.bm == 128 && p.bn == 64) LAUNCH(128, 64, 2, 2);
+  else if (p.bm == 128 && p.bn == 32) LAUNCH(128, 32, 4, 1);
+  else LAUNCH(64, 64, 2, 2);
+#undef LAUNCH
+  return cpm::check_launch("conv igemm");
 }
 
 int validate(const cpm_conv_desc* d) {
@@ -554,21 +564,24 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
   IgemmArgs a = {};
   a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
   a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C;
-  a.OH = d->P; a.OW = d->Q; a.OCtot = d->K;
-  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dilation;
+  a.OH = d->P; a.OW = d->Q; a.OCtot = d->K; a.OHp = d->P; a.OWp = d->Q;
+  a.R = d->R; a.S = d->S;
+  a.ihmul = a.iwmul = d->stride; a.ihadd = a.iwadd = -d->pad; a.hstep = a.wstep = d->dilation;
+  a.r0 = a.s0 = 0; a.rstep = a.sstep = 1; a.nr = d->R; a.ns = d->S;
+  a.osh = a.osw = 1; a.oah = a.oaw = 0;
   a.groups = d->groups; a.CgR = d->C / d->groups; a.OCg = d->K / d->groups;
   a.M = d->N * d->P * d->Q;
   a.ksteps_per_tap = cpm::cdiv(a.CgR, BK);
   a.ksteps = d->R * d->S * a.ksteps_per_tap;
   a.res_mode = res_mode; a.relu = relu;
-  const int64_t tiles = (int64_t)cpm::cdiv(a.M, 64) * cpm::cdiv(a.OCg, 64) * a.groups;
-  a.split_k = pick_split_k(tiles, a.ksteps);
+  Plan p = plan_igemm(a);
+  a.split_k = p.split;
   a.atomic_out = a.split_k > 1;
   if (a.atomic_out) {
     if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
-  int rc = launch_igemm<MODE_FWD>(a, s);
+  int rc = launch_igemm(a, p, s, 0);
   if (rc != CPM_OK) return rc;
   if (a.atomic_out && (scale || shift || residual || relu)) {
     const int64_t total = (int64_t)a.M * a.OCtot;
@@ -600,25 +613,52 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   a.in = dy; a.wm = wt; a.out = dx; a.shift = shift; a.relu = relu;
   a.N = d->N; a.IH = d->P; a.IW = d->Q; a.Ctot = d->K;      // the GEMM's "input" is dy
   a.OH = d->H; a.OW = d->W; a.OCtot = d->C;                 // its "output" is dx
-  a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = 1;
+  a.R = d->R; a.S = d->S;
   a.groups = d->groups; a.CgR = Kg; a.OCg = Cg;
-  a.M = d->N * d->H * d->W;
   a.ksteps_per_tap = cpm::cdiv(a.CgR, BK);
-  a.ksteps = d->R * d->S * a.ksteps_per_tap;
-  const int64_t tiles = (int64_t)cpm::cdiv(a.M, 64) * cpm::cdiv(a.OCg, 64) * a.groups;
-  a.split_k = pick_split_k(tiles, a.ksteps);
+  const int st = d->stride;
+  // split-K / accumulate decision on the whole problem so that every phase agrees on atomics
+  IgemmArgs whole = a;
+  whole.M = d->N * d->H * d->W;
+  whole.ksteps = cpm::cdiv(d->R, st) * cpm::cdiv(d->S, st) * a.ksteps_per_tap;
+  Plan p = plan_igemm(whole);
+  a.split_k = p.split;
   a.atomic_out = (a.split_k > 1) || accumulate;
   if (a.atomic_out && !accumulate) {
-    if (hipMemsetAsync(dx, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
+    if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
-  int rc = launch_igemm<MODE_DGRAD>(a, s);
+  int rc = CPM_OK;
+  for (int pa = 0; pa < st && rc == CPM_OK; ++pa) {
+    for (int pb = 0; pb < st && rc == CPM_OK; ++pb) {
+      a.OHp = (d->H - pa + st - 1) / st;
+      a.OWp = (d->W - pb + st - 1) / st;
+      if (a.OHp <= 0 || a.OWp <= 0) continue;
+      a.r0 = (pa + d->pad) % st; a.s0 = (pb + d->pad) % st;
+      a.rstep = a.sstep = st;
+      a.nr = a.r0 < d->R ? (d->R - a.r0 + st - 1) / st : 0;
+      a.ns = a.s0 < d->S ? (d->S - a.s0 + st - 1) / st : 0;
+      a.ihmul = a.iwmul = 1;
+      a.ihadd = (pa + d->pad - a.r0) / st; a.iwadd = (pb + d->pad - a.s0) / st;
+      a.hstep = a.wstep = -1;
+      a.osh = a.osw = st; a.oah = pa; a.oaw = pb;
+      a.M = d->N * a.OHp * a.OWp;
+      a.ksteps = a.nr * a.ns * a.ksteps_per_tap;
+      if (a.ksteps == 0 && a.atomic_out) continue;      // nothing to add
+      Plan pp = plan_igemm(a);
+      pp.split = a.split_k;
+      if (a.ksteps < a.split_k) { a.split_k = 1; pp.split = 1; }
+      rc = launch_igemm(a, pp, s, 1);
+      a.split_k = p.split;
+      g_flops_next = 0.0;                               // the call's flops are booked on its first launch
+    }
+  }
   if (rc != CPM_OK) return rc;
   if (a.atomic_out && (shift || relu)) {
-    const int64_t total = (int64_t)a.M * a.OCtot;
+    const int64_t total = (int64_t)whole.M * a.OCtot;
     int64_t b = (total + 255) / 256;
     hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, dx,
-                       (const float*)nullptr, shift, (const float*)nullptr, (int64_t)a.M, a.OCtot, a.OH, a.OW, 0,
+                       (const float*)nullptr, shift, (const float*)nullptr, (int64_t)whole.M, a.OCtot, a.OH, a.OW, 0,
                        relu);
     rc = cpm::check_launch("dgrad epilogue");
   }

@@ -64,6 +64,13 @@ def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, di
 def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups):
     n, c, h, wd = x_shape
     k, _, r, s = w.shape
+    if (r, s) == (h, wd) and pad == 0 and stride == 1 and dil == 1 and groups == 1 and (r > 1 or s > 1):
+        # full-window conv (an FC over a flattened NHWC map): every input pixel sees exactly one tap, so the data
+        # gradient is the plain GEMM dy[N,K] x W[K, R*S*C] -- run it as a 1x1 problem over R*S*C "channels"
+        # (the KRSC weight bytes are already that matrix) instead of 49 taps of which 48 are masked per row
+        w2 = w.permute(0, 2, 3, 1).reshape(k, r * s * c, 1, 1)
+        dx2 = conv2d_backward_data(dy.reshape(n, k, 1, 1), w2, (n, r * s * c, 1, 1), 1, 0, 1, 1)
+        return dx2.view(n, r, s, c).permute(0, 3, 1, 2)
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     dx = empty_nhwc((n, c, h, wd), dy)
     if dx.numel() == 0:

@@ -18,7 +18,8 @@ class FlatSGD(torch.optim.Optimizer):
         """named_params: list of (name, param, group_index) in flat-buffer order."""
         params = [p for _, p, _ in named_params]
         device = params[0].device
-        total = sum(p.numel() for p in params)
+        align = 64                                 # every tensor starts on a 256-byte boundary (16-B vector loads)
+        total = sum((p.numel() + align - 1) // align * align for p in params)
         self.flat_param = torch.empty(total, dtype=torch.float32, device=device)
         self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         self.flat_mom = torch.zeros(total, dtype=torch.float32, device=device)
@@ -30,7 +31,7 @@ class FlatSGD(torch.optim.Optimizer):
             begins.append(off)
             ends.append(off + n)
             gidx.append(gi)
-            off += n
+            off += (n + align - 1) // align * align
         self.names = [n for n, _, _ in named_params]
         self.seg_begin = torch.tensor(begins, dtype=torch.int64, device=device)
         self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)

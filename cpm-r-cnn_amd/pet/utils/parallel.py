@@ -33,7 +33,7 @@ class FlatGradReducer(object):
         for b, e in zip(begins, ends):
             self.seg_chunk.append(len(self.chunks))
             nseg += 1
-            if e - start >= target or e == total:
+            if e - start >= target or e == ends[-1]:
                 self.chunks.append((start, e, nseg))
                 start, nseg = e, 0
         self.overlap = overlap and self.world > 1 and self.flat.is_cuda
