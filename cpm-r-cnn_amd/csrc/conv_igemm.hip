@@ -36,6 +36,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats
 
+// 16-byte load through a buffer descriptor: an offset at or beyond num_records returns zeros WITHOUT touching
+// memory.  Masked gather lanes (padding, row/channel tails) are simply given OOB_OFF: no branch around the load
+// (hipcc drains vmcnt(0) inside such branches), no select, and no hot cache line as with a dummy address.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_OFF = 0xFFFFFFF0u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 // One gather description serves both directions.  GEMM row m = (n, i, j) on a (OHp x OWp) row grid:
 //   input tap  : ih = i*ihmul + ihadd + t_r*hstep,  iw = j*iwmul + iwadd + t_s*wstep   (zero outside the image)
 //   weight tap : r = r0 + t_r*rstep,                s = s0 + t_s*sstep,  t_r < nr, t_s < ns
@@ -67,6 +80,7 @@ struct IgemmArgs {
   int split_k;         // >= 1
   int res_mode, relu;
   int atomic_out;      // 1: atomicAdd raw accumulators (split-K / accumulate)
+  unsigned in_bytes, wm_bytes;
 };
 
 template <int BM, int BN, int WM, int WN, bool VEC>
@@ -119,6 +133,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const int nk = k_end - k_begin;
 
   float4 ra[AP], rb[BP];
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
 
   auto load_tile = [&](int kt) {
     const int tap = kt / a.ksteps_per_tap;
@@ -132,33 +147,32 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
     for (int i = 0; i < AP; ++i) {
       const int ih = a_h[i] + dh, iw = a_w[i] + dw;
       const bool ok = a_ok[i] && c_ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
-      const int off = a_base[i] + aoff;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
-        if (VEC) {
-          v = *(const float4*)(a.in + off);
-        } else {
-          v.x = a.in[off];
-          if (c0 + 1 < a.CgR) v.y = a.in[off + 1];
-          if (c0 + 2 < a.CgR) v.z = a.in[off + 2];
-          if (c0 + 3 < a.CgR) v.w = a.in[off + 3];
-        }
+      if (VEC) {
+        // branch-free: all the step's loads issue back to back (a branch per load makes hipcc wait vmcnt(0)
+        // inside each branch)
+        v = bload4(rs_in, ok ? (unsigned)(a_base[i] + aoff) * 4u : OOB_OFF);
+      } else if (ok) {
+        const int off = a_base[i] + aoff;
+        v.x = a.in[off];
+        if (c0 + 1 < a.CgR) v.y = a.in[off + 1];
+        if (c0 + 2 < a.CgR) v.z = a.in[off + 2];
+        if (c0 + 3 < a.CgR) v.w = a.in[off + 3];
       }
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_ok[i] && c_ok) {
+      const bool ok = b_ok[i] && c_ok;
+      if (VEC) {
+        v = bload4(rs_wm, ok ? (unsigned)(b_base[i] + wtap + c0) * 4u : OOB_OFF);
+      } else if (ok) {
         const int off = b_base[i] + wtap + c0;
-        if (VEC) {
-          v = *(const float4*)(a.wm + off);
-        } else {
-          v.x = a.wm[off];
-          if (c0 + 1 < a.CgR) v.y = a.wm[off + 1];
-          if (c0 + 2 < a.CgR) v.z = a.wm[off + 2];
-          if (c0 + 3 < a.CgR) v.w = a.wm[off + 3];
-        }
+        v.x = a.wm[off];
+        if (c0 + 1 < a.CgR) v.y = a.wm[off + 1];
+        if (c0 + 2 < a.CgR) v.z = a.wm[off + 2];
+        if (c0 + 3 < a.CgR) v.w = a.wm[off + 3];
       }
       rb[i] = v;
     }
@@ -315,9 +329,10 @@ struct WgradArgs {
   int N, IH, IW, Ctot, OH, OW, OCtot;
   int R, S, stride, pad, dil, groups, Cg, OCg, M;
   int split_k, chunks;  // chunks = ceil(M/32)
+  unsigned x_bytes, dy_bytes;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -341,8 +356,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   const int nk = ch_end - ch_begin;
 
   float4 ra[APASS], rb[BPASS];
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
   const bool vec_a = (a.OCtot & 3) == 0 && (a.OCg & 3) == 0;
   const bool vec_b = (a.Ctot & 3) == 0 && (a.Cg & 3) == 0;
+
+  // Each thread owns fixed (pixel-row, channel-vector) slots of the 32-pixel chunk; its pixel index advances by
+  // 32 per chunk, so (n, oh, ow) is decomposed ONCE here and then stepped with precomputed carries -- no
+  // integer division in the reduction loop.
+  const int hw = a.OH * a.OW;
+  const int dn = 32 / hw, rem = 32 % hw;
+  const int dh = rem / a.OW, dwid = rem % a.OW;
+  int b_n[BPASS], b_oh[BPASS], b_ow[BPASS];
+#pragma unroll
+  for (int i = 0; i < BPASS; ++i) {
+    const int pr = (tid + i * 256) / BV;
+    const int m = ch_begin * 32 + pr;
+    b_ow[i] = m % a.OW;
+    const int t = m / a.OW;
+    b_oh[i] = t % a.OH;
+    b_n[i] = t / a.OH;
+  }
 
   auto load_chunk = [&](int ch) {
     const int mbase = ch * 32;
@@ -352,7 +385,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const int pr = id / AV, cv = (id % AV) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int m = mbase + pr;
-      if (pr < 32 && m < a.M) {
+      if (VEC) {
+        const int ocl = oc0 + cv;
+        const bool ok = pr < 32 && m < a.M && ocl < a.OCg;
+        v = bload4(rs_dy, ok ? (unsigned)(m * a.OCtot + g * a.OCg + ocl) * 4u : OOB_OFF);
+      } else if (pr < 32 && m < a.M) {
         const int ocl = oc0 + cv;
         const size_t off = (size_t)m * a.OCtot + g * a.OCg + ocl;
         if (vec_a && ocl + 3 < a.OCg) {
@@ -371,14 +408,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       const int id = tid + i * 256;
       const int pr = id / BV, cv = (id % BV) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const int m = mbase + pr;
-      if (pr < 32 && m < a.M) {
-        const int ow = m % a.OW, t = m / a.OW;
-        const int oh = t % a.OH, n = t / a.OH;
-        const int ih = oh * a.stride - a.pad + r * a.dil, iw = ow * a.stride - a.pad + s * a.dil;
+      if (VEC) {
+        const int ih = b_oh[i] * a.stride - a.pad + r * a.dil, iw = b_ow[i] * a.stride - a.pad + s * a.dil;
+        const int cl = c0 + cv;
+        const bool ok = pr < 32 && b_n[i] < a.N && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW &&
+                        cl < a.Cg;
+        v = bload4(rs_x, ok ? (unsigned)(((b_n[i] * a.IH + ih) * a.IW + iw) * a.Ctot + g * a.Cg + cl) * 4u : OOB_OFF);
+      } else if (pr < 32 && b_n[i] < a.N) {
+        const int ih = b_oh[i] * a.stride - a.pad + r * a.dil, iw = b_ow[i] * a.stride - a.pad + s * a.dil;
         if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW) {
           const int cl = c0 + cv;
-          const size_t off = ((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g * a.Cg + cl;
+          const size_t off = ((size_t)(b_n[i] * a.IH + ih) * a.IW + iw) * a.Ctot + g * a.Cg + cl;
           if (vec_b && cl + 3 < a.Cg) {
             v = *(const float4*)(a.x + off);
           } else {
@@ -390,6 +430,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         }
       }
       rb[i] = v;
+      // advance this slot to the next chunk
+      b_n[i] += dn; b_oh[i] += dh; b_ow[i] += dwid;
+      if (b_ow[i] >= a.OW) { b_ow[i] -= a.OW; ++b_oh[i]; }
+      if (b_oh[i] >= a.OH) { b_oh[i] -= a.OH; ++b_n[i]; }
     }
   };
   auto store_chunk = [&](int buf) {
@@ -537,8 +581,9 @@ int validate(const cpm_conv_desc* d) {
   const int P = (d->H + 2 * d->pad - d->dilation * (d->R - 1) - 1) / d->stride + 1;
   const int Q = (d->W + 2 * d->pad - d->dilation * (d->S - 1) - 1) / d->stride + 1;
   if (P != d->P || Q != d->Q) return CPM_EINVAL;
-  if ((int64_t)d->N * d->H * d->W * d->C >= (1ll << 31) || (int64_t)d->N * d->P * d->Q * d->K >= (1ll << 31) ||
-      (int64_t)d->K * d->R * d->S * (d->C / d->groups) >= (1ll << 31))
+  // byte offsets travel as 32-bit buffer offsets: every tensor must stay below 2^30 floats (4 GiB - 16)
+  if ((int64_t)d->N * d->H * d->W * d->C >= (1ll << 30) - 4 || (int64_t)d->N * d->P * d->Q * d->K >= (1ll << 30) - 4 ||
+      (int64_t)d->K * d->R * d->S * (d->C / d->groups) >= (1ll << 30) - 4)
     return CPM_EINVAL;
   return CPM_OK;
 }
@@ -574,6 +619,8 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
   a.ksteps_per_tap = cpm::cdiv(a.CgR, BK);
   a.ksteps = d->R * d->S * a.ksteps_per_tap;
   a.res_mode = res_mode; a.relu = relu;
+  a.in_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->C * 4);
+  a.wm_bytes = (unsigned)((size_t)d->K * d->R * d->S * (d->C / d->groups) * 4);
   Plan p = plan_igemm(a);
   a.split_k = p.split;
   a.atomic_out = a.split_k > 1;
@@ -616,6 +663,8 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   a.R = d->R; a.S = d->S;
   a.groups = d->groups; a.CgR = Kg; a.OCg = Cg;
   a.ksteps_per_tap = cpm::cdiv(a.CgR, BK);
+  a.in_bytes = (unsigned)((size_t)d->N * d->P * d->Q * d->K * 4);
+  a.wm_bytes = (unsigned)((size_t)d->K * d->R * d->S * Cg * 4);
   const int st = d->stride;
   // split-K / accumulate decision on the whole problem so that every phase agrees on atomics
   IgemmArgs whole = a;
@@ -696,6 +745,8 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   a.groups = d->groups; a.Cg = d->C / d->groups; a.OCg = d->K / d->groups;
   a.M = d->N * d->P * d->Q;
   a.chunks = cpm::cdiv(a.M, 32);
+  a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->C * 4);
+  a.dy_bytes = (unsigned)((size_t)d->N * d->P * d->Q * d->K * 4);
   const int taps = d->R * d->S;
   auto blocks = [&](int bm, int bn) {
     return (int64_t)cpm::cdiv(a.OCg, bm) * cpm::cdiv(a.Cg, bn) * taps * a.groups;
@@ -710,18 +761,23 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   };
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   ProfScope prof_scope(s, 2);
+  const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) &&
+                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
 #define WLAUNCH(BM, BN, WM, WN)                                                                      \
   do {                                                                                               \
     a.split_k = split_for(blocks(BM, BN));                                                           \
     dim3 grid((unsigned)(cpm::cdiv(a.OCg, BM) * cpm::cdiv(a.Cg, BN)), taps, a.groups * a.split_k);  \
-    hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN>), grid, dim3(256), 0, s, a);                    \
+    if (wvec)                                                                                        \
+      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
+    else                                                                                             \
+      hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);           \
   } while (0)
   if (a.OCg <= 32 || a.Cg <= 32) {
     if (a.OCg <= 32 && a.Cg > 32) WLAUNCH(32, 128, 1, 4);
     else if (a.Cg <= 32 && a.OCg > 32) WLAUNCH(128, 32, 4, 1);
     else WLAUNCH(64, 64, 2, 2);
-  } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && blocks(128, 128) >= 128) {
-    WLAUNCH(128, 128, 2, 2);
+  } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && a.chunks >= 64) {
+    WLAUNCH(128, 128, 2, 2);        // the reduction (pixels) is split until the grid fills the chip
   } else {
     WLAUNCH(64, 64, 2, 2);
   }
