@@ -1,0 +1,102 @@
+"""CPU-only, world_size 2 over gloo: the flat-buffer gradient reducer (pet/utils/parallel.py) and the fused
+loss-scalar reduce -- the N > 1 path of bench.py -- plus the flat optimizer's buffer layout."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import sys
+    from conftest import PKG, ROOT
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pet.utils.optimizer import FlatSGD
+        from pet.utils.parallel import FlatGradReducer, reduce_losses
+        torch.manual_seed(0)                                    # same weights on every rank
+        net = torch.nn.Sequential(torch.nn.Linear(13, 37), torch.nn.ReLU(), torch.nn.Linear(37, 5),
+                                  torch.nn.Conv2d(1, 3, 3))
+        named = [(k, p, 1 if "bias" in k else 0) for k, p in net.named_parameters()]
+        named.reverse()
+        opt = FlatSGD(named, [dict(weight_decay=1e-4, lr_scale=1), dict(weight_decay=0.0, lr_scale=2),
+                              dict(weight_decay=0.0, lr_scale=1)], 0.9)
+        # layout: every tensor is a view into the flat buffers, 256-byte aligned, reverse registration order
+        for (_, p, _), b in zip(named, opt.seg_begin.tolist()):
+            assert p.data_ptr() == opt.flat_param.data_ptr() + 4 * b and b % 64 == 0
+            assert p.grad.data_ptr() == opt.flat_grad.data_ptr() + 4 * b
+        red = FlatGradReducer(opt, num_chunks=3, overlap=True)   # overlap silently off on CPU tensors
+        assert opt.grad_scale == 1.0 / world
+        covered = sorted((b, e) for b, e, _ in red.chunks)
+        assert covered[0][0] == 0 and covered[-1][1] == opt.seg_end.tolist()[-1]
+        assert all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+        assert sum(n for _, _, n in red.chunks) == len(named)
+        torch.manual_seed(100 + rank)                            # different data per rank
+        x = torch.randn(4, 13)
+        opt.zero_grad()
+        red.begin_step()
+        y = net[2](net[1](net[0](x)))
+        loss = (y ** 2).mean() + (net[3](torch.randn(2, 1, 6, 6)) ** 2).mean()
+        loss.backward()
+        local = opt.flat_grad.clone()
+        red.finish()
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(opt.flat_grad, sum(gathered), rtol=1e-6, atol=1e-7)
+        out = reduce_losses({"loss_b": torch.tensor(float(rank + 1)), "loss_a": torch.tensor(10.0 * (rank + 1))})
+        assert abs(out["loss_a"] - 15.0) < 1e-6 and abs(out["loss_b"] - 1.5) < 1e-6
+        q.put((rank, "ok"))
+    except Exception as e:      # surface the failure in the parent
+        q.put((rank, "FAIL %r" % (e,)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_flat_reducer_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
+def test_lr_schedule_matches_reference_formula():
+    """warm-up (linear, factor 0.1, 500 it) then x0.1 steps at 120k/160k, bias groups at 2x (lr_scheduler.py:69-127)."""
+    from pet.rcnn.core import config
+    from pet.utils.lr_scheduler import LearningRateScheduler
+    config.reset_cfg()
+    config.merge_cfg_from_list(["SOLVER.BASE_LR", 0.02, "SOLVER.STEPS", [120000, 160000], "SOLVER.MAX_ITER", 180000])
+    w = torch.nn.Parameter(torch.zeros(3))
+    b = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([dict(params=[w], lr=0, lr_scale=1), dict(params=[b], lr=0, lr_scale=2)], momentum=0.9)
+    s = LearningRateScheduler(opt, config.cfg.SOLVER, start_iter=0)
+    s.step()
+    assert abs(s.new_lr - 0.02 * (0.1 * (1 - 1 / 500) + 1 / 500)) < 1e-12
+    assert abs(opt.param_groups[1]["lr"] - 2 * s.new_lr) < 1e-12
+    s.step(500)
+    assert abs(s.new_lr - 0.02) < 1e-12
+    s.step(120000)
+    assert abs(s.new_lr - 0.002) < 1e-12
+    s.step(170000)
+    assert abs(s.new_lr - 0.0002) < 1e-12
+    config.reset_cfg()
