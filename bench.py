@@ -69,6 +69,37 @@ def synthetic_batch(n, h, w, gts, seed, device):
     return il, targets
 
 
+@torch.no_grad()
+def calibrate_frozen_affine(model, images):
+    """Stand-in for the pretrained statistics the reference always starts from (TRAIN.WEIGHTS = ImageNet caffe
+    model): with random conv weights the folded BN statistics (mean 0, var 1) are meaningless and the un-normalised
+    activations make SGD at the config's learning rate diverge within a few steps.  Here every frozen affine of
+    the backbone is set, layer by layer, to normalise its conv's output on the benchmark batch (gamma = 1,
+    including the last norm of each block, which the from-scratch initialiser zeroes).  Runs once, untimed."""
+    import pet.lib.ops as ops
+
+    def fit(conv, aff, x, relu, residual=None):
+        raw = ops.conv2d(x, conv.weight, None, None, None, conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups)
+        mean = raw.mean(dim=(0, 2, 3))
+        std = raw.var(dim=(0, 2, 3), unbiased=False).add(1e-5).sqrt()
+        aff.weight.data.copy_(1.0 / std)
+        aff.bias.data.copy_(-mean / std)
+        return conv(x, scale=aff.weight, shift=aff.bias, residual=residual, relu=relu)
+
+    body = model.Conv_Body
+    x = images.contiguous(memory_format=torch.channels_last)
+    fit(body.conv1, body.bn1, x, True)
+    body._stem_cache = None
+    s, b = body.bn1.weight, body.bn1.bias
+    x = ops.stem_forward(images, body._stem_weight(), s, b, 7, 7, 2, 3)
+    for li in range(1, len(body.layers) + 1):
+        for blk in getattr(body, "layer%d" % li):
+            out = fit(blk.conv1, blk.bn1, x, True)
+            out = fit(blk.conv2, blk.bn2, out, True)
+            res = x if blk.downsample is None else fit(blk.downsample[0], blk.downsample[1], x, False)
+            x = fit(blk.conv3, blk.bn3, out, True, residual=res)
+
+
 class Trainer(object):
     """The reference's loop body (tools/rcnn/train_net.py:62-78) over the HIP model."""
 
@@ -183,6 +214,7 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--layers", type=str, default="3,4,6,3", help="ResNet depth: 3,4,6,3 (R-50) / 3,4,23,3 (R-101)")
+    ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,18 +234,26 @@ def main():
     layers = tuple(int(x) for x in a.layers.split(","))
     trainer = Trainer(device, layers=layers)
     images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
+    cal_img, _ = synthetic_batch(a.batch, a.height, a.width, 1, 4321, device)     # same on every rank
+    calibrate_frozen_affine(trainer.model, cal_img.tensors)
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    for i in range(a.warmup):
         trainer.step(images, targets)
+        if a.verbose and rank == 0:
+            print("warmup %d lr=%.5f %s" % (i, trainer.scheduler.new_lr, {k: round(float(v.detach()), 4)
+                                                                      for k, v in trainer.last_losses.items()}), flush=True)
     sync()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for i in range(a.steps):
         trainer.step(images, targets)
+        if a.verbose and rank == 0:
+            print("step %d lr=%.5f %s" % (i, trainer.scheduler.new_lr, {k: round(float(v.detach()), 4)
+                                                                    for k, v in trainer.last_losses.items()}), flush=True)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -240,7 +280,7 @@ def main():
             "ms_per_step": round(1000.0 * elapsed / a.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s CPM R-CNN (CMM x3 + ISM + RSM) training step, %d x 3x%dx%d per GPU, "
-                                   "16 gt boxes/img, reference initialisers" % (model_name, a.batch, a.height, a.width),
+                                   "16 gt boxes/img, reference initialisers + frozen-BN affine calibrated on a synthetic batch" % (model_name, a.batch, a.height, a.width),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world,
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},

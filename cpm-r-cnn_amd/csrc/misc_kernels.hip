@@ -210,28 +210,38 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, 
 }
 
 // ---- fused SGD ------------------------------------------------------------------------------------------------
+// One thread updates 4 consecutive elements; the segment (lr, weight decay) of each 64-element block comes from a
+// lookup table (segments are 64-element aligned), blocks in the alignment gaps are skipped.
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
-                           const int64_t* __restrict__ seg_begin, const int64_t* __restrict__ seg_end,
-                           const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int nseg,
-                           int64_t total, float momentum, float grad_scale, int first_step) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    // binary search of the segment holding element i (segments sorted, may leave gaps)
-    int lo = 0, hi = nseg - 1, sidx = -1;
-    while (lo <= hi) {
-      const int mid = (lo + hi) >> 1;
-      if (i < seg_begin[mid]) hi = mid - 1;
-      else if (i >= seg_end[mid]) lo = mid + 1;
-      else { sidx = mid; break; }
-    }
+                           const int32_t* __restrict__ block_seg, const int64_t* __restrict__ seg_end,
+                           const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int64_t total,
+                           float momentum, float grad_scale, int first_step) {
+  const int64_t nvec = total >> 2;
+  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = v << 2;
+    const int sidx = block_seg[i >> 6];
     if (sidx < 0) continue;
+    const int64_t end = seg_end[sidx];
+    if (i >= end) continue;
     const float lr = seg_lr[sidx], wd = seg_wd[sidx];
-    const float pv = p[i];
-    float d = g[i] * grad_scale;
-    if (wd != 0.f) d = d + wd * pv;
-    float b = first_step ? d : momentum * buf[i] + d;
-    buf[i] = b;
-    p[i] = pv - lr * b;
+    float4 pv = *(const float4*)(p + i);
+    const float4 gv = *(const float4*)(g + i);
+    float4 bv = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(buf + i);
+    float* pp = &pv.x; const float* gp = &gv.x; float* bp = &bv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float d = gp[k] * grad_scale;
+      if (wd != 0.f) d = d + wd * pp[k];
+      const float b = first_step ? d : momentum * bp[k] + d;
+      bp[k] = b;
+      pp[k] = pp[k] - lr * b;
+    }
+    if (i + 4 <= end) {
+      *(float4*)(p + i) = pv;
+      *(float4*)(buf + i) = bv;
+    } else {
+      for (int k = 0; k < 4 && i + k < end; ++k) { p[i + k] = pp[k]; buf[i + k] = bp[k]; }
+    }
   }
 }
 
@@ -304,12 +314,12 @@ CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q,
   return cpm::check_launch("upsample2x_add_backward");
 }
 
-CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int64_t* seg_begin,
+CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
                             const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
                             int64_t total, float momentum, float grad_scale, int first_step, void* stream) {
-  CPM_REQUIRE(params && grads && momentum_buf && seg_begin && seg_end && seg_lr && seg_wd, "null pointer");
-  CPM_REQUIRE(nseg > 0 && total > 0, "bad shape");
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, (hipStream_t)stream, params, grads,
-                     momentum_buf, seg_begin, seg_end, seg_lr, seg_wd, nseg, total, momentum, grad_scale, first_step);
+  CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_lr && seg_wd, "null pointer");
+  CPM_REQUIRE(nseg > 0 && total > 0 && total % 64 == 0, "bad shape (total must be a multiple of 64)");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
+                     grads, momentum_buf, block_seg, seg_end, seg_lr, seg_wd, total, momentum, grad_scale, first_step);
   return cpm::check_launch("sgd_step");
 }

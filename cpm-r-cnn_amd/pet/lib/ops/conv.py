@@ -130,8 +130,15 @@ class _ConvFn(Function):
     def forward(ctx, x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode):
         H.require_gpu(x, w, scale, shift, residual)
         x = nhwc(x)
+        w_in = w
         w = _wmem(w)
         res = nhwc(residual) if residual is not None else None
+        # a parameter owned by the flat optimizer carries `_cpm_grad_sink` (its slice of the flat gradient buffer):
+        # the weight-gradient kernel then accumulates straight into it (no temporary, no autograd add) and the
+        # data-parallel reducer is told when the last use of the step has been accumulated
+        ctx.wparam = w_in if (ctx.needs_input_grad[1] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
+        if ctx.wparam is not None:
+            w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
         y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
         ctx.cfg = (stride, pad, dil, groups, relu, res_mode, tuple(x.shape),
                    None if residual is None else tuple(residual.shape))
@@ -163,7 +170,18 @@ class _ConvFn(Function):
         if want_res:
             gres = g if res_mode == 0 else upsample2x_add_backward(g, res_shape)
         dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups) if need_x else None
-        dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups) if need_w else None
+        dw = None
+        if need_w:
+            wp = ctx.wparam
+            if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
+                conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink)
+                wp._cpm_uses -= 1
+                if wp._cpm_uses == 0:
+                    ready = getattr(wp, "_cpm_grad_ready", None)
+                    if ready is not None:
+                        ready(wp)
+            else:
+                dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups)
         return dx, dw, None, dshift, gres, None, None, None, None, None, None
 
 

@@ -38,6 +38,12 @@ class FlatSGD(torch.optim.Optimizer):
         self.seg_group = torch.tensor(gidx, dtype=torch.int64, device=device)
         self.seg_lr = torch.zeros(len(begins), dtype=torch.float32, device=device)
         self.seg_wd = torch.zeros(len(begins), dtype=torch.float32, device=device)
+        # segment of every 64-element block (-1 in the alignment gaps): the SGD kernel looks its segment up instead
+        # of searching
+        table = torch.full((total // align,), -1, dtype=torch.int32)
+        for si, (b, e) in enumerate(zip(begins, ends)):
+            table[b // align:(e + align - 1) // align] = si
+        self.block_seg = table.to(device)
         self.total, self.momentum, self._steps, self._last = total, float(momentum), 0, None
         self.grad_scale = 1.0
         groups = []
@@ -64,9 +70,16 @@ class FlatSGD(torch.optim.Optimizer):
         dst.copy_(p.data)
         p.data = dst
         p.grad = self._view(self.flat_grad, p, off, n)
+        if p.dim() == 4:
+            p._cpm_grad_sink = p.grad          # conv weight gradients are accumulated in place by the HIP kernel
+            p._cpm_uses = 0
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()                                       # one memset; .grad views stay attached
+        for g in self.param_groups:
+            for p in g["params"]:
+                if hasattr(p, "_cpm_uses"):
+                    p._cpm_uses = 0
 
     def _refresh_tables(self):
         key = tuple((g["lr"], g["weight_decay"]) for g in self.param_groups)
@@ -82,7 +95,7 @@ class FlatSGD(torch.optim.Optimizer):
         self._refresh_tables()
         with torch.cuda.device(self.flat_param.device):
             rc = H.lib().cpm_sgd_step(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
-                                      H.ptr(self.seg_begin), H.ptr(self.seg_end), H.ptr(self.seg_lr),
+                                      H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_lr),
                                       H.ptr(self.seg_wd), len(self._seg_pg), H.c_int64(self.total),
                                       H.f(self.momentum), H.f(self.grad_scale), int(self._steps == 0), H.stream())
         H.check(rc, "sgd_step")

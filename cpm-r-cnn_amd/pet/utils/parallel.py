@@ -51,7 +51,10 @@ class FlatGradReducer(object):
             for p in by_id.values():
                 off = (p.grad.data_ptr() - base) // 4
                 ci = next(i for i, (b, e, _) in enumerate(self.chunks) if b <= off < e)
-                p.register_post_accumulate_grad_hook(self._make_hook(ci))
+                hook = self._make_hook(ci)
+                p.register_post_accumulate_grad_hook(hook)
+                if hasattr(p, "_cpm_grad_sink"):
+                    p._cpm_grad_ready = hook        # conv weights bypass autograd's accumulation (pet.lib.ops.conv)
 
     def _make_hook(self, ci):
         def hook(_):

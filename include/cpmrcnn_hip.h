@@ -168,11 +168,13 @@ int cpm_prof_summary(int kind, double* total_ms, double* total_flops, int64_t* l
 
 /* ---- fused SGD with momentum over a flat parameter buffer -------------------
  * Replaces torch.optim.SGD.step as built by pet/utils/optimizer.py:40-65 (3 param
- * groups: weights / biases (lr x2, no wd) / GN).  seg_* are device arrays of
- * `nseg` segments sorted by begin: [begin,end) element ranges with per-segment lr
- * and weight decay.  d = g*grad_scale + wd*p; buf = momentum*buf + d; p -= lr*buf
- * (torch.optim.SGD with dampening 0, first step buf = d when first_step != 0).   */
-int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int64_t* seg_begin,
+ * groups: weights / biases (lr x2, no wd) / GN).  The flat buffer is cut into `nseg`
+ * segments that start on 64-element boundaries: block_seg[i/64] (device int32) is the
+ * segment of element i or -1 in an alignment gap, seg_end/seg_lr/seg_wd (device, per
+ * segment) its end, learning rate and weight decay.
+ * d = g*grad_scale + wd*p; buf = momentum*buf + d (buf = d on the first step); p -= lr*buf
+ * (torch.optim.SGD, dampening 0).                                                      */
+int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
                  const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg, int64_t total,
                  float momentum, float grad_scale, int first_step, void* stream);
 

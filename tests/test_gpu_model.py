@@ -168,3 +168,68 @@ def test_inference_single_image(model):
     assert r.bbox.shape[1] == 4 and r.has_field("scores") and r.has_field("labels")
     if len(r):
         assert torch.isfinite(r.bbox).all() and (r.get_field("labels") > 0).all()
+
+
+def test_flat_sgd_matches_torch_sgd():
+    """cpm_sgd_step over the flat buffer == torch.optim.SGD with the reference's three parameter groups
+    (pet/utils/optimizer.py:40-65): weights (wd), biases (lr x2, no wd), GroupNorm affine (wd_gn)."""
+    from pet.utils.optimizer import FlatSGD
+    torch.manual_seed(0)
+    shapes = [(64, 32, 3, 3), (64,), (7, 33), (7,), (36,), (36,), (5, 3, 1, 1)]
+    kinds = [0, 1, 0, 1, 2, 2, 0]
+    ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ps[0].data = ps[0].data.contiguous(memory_format=CL)
+    ref = [torch.nn.Parameter(p.detach().clone().cpu().contiguous()) for p in ps]
+    groups = [dict(weight_decay=1e-4, lr_scale=1), dict(weight_decay=0.0, lr_scale=2), dict(weight_decay=0.0, lr_scale=1)]
+    opt = FlatSGD([("p%d" % i, p, k) for i, (p, k) in enumerate(zip(ps, kinds))], groups, 0.9)
+    topt = torch.optim.SGD([dict(params=[r for r, k in zip(ref, kinds) if k == g], weight_decay=groups[g]["weight_decay"])
+                            for g in range(3)], lr=0.1, momentum=0.9)
+    for step in range(3):
+        lr = 0.05 * (step + 1)
+        for g, tg, cfgg in zip(opt.param_groups, topt.param_groups, groups):
+            g["lr"] = lr * cfgg["lr_scale"]
+            tg["lr"] = lr * cfgg["lr_scale"]
+        opt.zero_grad()
+        for p, r in zip(ps, ref):
+            gq = torch.randn(p.shape)
+            p.grad.add_(gq.cuda())
+            r.grad = gq.clone()
+        opt.step()
+        topt.step()
+        for p, r in zip(ps, ref):
+            torch.testing.assert_close(p.detach().cpu().contiguous(), r.detach(), rtol=1e-5, atol=1e-6)
+
+
+def test_flat_optimizer_grad_sink_equals_autograd(model, golden_model):
+    """With the flat optimizer attached, conv weight gradients are accumulated in place by the wgrad kernel
+    (bypassing autograd's accumulation); they must equal the plain autograd path."""
+    from pet.rcnn.core.config import cfg
+    from pet.utils.optimizer import Optimizer
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_model
+
+    def run():
+        x = torch.from_numpy(g["m_img"]).cuda()
+        boxes = [BoxList(torch.from_numpy(g["m_rois"]).cuda(), (96, 64))]
+        G = model.Grid_Cascade_RCNN
+        p = model.Conv_Body_FPN(model.Conv_Body(x))
+        xg, _ = G.Head_grid_0(p, boxes)
+        hm, _ = G.Output_grid_0(xg, None)
+        lo, br = model.RPN.head(p)
+        loss = (hm["unfused"] ** 2).mean() + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)
+        loss.backward()
+
+    model.train()
+    model.zero_grad(set_to_none=True)
+    run()
+    want = {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.grad is not None}
+    opt = Optimizer(model, cfg.SOLVER).build()
+    assert hasattr(model.RPN.head.conv.weight, "_cpm_grad_sink")
+    opt.zero_grad()
+    run()
+    for k, q in model.named_parameters():
+        if k in want:
+            a, b = q.grad.detach(), want[k]
+            err = float((a - b).abs().max() / (b.abs().max() + 1e-20))
+            assert err < 1e-4, (k, err)
+    assert model.RPN.head.conv.weight._cpm_uses == 0      # 5 uses (one per FPN level) counted up and back down
