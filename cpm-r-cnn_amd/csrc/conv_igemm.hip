@@ -25,6 +25,8 @@
 //     float atomics into a zeroed output and the epilogue runs as a second tiny kernel.
 //
 // Reference call sites replaced: see include/cpmrcnn_hip.h (conv section).
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -81,14 +83,18 @@ struct IgemmArgs {
   int res_mode, relu;
   int atomic_out;      // 1: atomicAdd raw accumulators (split-K / accumulate)
   unsigned in_bytes, wm_bytes;
+  int xcd_swizzle;
+  int m_base;          // first GEMM row of this launch (rows [m_base, M) are tiled)
 };
 
 template <int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+  constexpr int NT = 64 * WM * WN;              // threads
+  constexpr int RPP = NT / 8;                   // rows per load pass (8 threads x float4 cover a 32-float row)
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
   constexpr int TM = WTM / 32, TN = WTN / 32;   // MFMA tiles per wave
-  constexpr int AP = BM / 32, BP = BN / 32;     // load passes (32 rows per pass)
-  static_assert(WM * WN == 4 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
+  constexpr int AP = BM / RPP, BP = BN / RPP;   // load passes
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile shape");
 
   __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDP];
@@ -96,19 +102,27 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (a.OCg + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2), so give
+  // each XCD a contiguous run of logical tiles -- the N-tiles of one row block and neighbouring row blocks (which
+  // share 3x3 halo rows) then hit the same L2.  Bijective for any grid size; a speed hint only.
+  int bid = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
   const int g = blockIdx.y;
   const int split = blockIdx.z;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = a.m_base + tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-thread load geometry --------------------------------------------------------------
-  const int lrow = tid >> 3;        // 0..31
+  const int lrow = tid >> 3;        // 0..RPP-1
   const int lcol = (tid & 7) * 4;   // 0,4,..,28
   int a_base[AP], a_h[AP], a_w[AP];
   bool a_ok[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
-    const int m = m0 + i * 32 + lrow;
+    const int m = m0 + i * RPP + lrow;
     a_ok[i] = m < a.M;
     const int mm = a_ok[i] ? m : 0;
     const int jj = mm % a.OWp, t = mm / a.OWp;
@@ -121,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   bool b_ok[BP];
 #pragma unroll
   for (int i = 0; i < BP; ++i) {
-    const int oc = n0 + i * 32 + lrow;
+    const int oc = n0 + i * RPP + lrow;
     b_ok[i] = oc < a.OCg;
     b_base[i] = (g * a.OCg + (b_ok[i] ? oc : 0)) * a.R * a.S * a.CgR;
   }
@@ -179,9 +193,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *(float4*)&As[buf][i * 32 + lrow][lcol] = ra[i];
+    for (int i = 0; i < AP; ++i) *(float4*)&As[buf][i * RPP + lrow][lcol] = ra[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *(float4*)&Bs[buf][i * 32 + lrow][lcol] = rb[i];
+    for (int i = 0; i < BP; ++i) *(float4*)&Bs[buf][i * RPP + lrow][lcol] = rb[i];
   };
 
   f32x16 acc[TM][TN];
@@ -218,8 +232,12 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(IgemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
+      // The next tile's registers go to LDS in the MIDDLE of the MFMA stream (its loads were issued half a step
+      // ago; the other buffer has been free since the last barrier): the step then ends with the barrier alone,
+      // and the wait + ds_writes of this wave overlap the co-resident wave's MFMAs instead of both waves of a
+      // SIMD leaving the matrix pipe idle at the same point of their (lock-stepped) iterations.
+      if (kb == BK / 16 - 1 && it + 1 < nk) store_tile(cur ^ 1);
     }
-    if (it + 1 < nk) store_tile(cur ^ 1);
     __syncthreads();
     cur ^= 1;
   }
@@ -526,18 +544,25 @@ struct ProfScope {
   }
 };
 
-struct Plan { int bm, bn, split; };
+struct Plan { int bm, bn, wm, wn, split; };
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 // tile + split-K choice: the biggest tile that still gives every CU two workgroups; thin problems take the small
 // tile and split the reduction until there are ~3 workgroups per CU (their K loops are latency bound otherwise)
 Plan plan_igemm(const IgemmArgs& a) {
   auto tiles = [&](int bm, int bn) { return (int64_t)cpm::cdiv(a.M, bm) * cpm::cdiv(a.OCg, bn) * a.groups; };
+  static const int big_waves = env_int("CPM_IGEMM_BIG_WAVES", 4);      // 4: 2x2 waves, 8: 2x4 waves on 128x128
   Plan p;
-  if (a.OCg <= 32) { p.bm = 128; p.bn = 32; }
+  p.wm = 2; p.wn = 2;
+  if (a.OCg <= 32) { p.bm = 128; p.bn = 32; p.wm = 4; p.wn = 1; }
   else if (a.OCg <= 64 || (a.OCg % 128 != 0 && a.OCg % 64 == 0)) {
     if (tiles(128, 64) >= 2 * num_cus()) { p.bm = 128; p.bn = 64; } else { p.bm = 64; p.bn = 64; }
   } else {
-    if (tiles(128, 128) >= 2 * num_cus()) { p.bm = 128; p.bn = 128; }
+    if (tiles(128, 128) >= 2 * num_cus()) { p.bm = 128; p.bn = 128; if (big_waves == 8) p.wn = 4; }
     else if (tiles(128, 64) >= 2 * num_cus()) { p.bm = 128; p.bn = 64; }
     else { p.bm = 64; p.bn = 64; }
   }
@@ -553,24 +578,54 @@ Plan plan_igemm(const IgemmArgs& a) {
   return p;
 }
 
-int launch_igemm(const IgemmArgs& a, const Plan& p, hipStream_t s, int prof_kind) {
-  const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
-                   (((uintptr_t)a.wm & 15) == 0);
-  ProfScope prof_scope(s, prof_kind);
+int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t s) {
+  const int rows = a.M - a.m_base;
 #define LAUNCH(BM, BN, WM, WN)                                                                       \
   do {                                                                                               \
-    dim3 grid((unsigned)(cpm::cdiv(a.M, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);           \
+    dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);          \
     if (vec)                                                                                         \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), 0, s, a);   \
     else                                                                                             \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);           \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), 0, s, a);  \
   } while (0)
-  if (p.bm == 128 && p.bn == 128) LAUNCH(128, 128, 2, 2);
-  else if (p.bm == 128 && p.bn == 64) LAUNCH(128, 64, 2, 2);
-  else if (p.bm == 128 && p.bn == 32) LAUNCH(128, 32, 4, 1);
+  if (bm == 128 && bn == 128 && wn == 4) LAUNCH(128, 128, 2, 4);
+  else if (bm == 128 && bn == 128) LAUNCH(128, 128, 2, 2);
+  else if (bm == 128 && bn == 64) LAUNCH(128, 64, 2, 2);
+  else if (bm == 128 && bn == 32) LAUNCH(128, 32, 4, 1);
   else LAUNCH(64, 64, 2, 2);
 #undef LAUNCH
   return cpm::check_launch("conv igemm");
+}
+
+int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
+  const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
+                   (((uintptr_t)a.wm & 15) == 0);
+  static const int swz = env_int("CPM_IGEMM_XCD", 1);
+  static const int tail_split = env_int("CPM_IGEMM_TAIL", 1);
+  a.xcd_swizzle = swz;
+  a.m_base = 0;
+  ProfScope prof_scope(s, prof_kind);
+  // Wave quantisation: the big tiles run 2 workgroups per CU (LDS), i.e. 512 at a time.  When the tile count is a
+  // little over a multiple of 512 the last round would keep a few CUs busy for a whole tile time while the rest
+  // idle (2100 tiles = 4.1 rounds cost 5).  So the rows of the full rounds go to the big tile and the remaining
+  // rows are re-tiled 64x64 (4 workgroups per CU, a quarter of the tile time) in a second launch.
+  if (tail_split && p.bm == 128 && p.bn >= 64 && a.split_k == 1 && a.groups == 1) {
+    const int tiles_n = cpm::cdiv(a.OCg, p.bn);
+    const int64_t tiles_m = cpm::cdiv(a.M, p.bm), total = tiles_m * tiles_n, slots = 2 * num_cus();
+    const int64_t rem = total % slots;
+    if (total > slots && rem != 0 && rem * 2 < slots) {
+      const int64_t main_m = (total - rem) / tiles_n;      // whole row blocks in the full rounds
+      if (main_m > 0 && main_m < tiles_m) {
+        IgemmArgs b = a;
+        b.M = (int)(main_m * p.bm);
+        int rc = launch_one(b, p.bm, p.bn, p.wn, vec, s);
+        if (rc != CPM_OK) return rc;
+        a.m_base = (int)(main_m * p.bm);
+        return launch_one(a, 64, 64, 2, vec, s);
+      }
+    }
+  }
+  return launch_one(a, p.bm, p.bn, p.wn, vec, s);
 }
 
 int validate(const cpm_conv_desc* d) {
@@ -751,13 +806,21 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   auto blocks = [&](int bm, int bn) {
     return (int64_t)cpm::cdiv(a.OCg, bm) * cpm::cdiv(a.Cg, bn) * taps * a.groups;
   };
-  auto split_for = [&](int64_t nb) {
-    int sk = (int)((3 * 256 + nb - 1) / nb);
-    const int maxs = a.chunks / 8 > 0 ? a.chunks / 8 : 1;
-    if (sk > maxs) sk = maxs;
-    if (sk < 1) sk = 1;
-    if (sk > 256) sk = 256;
-    return sk;
+  // split of the pixel reduction: enough workgroups to fill the chip, chosen so that the grid is close to a whole
+  // number of residency rounds (2 workgroups per CU for the 128-tiles, 4 for the 64-tiles)
+  auto split_for = [&](int64_t nb, int per_cu) {
+    const int64_t slots = (int64_t)per_cu * num_cus();
+    const int maxs = a.chunks / 8 > 0 ? (a.chunks / 8 > 256 ? 256 : a.chunks / 8) : 1;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sk = 1; sk <= maxs; ++sk) {
+      const int64_t blocks = nb * sk;
+      const int64_t rounds = (blocks + slots - 1) / slots;
+      // time ~ rounds * (work per block) ~ rounds / sk; small penalty per extra split (atomic traffic)
+      const double cost = (double)rounds / sk * (1.0 + 0.01 * sk);
+      if (cost < best_cost - 1e-12) { best_cost = cost; best = sk; }
+    }
+    return best;
   };
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   ProfScope prof_scope(s, 2);
@@ -765,7 +828,7 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
                     (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
 #define WLAUNCH(BM, BN, WM, WN)                                                                      \
   do {                                                                                               \
-    a.split_k = split_for(blocks(BM, BN));                                                           \
+    a.split_k = split_for(blocks(BM, BN), (BM) * (BN) >= 128 * 128 ? 2 : 4);                          \
     dim3 grid((unsigned)(cpm::cdiv(a.OCg, BM) * cpm::cdiv(a.Cg, BN)), taps, a.groups * a.split_k);  \
     if (wvec)                                                                                        \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
