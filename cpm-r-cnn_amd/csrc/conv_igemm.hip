@@ -558,18 +558,26 @@ Plan plan_igemm(const IgemmArgs& a) {
   static const int big_waves = env_int("CPM_IGEMM_BIG_WAVES", 4);      // 4: 2x2 waves, 8: 2x4 waves on 128x128
   Plan p;
   p.wm = 2; p.wn = 2;
+  // measured on MI355X (tools/sweep_igemm.sh): the 128x128 tile wins once it fills two residency rounds' worth of
+  // CUs; below that the 64x64 tile at 4 workgroups per CU (reduction split until ~1024 workgroups) beats both the
+  // 128x64 tile and an un-split 64x64 grid -- thin problems are latency bound per workgroup
   if (a.OCg <= 32) { p.bm = 128; p.bn = 32; p.wm = 4; p.wn = 1; }
-  else if (a.OCg <= 64 || (a.OCg % 128 != 0 && a.OCg % 64 == 0)) {
-    if (tiles(128, 64) >= 2 * num_cus()) { p.bm = 128; p.bn = 64; } else { p.bm = 64; p.bn = 64; }
-  } else {
-    if (tiles(128, 128) >= 2 * num_cus()) { p.bm = 128; p.bn = 128; if (big_waves == 8) p.wn = 4; }
-    else if (tiles(128, 64) >= 2 * num_cus()) { p.bm = 128; p.bn = 64; }
-    else { p.bm = 64; p.bn = 64; }
+  else if (a.OCg >= 128 && tiles(128, 128) >= 2 * num_cus()) { p.bm = 128; p.bn = 128; if (big_waves == 8) p.wn = 4; }
+  else if (a.OCg <= 64 && tiles(128, 64) >= 4 * num_cus()) { p.bm = 128; p.bn = 64; }
+  else { p.bm = 64; p.bn = 64; }
+  if (const char* f = getenv("CPM_IGEMM_FORCE")) {          // experiments: "bm,bn,split"
+    int bm, bn, sp;
+    if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3) {
+      p.bm = bm; p.bn = bn; p.wm = bn == 32 ? 4 : 2; p.wn = bn == 32 ? 1 : 2; p.split = sp < 1 ? 1 : sp;
+      if (p.split > a.ksteps / 2) p.split = a.ksteps / 2 > 0 ? a.ksteps / 2 : 1;
+      return p;
+    }
   }
   const int64_t t = tiles(p.bm, p.bn);
   p.split = 1;
-  if (t < 2 * num_cus() && a.ksteps >= 32) {
-    int want = (int)((3 * num_cus() + t - 1) / t);
+  const int64_t want_blocks = (p.bm == 64 ? 4 : 2) * num_cus();
+  if (t < want_blocks && a.ksteps >= 32) {
+    int want = (int)((want_blocks + t - 1) / t);
     int maxs = a.ksteps / 16;
     p.split = want < maxs ? want : maxs;
     if (p.split < 1) p.split = 1;
