@@ -210,12 +210,15 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, 
 }
 
 // ---- fused SGD ------------------------------------------------------------------------------------------------
-// One thread updates 4 consecutive elements; the segment (lr, weight decay) of each 64-element block comes from a
-// lookup table (segments are 64-element aligned), blocks in the alignment gaps are skipped.
+// One thread updates 4 consecutive elements; the segment of each 64-element block comes from a lookup table
+// (segments are 64-element aligned; blocks in the alignment gaps are skipped); the segment's parameter group gives
+// the learning rate / weight decay, which travel as kernel arguments (no host->device copy when the schedule moves).
+struct SgdGroups { float lr[8]; float wd[8]; };
+
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                            const int32_t* __restrict__ block_seg, const int64_t* __restrict__ seg_end,
-                           const float* __restrict__ seg_lr, const float* __restrict__ seg_wd, int64_t total,
-                           float momentum, float grad_scale, int first_step) {
+                           const int32_t* __restrict__ seg_group, SgdGroups grp, int64_t total, float momentum,
+                           float grad_scale, int first_step) {
   const int64_t nvec = total >> 2;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = v << 2;
@@ -223,7 +226,8 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     if (sidx < 0) continue;
     const int64_t end = seg_end[sidx];
     if (i >= end) continue;
-    const float lr = seg_lr[sidx], wd = seg_wd[sidx];
+    const int gi = seg_group[sidx] & 7;
+    const float lr = grp.lr[gi], wd = grp.wd[gi];
     float4 pv = *(const float4*)(p + i);
     const float4 gv = *(const float4*)(g + i);
     float4 bv = first_step ? make_float4(0.f, 0.f, 0.f, 0.f) : *(const float4*)(buf + i);
@@ -315,11 +319,15 @@ CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q,
 }
 
 CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
-                            const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg,
-                            int64_t total, float momentum, float grad_scale, int first_step, void* stream) {
-  CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_lr && seg_wd, "null pointer");
-  CPM_REQUIRE(nseg > 0 && total > 0 && total % 64 == 0, "bad shape (total must be a multiple of 64)");
+                            const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
+                            const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
+                            int first_step, void* stream) {
+  CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_group && h_group_lr && h_group_wd,
+              "null pointer");
+  CPM_REQUIRE(ngroups > 0 && ngroups <= 8 && total > 0 && total % 64 == 0, "bad shape (total % 64, <= 8 groups)");
+  SgdGroups grp = {};
+  for (int i = 0; i < ngroups; ++i) { grp.lr[i] = h_group_lr[i]; grp.wd[i] = h_group_wd[i]; }
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
-                     grads, momentum_buf, block_seg, seg_end, seg_lr, seg_wd, total, momentum, grad_scale, first_step);
+                     grads, momentum_buf, block_seg, seg_end, seg_group, grp, total, momentum, grad_scale, first_step);
   return cpm::check_launch("sgd_step");
 }

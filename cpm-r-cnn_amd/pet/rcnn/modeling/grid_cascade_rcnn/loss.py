@@ -28,8 +28,8 @@ class CLSLossComputation(object):
         for p, t in zip(proposals, targets):
             matched = self.proposal_matcher(boxlist_iou(t, p))
             lab = t.get_field("labels")[matched.clamp(min=0)].to(dtype=torch.int64)
-            lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
-            lab[matched == Matcher.BETWEEN_THRESHOLDS] = -1
+            lab = lab.masked_fill(matched == Matcher.BELOW_LOW_THRESHOLD, 0)
+            lab = lab.masked_fill(matched == Matcher.BETWEEN_THRESHOLDS, -1)
             labels.append(lab)
         return labels
 

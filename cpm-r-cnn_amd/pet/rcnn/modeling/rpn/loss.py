@@ -26,11 +26,11 @@ class RPNLossComputation(object):
         for (abox, vis), t in zip(anchors, targets):
             matched = self.proposal_matcher(box_iou_plus1(t.bbox, abox))
             lab = self.generate_labels_func(matched).to(dtype=torch.float32)
-            lab[matched == Matcher.BELOW_LOW_THRESHOLD] = 0
+            lab = lab.masked_fill(matched == Matcher.BELOW_LOW_THRESHOLD, 0)
             if "not_visibility" in self.discard_cases:
-                lab[~vis] = -1
+                lab = lab.masked_fill(~vis, -1)
             if "between_thresholds" in self.discard_cases:
-                lab[matched == Matcher.BETWEEN_THRESHOLDS] = -1
+                lab = lab.masked_fill(matched == Matcher.BETWEEN_THRESHOLDS, -1)
             labels.append(lab)
             regression_targets.append(self.box_coder.encode(t.bbox[matched.clamp(min=0)], abox))
         return labels, regression_targets

@@ -20,8 +20,10 @@ class Matcher(object):
             raise ValueError("No proposal boxes available for one of the images during training")
         vals, matches = match_quality_matrix.max(dim=0)
         best = matches.clone() if self.allow_low_quality_matches else None
-        matches[vals < self.low_threshold] = Matcher.BELOW_LOW_THRESHOLD
-        matches[(vals >= self.low_threshold) & (vals < self.high_threshold)] = Matcher.BETWEEN_THRESHOLDS
+        # torch.where instead of masked assignment: `t[mask] = v` runs a nonzero and synchronises with the device
+        matches = torch.where(vals < self.low_threshold, torch.full_like(matches, Matcher.BELOW_LOW_THRESHOLD), matches)
+        matches = torch.where((vals >= self.low_threshold) & (vals < self.high_threshold),
+                              torch.full_like(matches, Matcher.BETWEEN_THRESHOLDS), matches)
         if self.allow_low_quality_matches:
             row_max, _ = match_quality_matrix.max(dim=1)
             tied = (match_quality_matrix == row_max[:, None]).any(dim=0)     # predictions tying some gt's best

@@ -7,6 +7,8 @@ re-pointed into ONE fp32 buffer (parameters), with matching flat gradient and mo
 reverse forward order so that gradient chunks complete front-to-back during backward.  The update of all 196
 tensors is then one launch of cpm_sgd_step, and the data-parallel all-reduce works on a few large contiguous
 chunks (pet.utils.parallel) instead of per-tensor buckets."""
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -57,6 +59,7 @@ class FlatSGD(torch.optim.Optimizer):
             for p in g["params"]:
                 self._group_of[id(p)] = gi
         self._seg_pg = [self._group_of[id(p)] for p in params]
+        self.seg_pg = torch.tensor(self._seg_pg, dtype=torch.int32, device=device)
 
     def _view(self, flat, p, off, n):
         v = flat[off:off + n]
@@ -81,23 +84,16 @@ class FlatSGD(torch.optim.Optimizer):
                 if hasattr(p, "_cpm_uses"):
                     p._cpm_uses = 0
 
-    def _refresh_tables(self):
-        key = tuple((g["lr"], g["weight_decay"]) for g in self.param_groups)
-        if key != self._last:
-            lr = torch.tensor([self.param_groups[i]["lr"] for i in self._seg_pg], dtype=torch.float32)
-            wd = torch.tensor([self.param_groups[i]["weight_decay"] for i in self._seg_pg], dtype=torch.float32)
-            self.seg_lr.copy_(lr)
-            self.seg_wd.copy_(wd)
-            self._last = key
-
     @torch.no_grad()
     def step(self, closure=None):
-        self._refresh_tables()
+        ng = len(self.param_groups)
+        lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
+        wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
         with torch.cuda.device(self.flat_param.device):
             rc = H.lib().cpm_sgd_step(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
-                                      H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_lr),
-                                      H.ptr(self.seg_wd), len(self._seg_pg), H.c_int64(self.total),
-                                      H.f(self.momentum), H.f(self.grad_scale), int(self._steps == 0), H.stream())
+                                      H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
+                                      H.c_int64(self.total), H.f(self.momentum), H.f(self.grad_scale),
+                                      int(self._steps == 0), H.stream())
         H.check(rc, "sgd_step")
         self._steps += 1
 

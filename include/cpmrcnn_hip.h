@@ -168,15 +168,17 @@ int cpm_prof_summary(int kind, double* total_ms, double* total_flops, int64_t* l
 
 /* ---- fused SGD with momentum over a flat parameter buffer -------------------
  * Replaces torch.optim.SGD.step as built by pet/utils/optimizer.py:40-65 (3 param
- * groups: weights / biases (lr x2, no wd) / GN).  The flat buffer is cut into `nseg`
- * segments that start on 64-element boundaries: block_seg[i/64] (device int32) is the
- * segment of element i or -1 in an alignment gap, seg_end/seg_lr/seg_wd (device, per
- * segment) its end, learning rate and weight decay.
+ * groups: weights / biases (lr x2, no wd) / GN).  The flat buffer is cut into segments
+ * that start on 64-element boundaries: block_seg[i/64] (device int32) is the segment of
+ * element i or -1 in an alignment gap; seg_end / seg_group (device, per segment) give its
+ * end and parameter group; h_group_lr / h_group_wd are HOST arrays of `ngroups` (<= 8)
+ * values passed by value to the kernel (the schedule changes them every iteration).
  * d = g*grad_scale + wd*p; buf = momentum*buf + d (buf = d on the first step); p -= lr*buf
  * (torch.optim.SGD, dampening 0).                                                      */
 int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
-                 const int64_t* seg_end, const float* seg_lr, const float* seg_wd, int nseg, int64_t total,
-                 float momentum, float grad_scale, int first_step, void* stream);
+                 const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
+                 const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
+                 int first_step, void* stream);
 
 #ifdef __cplusplus
 }
