@@ -146,10 +146,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   const int k_end = min(a.ksteps, k_begin + per);
   const int nk = k_end - k_begin;
 
-  float4 ra[AP], rb[BP];
+  // two register sets: the loads of tile t+2 are in flight while tile t is multiplied and tile t+1 moves to LDS
+  float4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, float4 (&ra)[AP], float4 (&rb)[BP]) {
     const int tap = kt / a.ksteps_per_tap;
     const int c0 = (kt - tap * a.ksteps_per_tap) * BK + lcol;
     const int tr = tap / a.ns, ts = tap - tr * a.ns;
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
       rb[i] = v;
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP]) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) *(float4*)&As[buf][i * RPP + lrow][lcol] = ra[i];
 #pragma unroll
@@ -206,18 +207,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  if (nk > 0) {
-    load_tile(k_begin);
-    store_tile(0);
-  }
-  __syncthreads();
-
   const int frow = lane & 31, fk = (lane >> 5) * 4;
-  int cur = 0;
-  for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) load_tile(k_begin + it + 1);
+  auto mma_half = [&](int cur, int kb0) {
 #pragma unroll
-    for (int kb = 0; kb < BK / 8; ++kb) {
+    for (int kb = kb0; kb < kb0 + BK / 16; ++kb) {
       float4 fa[TM], fb[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = *(const float4*)&As[cur][wm * WTM + i * 32 + frow][kb * 8 + fk];
@@ -232,14 +225,30 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].z, fb[j].z, acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i].w, fb[j].w, acc[i][j], 0, 0, 0);
         }
-      // The next tile's registers go to LDS in the MIDDLE of the MFMA stream (its loads were issued half a step
-      // ago; the other buffer has been free since the last barrier): the step then ends with the barrier alone,
-      // and the wait + ds_writes of this wave overlap the co-resident wave's MFMAs instead of both waves of a
-      // SIMD leaving the matrix pipe idle at the same point of their (lock-stepped) iterations.
-      if (kb == BK / 16 - 1 && it + 1 < nk) store_tile(cur ^ 1);
     }
+  };
+  // One k-step: issue the loads of tile t+2, multiply the first half of tile t, move tile t+1 (loaded a whole
+  // step ago, so its wait is short) from registers to the other LDS buffer, multiply the second half, barrier.
+  // The store sits in the MIDDLE of the MFMA stream so that the wait + ds_writes of this wave overlap the
+  // co-resident waves' MFMAs and the step ends with the barrier alone.
+  auto step = [&](int it, int cur, float4 (&la)[AP], float4 (&lb)[BP], const float4 (&sa)[AP],
+                  const float4 (&sb)[BP]) {
+    if (it + 2 < nk) load_tile(k_begin + it + 2, la, lb);
+    mma_half(cur, 0);
+    if (it + 1 < nk) store_tile(cur ^ 1, sa, sb);
+    mma_half(cur, BK / 16);
     __syncthreads();
-    cur ^= 1;
+  };
+
+  if (nk > 0) {
+    load_tile(k_begin, ra0, rb0);
+    store_tile(0, ra0, rb0);
+    if (nk > 1) load_tile(k_begin + 1, ra1, rb1);
+  }
+  __syncthreads();
+  for (int it = 0; it < nk; it += 2) {
+    step(it, 0, ra0, rb0, ra1, rb1);                    // tile it in LDS[0]; tile it+1 waits in set 1
+    if (it + 1 < nk) step(it + 1, 1, ra1, rb1, ra0, rb0);
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
@@ -557,14 +566,8 @@ Plan plan_igemm(const IgemmArgs& a) {
   auto tiles = [&](int bm, int bn) { return (int64_t)cpm::cdiv(a.M, bm) * cpm::cdiv(a.OCg, bn) * a.groups; };
   static const int big_waves = env_int("CPM_IGEMM_BIG_WAVES", 4);      // 4: 2x2 waves, 8: 2x4 waves on 128x128
   Plan p;
-  p.wm = 2; p.wn = 2;
-  // measured on MI355X (tools/sweep_igemm.sh): the 128x128 tile wins once it fills two residency rounds' worth of
-  // CUs; below that the 64x64 tile at 4 workgroups per CU (reduction split until ~1024 workgroups) beats both the
-  // 128x64 tile and an un-split 64x64 grid -- thin problems are latency bound per workgroup
-  if (a.OCg <= 32) { p.bm = 128; p.bn = 32; p.wm = 4; p.wn = 1; }
-  else if (a.OCg >= 128 && tiles(128, 128) >= 2 * num_cus()) { p.bm = 128; p.bn = 128; if (big_waves == 8) p.wn = 4; }
-  else if (a.OCg <= 64 && tiles(128, 64) >= 4 * num_cus()) { p.bm = 128; p.bn = 64; }
-  else { p.bm = 64; p.bn = 64; }
+  p.wm = 2; p.wn = 2; p.split = 1;
+  if (a.OCg <= 32) { p.bm = 128; p.bn = 32; p.wm = 4; p.wn = 1; return p; }
   if (const char* f = getenv("CPM_IGEMM_FORCE")) {          // experiments: "bm,bn,split"
     int bm, bn, sp;
     if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3) {
@@ -573,16 +576,42 @@ Plan plan_igemm(const IgemmArgs& a) {
       return p;
     }
   }
-  const int64_t t = tiles(p.bm, p.bn);
-  p.split = 1;
-  const int64_t want_blocks = (p.bm == 64 ? 4 : 2) * num_cus();
-  if (t < want_blocks && a.ksteps >= 32) {
-    int want = (int)((want_blocks + t - 1) / t);
-    int maxs = a.ksteps / 16;
-    p.split = want < maxs ? want : maxs;
-    if (p.split < 1) p.split = 1;
-    if (p.split > 64) p.split = 64;
+  // Cost model fitted to tools/sweep_igemm.sh on MI355X.  A candidate = (tile, reduction split).  Its grid runs in
+  // residency rounds of `per_cu` workgroups per CU (LDS-limited: 2 for the 128-tiles, 4 for 64x64); a workgroup
+  // costs its MFMA work / tile efficiency plus a fixed prologue+epilogue, and a partly filled round is cheaper
+  // than a full one (a workgroup alone on a CU is latency bound, not 4x faster).  Thin problems therefore get the
+  // small tile with the reduction split until the chip holds ~4 workgroups per CU, big ones the 128x128 tile
+  // with the remainder of the last round re-tiled (launch_igemm).
+  struct Cand { int bm, bn, per_cu; double eff; };
+  const Cand cands[3] = {{128, 128, 2, 1.00}, {128, 64, 2, 0.86}, {64, 64, 4, 0.78}};
+  double best = 1e300;
+  for (const Cand& c : cands) {
+    if (c.bn == 128 && a.OCg < 128) continue;
+    const int64_t t = tiles(c.bm, c.bn);
+    const int64_t slots = (int64_t)c.per_cu * num_cus();
+    const int max_split = a.ksteps >= 32 ? a.ksteps / 16 : 1;
+    for (int sp = 1; sp <= max_split && sp <= 64; ++sp) {
+      const int64_t blocks = t * sp;
+      const double per_block = ((double)c.bm * c.bn * ((double)a.ksteps / sp + 5.0)) / c.eff;
+      const int64_t full = blocks / slots, tail = blocks % slots;
+      double rounds = (double)full;
+      if (tail) {
+        const double occ = (double)((tail + num_cus() - 1) / num_cus()) / c.per_cu;     // fraction of a full round
+        rounds += 0.42 + 0.58 * occ;
+      }
+      // the 128x128 grid drops its partial round onto 64x64 tiles when that round is less than half full
+      if (c.bm == 128 && c.bn == 128 && sp == 1 && full >= 1 && tail && tail * 2 < slots)
+        rounds = (double)full + 0.30 + 0.7 * (double)tail / slots;
+      double cost = rounds * per_block * c.per_cu;     // a round of per_cu workgroups shares the CU's MFMA pipes
+      if (sp > 1) cost += 3.0 * (double)a.M * a.OCg * a.groups / num_cus();            // memset + atomics + epilogue pass
+      if (cost < best) { best = cost; p.bm = c.bm; p.bn = c.bn; p.split = sp; }
+      if (blocks >= 4 * slots) break;
+    }
   }
+  if (p.bm == 128 && p.bn == 128 && big_waves == 8) p.wn = 4;
+  static const int dbg = env_int("CPM_IGEMM_DEBUG", 0);
+  if (dbg) fprintf(stderr, "[igemm plan] M=%d OCg=%d ksteps=%d groups=%d -> %dx%d split %d (tiles %lld)\n", a.M, a.OCg,
+                   a.ksteps, a.groups, p.bm, p.bn, p.split, (long long)tiles(p.bm, p.bn));
   return p;
 }
 
