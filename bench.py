@@ -152,6 +152,9 @@ def conv_roofline(trainer, images, targets, steps=2):
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
         L.cpm_prof_summary(kind, ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         kinds[name] = dict(ms=ms.value / steps, gflop=fl.value / steps / 1e9, launches=n.value // steps)
+    dump = os.environ.get("CPM_PROF_DUMP")
+    if dump:
+        L.cpm_prof_dump(dump.encode())
     L.cpm_prof_enable(0)
     # dominant kernel = igemm_kernel<...> (forward-gather + data-gradient-gather instantiations of one template)
     ms = kinds["igemm_fwd"]["ms"] + kinds["igemm_dgrad"]["ms"]

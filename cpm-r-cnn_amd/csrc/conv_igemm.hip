@@ -96,8 +96,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   constexpr int AP = BM / RPP, BP = BN / RPP;   // load passes
   static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile shape");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDP];
+  constexpr int CP = BN + 4;                    // epilogue staging pitch (floats)
+  constexpr int LDS_AB = 2 * (BM + BN) * LDP, LDS_C = BM * CP;
+  __shared__ __attribute__((aligned(16))) float smem[LDS_AB > LDS_C ? LDS_AB : LDS_C];
+  float (*As)[BM][LDP] = reinterpret_cast<float (*)[BM][LDP]>(smem);
+  float (*Bs)[BN][LDP] = reinterpret_cast<float (*)[BN][LDP]>(smem + 2 * BM * LDP);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -255,6 +258,68 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
   const bool dense_rows = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
+  if (a.res && !a.atomic_out) {
+    // Residual epilogue (bottleneck conv3, FPN laterals): memory bound on thin reductions.  Stage the tile through
+    // LDS (the operand buffers are free after the last barrier) and finish it row-wise with 16-byte accesses, so
+    // that the residual reads and the stores are whole 512-byte rows instead of 4-byte column slices.
+    float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+          Cs[wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0][wn * WTN + j * 32 + ecol] = acc[i][j][e];
+    __syncthreads();
+    constexpr int CV = BN / 4;                  // float4 per tile row
+    constexpr int RPS = NT / CV;                // rows per store pass
+    const int cv = (tid % CV) * 4, r0 = tid / CV;
+    const int ocl = n0 + cv;
+    const bool vec_out = (a.OCg & 3) == 0 && (a.OCtot & 3) == 0 && ocl + 3 < a.OCg;
+    const int oc = g * a.OCg + ocl;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ocl < a.OCg) {
+      float* scp = &sc.x; float* shp = &sh.x;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (ocl + k < a.OCg) {
+          if (a.scale) scp[k] = a.scale[oc + k];
+          if (a.shift) shp[k] = a.shift[oc + k];
+        }
+    }
+    for (int r = r0; r < BM; r += RPS) {
+      const int m = m0 + r;
+      if (m >= a.M || ocl >= a.OCg) continue;
+      int orow = m, oh = 0, ow = 0, n = 0;
+      if (!dense_rows || a.res_mode == 1) {
+        const int jj = m % a.OWp, t = m / a.OWp;
+        const int ii = t % a.OHp;
+        n = t / a.OHp;
+        oh = ii * a.osh + a.oah;
+        ow = jj * a.osw + a.oaw;
+        orow = (n * a.OH + oh) * a.OW + ow;
+      }
+      float4 v = *(const float4*)&Cs[r][cv];
+      v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+      float* dst = a.out + (size_t)orow * a.OCtot + oc;
+      const float* rp = a.res_mode == 0
+                            ? a.res + (size_t)orow * a.OCtot + oc
+                            : a.res + ((size_t)(n * ((a.OH + 1) / 2) + oh / 2) * ((a.OW + 1) / 2) + ow / 2) * a.OCtot + oc;
+      if (vec_out) {
+        const float4 rv = *(const float4*)rp;
+        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        *(float4*)dst = v;
+      } else {
+        float* vp = &v.x;
+        for (int k = 0; k < 4 && ocl + k < a.OCg; ++k) {
+          float o = vp[k] + rp[k];
+          dst[k] = a.relu ? fmaxf(o, 0.f) : o;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -534,16 +599,18 @@ int num_cus() { return 256; }
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default:
 // the hot path pays one predictable branch.
-struct ProfRec { hipEvent_t a, b; double flops; int kind; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; int dims[10]; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static double g_flops_next = 0.0;
+static int g_dims_next[10] = {0};
 
 struct ProfScope {
   hipStream_t s; int kind; bool on; ProfRec r;
   ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_), on(g_prof_on) {
     if (on) {
       r.kind = kind; r.flops = g_flops_next;
+      for (int i = 0; i < 10; ++i) r.dims[i] = g_dims_next[i];
       on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess &&
            hipEventRecord(r.a, s) == hipSuccess;
     }
@@ -720,6 +787,7 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
     if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = launch_igemm(a, p, s, 0);
   if (rc != CPM_OK) return rc;
   if (a.atomic_out && (scale || shift || residual || relu)) {
@@ -769,6 +837,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = CPM_OK;
   for (int pa = 0; pa < st && rc == CPM_OK; ++pa) {
     for (int pb = 0; pb < st && rc == CPM_OK; ++pb) {
@@ -860,6 +929,7 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
     return best;
   };
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   ProfScope prof_scope(s, 2);
   const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) &&
                     (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
@@ -905,5 +975,22 @@ CPM_EXPORT int cpm_prof_summary(int kind, double* total_ms, double* total_flops,
     ms += t; fl += r.flops; ++n;
   }
   *total_ms = ms; *total_flops = fl; *launches = n;
+  return CPM_OK;
+}
+
+CPM_EXPORT int cpm_prof_dump(const char* path) {
+  CPM_REQUIRE(path, "null path");
+  FILE* f = fopen(path, "w");
+  CPM_REQUIRE(f, "cannot open file");
+  fprintf(f, "kind,N,H,W,C,K,R,stride,groups,P,Q,gflop,ms\n");
+  for (auto& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) { fclose(f); return CPM_ELAUNCH; }
+    float t = 0.f;
+    (void)hipEventElapsedTime(&t, r.a, r.b);
+    fprintf(f, "%d", r.kind);
+    for (int i = 0; i < 10; ++i) fprintf(f, ",%d", r.dims[i]);
+    fprintf(f, ",%.4f,%.5f\n", r.flops / 1e9, t);
+  }
+  fclose(f);
   return CPM_OK;
 }

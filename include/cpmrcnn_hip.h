@@ -165,6 +165,8 @@ int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, flo
  * 1 = igemm data-gradient-gather, 2 = weight gradient.  Not thread safe; off on the hot path. */
 int cpm_prof_enable(int on);
 int cpm_prof_summary(int kind, double* total_ms, double* total_flops, int64_t* launches);
+/* per-launch CSV (kind, conv dims, algorithmic GFLOP, HIP-event ms) of everything recorded since cpm_prof_enable(1) */
+int cpm_prof_dump(const char* path);
 
 /* ---- fused SGD with momentum over a flat parameter buffer -------------------
  * Replaces torch.optim.SGD.step as built by pet/utils/optimizer.py:40-65 (3 param
