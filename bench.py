@@ -218,6 +218,8 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--layers", type=str, default="3,4,6,3", help="ResNet depth: 3,4,6,3 (R-50) / 3,4,23,3 (R-101)")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
+                    "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -225,11 +227,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = local_rank if a.backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", init_method="env://")      # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend=a.backend, init_method="env://")   # "nccl" is RCCL on ROCm
     assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     import __graft_entry__ as entry
@@ -284,7 +287,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s CPM R-CNN (CMM x3 + ISM + RSM) training step, %d x 3x%dx%d per GPU, "
                                    "16 gt boxes/img, reference initialisers + frozen-BN affine calibrated on a synthetic batch" % (model_name, a.batch, a.height, a.width),
-                       "global_batch": a.batch * world, "parallelism": "dp%d" % world,
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "cpu_baseline": cpu,
