@@ -40,6 +40,54 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
   }
 }
 
+// Vectorised variant: a thread owns 4 consecutive channels (one float4) and walks rows; the 256 threads of a block
+// cover `RP` rows x `CV` float4-columns per iteration (CV = 256/RP), so every load/store is 16 bytes and coalesced.
+template <int RP>
+__global__ __launch_bounds__(256) void epilogue_bwd_vec_kernel(const float* __restrict__ dy,
+                                                               const float* __restrict__ y,
+                                                               const float* __restrict__ scale, int relu, int64_t M,
+                                                               int K, int rows_per_slab, float* __restrict__ dpre,
+                                                               float* __restrict__ dres, float* __restrict__ dshift) {
+  constexpr int CV = 256 / RP;                    // float4 columns handled by one block
+  __shared__ float4 part[256];
+  const int cv = threadIdx.x % CV, rp = threadIdx.x / CV;
+  const int k = (blockIdx.x * CV + cv) * 4;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_slab;
+  const int64_t r1 = r0 + rows_per_slab < M ? r0 + rows_per_slab : M;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (k < K) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (scale) sc = *(const float4*)(scale + k);
+    for (int64_t m = r0 + rp; m < r1; m += RP) {
+      const int64_t idx = m * K + k;
+      float4 g = *(const float4*)(dy + idx);
+      if (relu) {
+        const float4 yv = *(const float4*)(y + idx);
+        if (!(yv.x > 0.f)) g.x = 0.f;
+        if (!(yv.y > 0.f)) g.y = 0.f;
+        if (!(yv.z > 0.f)) g.z = 0.f;
+        if (!(yv.w > 0.f)) g.w = 0.f;
+      }
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+      if (dres) *(float4*)(dres + idx) = g;
+      if (dpre) *(float4*)(dpre + idx) = make_float4(g.x * sc.x, g.y * sc.y, g.z * sc.z, g.w * sc.w);
+    }
+  }
+  if (dshift) {
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if (rp == 0 && k < K) {
+      float4 t = acc;
+      for (int r = 1; r < RP; ++r) {
+        const float4 o = part[r * CV + cv];
+        t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+      }
+      atomicAdd(dshift + k, t.x); atomicAdd(dshift + k + 1, t.y);
+      atomicAdd(dshift + k + 2, t.z); atomicAdd(dshift + k + 3, t.w);
+    }
+  }
+}
+
 // ---- im2col (thin-channel stem) --------------------------------------------------------------------------
 __global__ void im2col_kernel(const float* __restrict__ x, int layout, int N, int C, int H, int W, int R, int S,
                               int stride, int pad, int P, int Q, int Kpad, float* __restrict__ out) {
@@ -256,6 +304,27 @@ CPM_EXPORT int cpm_epilogue_backward(const float* dy, const float* y, const floa
   CPM_REQUIRE(M >= 0 && K > 0, "bad shape");
   if (M == 0) return CPM_OK;
   CPM_REQUIRE(dy && (!relu || y), "null pointer");
+  const bool aligned = (K % 4 == 0) && !((uintptr_t)dy & 15) && !((uintptr_t)y & 15) && !((uintptr_t)dpre & 15) &&
+                       !((uintptr_t)dres & 15) && !((uintptr_t)scale & 15);
+  const int cvk = K / 4;                      // float4 per row
+  if (aligned && cvk >= 16) {
+    // rows per block iteration: as many as fit 256 threads (power of two), at least 1
+    int rp = 1;
+    while (rp < 16 && cvk * rp * 2 <= 256) rp *= 2;
+    const int cv = 256 / rp;
+    const int gx = cpm::cdiv(cvk, cv);
+    int64_t want = (int64_t)2048 / gx;        // ~8 blocks per CU overall
+    if (want < 1) want = 1;
+    int64_t rows = (M + want - 1) / want;
+    if (rows < 64) rows = 64;
+    const int slabs = (int)((M + rows - 1) / rows);
+#define EL(RP)                                                                                               \
+  hipLaunchKernelGGL((epilogue_bwd_vec_kernel<RP>), dim3(gx, slabs), dim3(256), 0, (hipStream_t)stream, dy, y, \
+                     scale, relu, M, K, (int)rows, dpre, dres, dshift)
+    if (rp == 1) EL(1); else if (rp == 2) EL(2); else if (rp == 4) EL(4); else if (rp == 8) EL(8); else EL(16);
+#undef EL
+    return cpm::check_launch("epilogue_backward");
+  }
   int slabs = (int)((M + 511) / 512);
   if (slabs > 2048) slabs = 2048;
   const int rows = (int)((M + slabs - 1) / slabs);
