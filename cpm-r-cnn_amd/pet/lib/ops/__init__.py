@@ -8,3 +8,4 @@ from .modules import Conv2d, Linear, ConvTranspose2d, GroupNorm, ReLU
 from .conv import conv2d, linear, conv_transpose2d, group_norm, stem_forward
 from .pool_points_interp import pool_points_interp, PoolPointsInterp
 from .boxes import box_iou
+from .deform_conv import deform_conv, cols_conv, DeformConv, DeformConvPack

@@ -1,0 +1,207 @@
+"""Deformable convolution v1 and narrow-group convolution (counterpart of pet/lib/ops/deform_conv.py:13-186,
+323-400,472-514; native side pet/lib/ops/csrc/Deformable/deform_conv_cuda.cu).
+
+Same call surface as the reference (`deform_conv(input, offset, weight, bias, stride, padding, dilation, groups,
+deformable_groups)`, `DeformConv`, `DeformConvPack` with its zero-initialised `conv_offset`), different engine:
+the sampled columns are written pixel-major (`cpm_deform_im2col`) so that the contraction, its data gradient and
+its weight gradient are ONE grouped 1x1 problem each on the MFMA implicit-GEMM kernels, with the frozen affine /
+bias / ReLU fused in the epilogue; `cpm_deform_col2im` / `cpm_deform_coord_grad` scatter the column gradient back
+to the input and the offsets.  `offset=None` runs the same path as a plain im2col: that is how ResNeXt's ordinary
+3x3 convs with 4..32 channels per group avoid zero-padding every group to a 32-deep MFMA k-step."""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from . import _hip as H
+from . import conv as F
+from .modules import Conv2d
+
+
+def _geom(x_shape, w_shape, stride, pad, dil, groups, dg):
+    n, c, h, w = x_shape
+    k, cg, r, s = w_shape
+    if cg * groups != c:
+        raise RuntimeError("weight [%d,%d,%d,%d] does not match %d input channels in %d groups" % (k, cg, r, s, c,
+                                                                                                    groups))
+    p, q = F.out_size(h, r, stride, pad, dil), F.out_size(w, s, stride, pad, dil)
+    return (int(n), int(h), int(w), int(c), int(r), int(s), int(stride), int(pad), int(dil), int(groups), int(dg),
+            int(p), int(q))
+
+
+def _check_offset(offset, geom):
+    n, _, _, _, r, s, _, _, _, _, dg, p, q = geom
+    if tuple(offset.shape) != (n, 2 * r * s * dg, p, q):
+        raise RuntimeError("offset must be [%d, %d, %d, %d], got %s" % (n, 2 * r * s * dg, p, q,
+                                                                        tuple(offset.shape)))
+
+
+def sample_columns(x, offset, geom):
+    """cols [N*P*Q, groups*R*S*C/groups]; logical NCHW view [N, R*S*C, P, Q] in NHWC memory."""
+    n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
+    cols = torch.empty((n, p, q, r * s * c), dtype=torch.float32, device=x.device)
+    if cols.numel():
+        with torch.cuda.device(x.device):
+            rc = H.lib().cpm_deform_im2col(H.ptr(x), H.ptr(offset), n, h, w, c, r, s, stride, pad, dil, groups, dg,
+                                           p, q, H.ptr(cols), H.stream())
+        H.check(rc, "deform_im2col")
+    return cols.permute(0, 3, 1, 2)
+
+
+def _w1x1(w):
+    """[K, C/g, R, S] in KRSC memory -> the same bytes as a [K, R*S*C/g, 1, 1] weight (no copy)."""
+    k, cg, r, s = w.shape
+    return w.permute(0, 2, 3, 1).reshape(k, r * s * cg, 1, 1)
+
+
+class _ColsConvFn(Function):
+    """y = relu?( contract(columns(x, offset), w) * scale + shift )"""
+
+    @staticmethod
+    def forward(ctx, x, offset, w, scale, shift, stride, pad, dil, groups, dg, relu):
+        H.require_gpu(x, offset, w, scale, shift)
+        x = F.nhwc(x)
+        w_in = w
+        w = F._wmem(w)
+        geom = _geom(x.shape, w.shape, stride, pad, dil, groups, dg)
+        if offset is not None:
+            offset = F.nhwc(offset)
+            _check_offset(offset, geom)
+        ctx.wparam = w_in if (ctx.needs_input_grad[2] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
+        if ctx.wparam is not None:
+            w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+        cols = sample_columns(x, offset, geom)
+        y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups)
+        ctx.geom, ctx.relu = geom, relu
+        ctx.has = (scale is not None, shift is not None)
+        need_cols = ctx.needs_input_grad[2]
+        ctx.save_for_backward(x, offset, w, scale, y if relu else None, cols if need_cols else None)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, offset, w, scale, y, cols = ctx.saved_tensors
+        n, h, wd, c, r, s, stride, pad, dil, groups, dg, p, q = ctx.geom
+        has_scale, has_shift = ctx.has
+        need_x, need_off, need_w, _, need_shift = ctx.needs_input_grad[:5]
+        dy = F.nhwc(dy)
+        dpre, dshift = dy, None
+        if ctx.relu or has_scale or (has_shift and need_shift):
+            dpre_k, _, dshift = F.epilogue_backward(dy, y, scale, ctx.relu, want_dpre=ctx.relu or has_scale,
+                                                    want_dshift=has_shift and need_shift)
+            dpre = dpre_k if dpre_k is not None else dy
+        w1 = _w1x1(w)
+        dw = None
+        if need_w:
+            wp = ctx.wparam
+            if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
+                F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups, out=wp._cpm_grad_sink)
+                wp._cpm_uses -= 1
+                if wp._cpm_uses == 0:
+                    ready = getattr(wp, "_cpm_grad_ready", None)
+                    if ready is not None:
+                        ready(wp)
+            else:
+                dw1 = F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups)
+                k, cg = w.shape[0], w.shape[1]
+                dw = dw1.view(k, r, s, cg).permute(0, 3, 1, 2)
+        dx = doff = None
+        need_off = need_off and offset is not None
+        if need_x or need_off:
+            dcols = F.conv2d_backward_data(dpre, w1, (n, r * s * c, p, q), 1, 0, 1, groups)
+            args = (n, h, wd, c, r, s, stride, pad, dil, groups, dg, p, q)
+            with torch.cuda.device(dy.device):
+                if need_x:
+                    dx = F.empty_nhwc((n, c, h, wd), dy).zero_()
+                    if dcols.numel():
+                        rc = H.lib().cpm_deform_col2im(H.ptr(dcols), H.ptr(offset), *args, H.ptr(dx), H.stream())
+                        H.check(rc, "deform_col2im")
+                if need_off:
+                    doff = torch.empty_like(offset)
+                    if dcols.numel():
+                        rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(offset), *args, H.ptr(doff),
+                                                           H.stream())
+                        H.check(rc, "deform_coord_grad")
+        return dx, doff, dw, None, dshift, None, None, None, None, None, None
+
+
+def _one(v):
+    a, b = _pair(v)
+    if a != b:
+        raise RuntimeError("only square stride / padding / dilation are on the hot path")
+    return int(a)
+
+
+def cols_conv(x, offset, weight, scale=None, shift=None, stride=1, padding=0, dilation=1, groups=1,
+              deformable_groups=1, relu=False):
+    return _ColsConvFn.apply(x, offset, weight, scale, shift, _one(stride), _one(padding), _one(dilation),
+                             int(groups), int(deformable_groups), bool(relu))
+
+
+def deform_conv(input, offset, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
+                im2col_step=64):
+    """Reference signature (deform_conv.py:13-27 + the bias add of :375-388); im2col_step is accepted and unused --
+    the whole batch is one launch here."""
+    if offset is None:
+        raise RuntimeError("deform_conv needs an offset tensor")
+    return cols_conv(input, offset, weight, None, bias, stride, padding, dilation, groups, deformable_groups)
+
+
+class DeformConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__()
+        self.with_bias = bias
+        assert in_channels % groups == 0, \
+            "in_channels {} cannot be divisible by groups {}".format(in_channels, groups)
+        assert out_channels % groups == 0, \
+            "out_channels {} cannot be divisible by groups {}".format(out_channels, groups)
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride, self.padding, self.dilation = _pair(stride), _pair(padding), _pair(dilation)
+        self.groups, self.deformable_groups = groups, deformable_groups
+        self.weight = nn.Parameter(torch.Tensor(out_channels, in_channels // groups, *self.kernel_size))
+        if bias:
+            self.bias = nn.Parameter(torch.Tensor(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        nn.init.kaiming_uniform_(self.weight, nonlinearity="relu")
+        if self.bias is not None:
+            nn.init.constant_(self.bias, 0)
+
+    def _run(self, x, offset, scale, shift, relu):
+        if shift is None:
+            shift = self.bias
+        else:
+            assert self.bias is None
+        return cols_conv(x, offset, self.weight, scale, shift, self.stride, self.padding, self.dilation, self.groups,
+                         self.deformable_groups, relu)
+
+    def forward(self, x, offset, scale=None, shift=None, relu=False):
+        return self._run(x, offset, scale, shift, relu)
+
+    def extra_repr(self):
+        return ("in_channels={in_channels}, out_channels={out_channels}, kernel_size={kernel_size}, stride={stride}, "
+                "padding={padding}, dilation={dilation}, groups={groups}, deformable_groups={deformable_groups}, "
+                "bias={with_bias}").format(**self.__dict__)
+
+
+class DeformConvPack(DeformConv):
+    """DeformConv that predicts its own offsets with a zero-initialised conv (deform_conv.py:472-513)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1,
+                 deformable_groups=1, bias=False):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, groups,
+                         deformable_groups, bias)
+        self.conv_offset = Conv2d(self.in_channels,
+                                  self.deformable_groups * 2 * self.kernel_size[0] * self.kernel_size[1],
+                                  kernel_size=self.kernel_size, stride=_pair(self.stride),
+                                  padding=_pair(self.padding), bias=True)
+        self.conv_offset.weight.data.zero_()
+        self.conv_offset.bias.data.zero_()
+
+    def forward(self, x, scale=None, shift=None, relu=False):
+        offset = self.conv_offset(x)
+        return self._run(x, offset, scale, shift, relu)

@@ -16,6 +16,13 @@ class Conv2d(nn.Conv2d):
             shift = self.bias
         else:
             assert self.bias is None
+        if self.groups > 1 and self.in_channels // self.groups < 32 and self.kernel_size != (1, 1) \
+                and residual is None:
+            # narrow groups (ResNeXt 64x4d: 4..16 channels per group): sample columns once and contract R*S*C/g
+            # deep instead of zero-padding every tap of every group to a 32-deep MFMA k-step
+            from .deform_conv import cols_conv
+            return cols_conv(x, None, self.weight, scale, shift, self.stride, self.padding, self.dilation,
+                             self.groups, 1, relu)
         return F.conv2d(x, self.weight, scale, shift, residual, self.stride[0], self.padding[0], self.dilation[0],
                         self.groups, relu, res_mode)
 

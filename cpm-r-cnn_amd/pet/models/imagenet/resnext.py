@@ -1,0 +1,101 @@
+"""ResNeXt bottleneck body (counterpart of pet/models/imagenet/resnext.py:14-83,173-297).
+
+Block layout and parameter names are the reference's (conv1/bn1 1x1, conv2/bn2 grouped 3x3 carrying the stride --
+an `ops.DeformConvPack` with its `conv_offset` child when the stage is 'deform' --, conv3/bn3 1x1,
+downsample.0/.1), so `resnext101b_64x4d` checkpoints map key-for-key.  Every conv runs on the HIP kernels with the
+frozen affine, residual add and ReLU fused; the grouped 3x3 (4..32 channels per group) goes through the column
+path of pet/lib/ops/deform_conv.py."""
+import math
+
+import torch.nn as nn
+
+import pet.lib.ops as ops
+from pet.models.imagenet.resnet import _affine
+from pet.utils.net import make_norm
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, base_width, cardinality, stride=1, dilation=1, norm="bn", conv="normal",
+                 context="none", ctx_ratio=0.0625, downsample=None):
+        super().__init__()
+        D = int(math.floor(planes * (base_width / 64.0)))
+        C = cardinality
+        if conv == "normal":
+            conv_op = ops.Conv2d
+        elif conv == "deform":
+            conv_op = ops.DeformConvPack
+        else:
+            raise ValueError("{} type conv operation is not on the hot path (dcn v1 and normal are).".format(conv))
+        if context != "none":
+            raise ValueError("{} type context operation is outside the hot path.".format(context))
+        self.conv1 = ops.Conv2d(inplanes, D * C, kernel_size=1, stride=1, padding=0, bias=False)
+        self.bn1 = make_norm(D * C, norm=norm)
+        self.conv2 = conv_op(D * C, D * C, kernel_size=3, stride=stride, dilation=dilation, padding=dilation,
+                             groups=C, bias=False)
+        self.bn2 = make_norm(D * C, norm=norm)
+        self.conv3 = ops.Conv2d(D * C, planes * 4, kernel_size=1, stride=1, padding=0, bias=False)
+        self.bn3 = make_norm(planes * 4, norm=norm)
+        self.ctx = None
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        s, b = _affine(self.bn1)
+        out = self.conv1(x, scale=s, shift=b, relu=True)
+        s, b = _affine(self.bn2)
+        out = self.conv2(out, scale=s, shift=b, relu=True)
+        residual = x
+        if self.downsample is not None:
+            s, b = _affine(self.downsample[1])
+            residual = self.downsample[0](x, scale=s, shift=b)
+        s, b = _affine(self.bn3)
+        return self.conv3(out, scale=s, shift=b, residual=residual, relu=True)
+
+
+class ResNeXt(nn.Module):
+    """Parameter container + layer builder shared with the detection backbone (resnext.py:173-297)."""
+
+    def __init__(self):
+        super().__init__()
+
+    @property
+    def stage_out_dim(self):
+        return [64, 64 * self.expansion, 128 * self.expansion, 256 * self.expansion, 512 * self.expansion]
+
+    def _init_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, (nn.BatchNorm2d, nn.GroupNorm)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.0001)
+                nn.init.constant_(m.bias, 0)
+        for m in self.modules():                       # zero-init the offset predictors (resnext.py:248-252)
+            if isinstance(m, ops.DeformConvPack):
+                nn.init.constant_(m.conv_offset.weight, 0)
+                nn.init.constant_(m.conv_offset.bias, 0)
+        for m in self.modules():                       # zero gamma of each block's last norm (:256-259)
+            if isinstance(m, Bottleneck):
+                nn.init.constant_(m.bn3.weight, 0)
+
+    def _make_layer(self, block, planes, blocks, stride=1, dilation=1, conv="normal", context="none"):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            if self.avg_down:
+                raise ValueError("AVG_DOWN is outside the hot path")
+            downsample = nn.Sequential(
+                ops.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                make_norm(planes * block.expansion, norm=self.norm))
+        layers = [block(self.inplanes, planes, self.base_width, self.cardinality, stride, dilation, self.norm, conv,
+                        context, self.ctx_ratio, downsample)]
+        self.inplanes = planes * block.expansion
+        for _ in range(1, blocks):
+            layers.append(block(self.inplanes, planes, self.base_width, self.cardinality, 1, dilation, self.norm,
+                                conv, context, self.ctx_ratio))
+        return nn.Sequential(*layers)

@@ -96,9 +96,3 @@ def resnet():
 @registry.BACKBONES.register("resnet_c4")
 def resnet_c4():
     return ResNet(norm=get_norm(), stride=16)
-
-
-@registry.BACKBONES.register("resnext")
-def resnext():
-    raise NotImplementedError("ResNeXt-64x4d + DCN (BASELINE config #5) needs the narrow-group and deformable "
-                              "im2col kernels scheduled for a later round (DESIGN.md, out of scope this round)")

@@ -144,6 +144,25 @@ int cpm_im2col(const float* x, int layout, int N, int C, int H, int W, int R, in
 /* nn.MaxPool2d(3, 2, 1) of the stem (backbone/ResNet.py:136), NHWC, forward only (frozen stage) */
 int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, int P, int Q, float* y, void* stream);
 
+/* ---- Deformable conv v1 / narrow-group 3x3 (ResNeXt-64x4d + DCN body) -------
+ * Replaces _C.deform_conv_forward / _backward_input / _backward_parameters
+ * (pet/lib/ops/csrc/vision.cpp:33-38, deform_conv_cuda.cu:324-736; sampling rules
+ * deform_conv_cuda_kernel.cu:95-460).  The contraction itself runs on cpm_conv2d_* as a grouped
+ * 1x1 conv over the columns, whose weight is the layer's own KRSC weight:
+ *   x [N,H,W,C] NHWC; offset [N,P,Q,2*R*S*deformable_groups] NHWC (channel 2*(i*S+j) = row offset,
+ *   +1 = column offset) or NULL (= plain im2col, used for ResNeXt's ordinary grouped 3x3);
+ *   cols / dcols [N*P*Q][groups][R*S][C/groups].
+ * cpm_deform_col2im accumulates into dx (caller zero-fills); cpm_deform_coord_grad overwrites doffset. */
+int cpm_deform_im2col(const float* x, const float* offset, int N, int H, int W, int C, int R, int S, int stride,
+                      int pad, int dilation, int groups, int deformable_groups, int P, int Q, float* cols,
+                      void* stream);
+int cpm_deform_col2im(const float* dcols, const float* offset, int N, int H, int W, int C, int R, int S, int stride,
+                      int pad, int dilation, int groups, int deformable_groups, int P, int Q, float* dx,
+                      void* stream);
+int cpm_deform_coord_grad(const float* dcols, const float* x, const float* offset, int N, int H, int W, int C,
+                          int R, int S, int stride, int pad, int dilation, int groups, int deformable_groups, int P,
+                          int Q, float* doffset, void* stream);
+
 /* ---- GroupNorm (+ReLU), NHWC ----------------------------------------------
  * Replaces nn.GroupNorm + nn.ReLU in grid_heads.py:47-55 and outputs.py:23,68.
  * x [N,HW,C]; mean/rstd [N,G] saved for backward; dgamma/dbeta accumulate.      */

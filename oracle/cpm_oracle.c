@@ -17,6 +17,8 @@
  *                        ml_nms (ml_nms.h:38) and nms lives in torchvision
  *                        (absent, unpinned version).  Restated from ml_nms.cu
  *                        and checked against a brute-force greedy in tests.
+ *   orc_deform_conv      PARITY UNPINNED (CUDA-only op in the reference; see its
+ *                        section header for what pins it instead).
  *   the box/level/grid helpers are pinned by goldens produced by importing the
  *   reference's Python (tests/golden/make_golden.py).
  */
@@ -517,4 +519,97 @@ ORC_API void orc_cell_anchors(double stride, const double* sizes, int ns,
       out[o++] = axc + 0.5 * (sw - 1); out[o++] = ayc + 0.5 * (sh - 1);
     }
   }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Deformable convolution v1 -- pet/lib/ops/csrc/Deformable/                 */
+/*   deform_conv_cuda_kernel.cu:95-128 (bilinear sample), :215-287 (im2col), */
+/*   :131-160 (gradient weight), :163-213 (coordinate weight), :290-460       */
+/*   (col2im / col2im_coord); contraction deform_conv_cuda.cu:402-407.        */
+/* PARITY UNPINNED against the reference binary (CUDA-only op, no CPU kernel  */
+/* and no test vectors in the reference); pinned instead by a known answer    */
+/* (zero offsets == grouped convolution) and an independent autograd          */
+/* formulation in tests/test_deform_oracle.py.                                */
+/* Layout NCHW; offset [N, dg*2*R*S, P, Q]; weight [K, C/groups, R, S].       */
+/* mode 0: y only.  mode 1: also dx, doffset, dw from dy (all accumulate into */
+/* zero-filled outputs).                                                      */
+/* ------------------------------------------------------------------------- */
+typedef struct { int ok; int h0, w0; float lh, lw; } orc_dsample;
+
+static orc_dsample orc_deform_pos(const float* offset, int n, int dg_n, int dgi, int R, int S, int P, int Q, int i,
+                                  int j, int p, int q, int stride, int pad, int dil, int H, int W, float* hh,
+                                  float* ww) {
+  orc_dsample s;
+  const int ch = ((n * dg_n + dgi) * R * S + i * S + j) * 2;
+  const float oh = offset ? offset[((size_t)ch * P + p) * Q + q] : 0.f;
+  const float ow = offset ? offset[((size_t)(ch + 1) * P + p) * Q + q] : 0.f;
+  const float h = (float)(p * stride - pad + i * dil) + oh;
+  const float w = (float)(q * stride - pad + j * dil) + ow;
+  s.ok = h > -1.f && w > -1.f && h < (float)H && w < (float)W;
+  s.h0 = (int)floorf(h);
+  s.w0 = (int)floorf(w);
+  s.lh = h - (float)s.h0;
+  s.lw = w - (float)s.w0;
+  *hh = h; *ww = w;
+  return s;
+}
+
+ORC_API void orc_deform_conv(const float* x, const float* offset, const float* wt, const float* dy, int N, int C,
+                             int H, int W, int K, int R, int S, int stride, int pad, int dil, int groups, int dg,
+                             int mode, float* y, float* dx, float* doffset, float* dw) {
+  const int P = (H + 2 * pad - dil * (R - 1) - 1) / stride + 1;
+  const int Q = (W + 2 * pad - dil * (S - 1) - 1) / stride + 1;
+  const int Cg = C / groups, Kg = K / groups, Cd = C / dg;
+  for (int n = 0; n < N; ++n)
+    for (int p = 0; p < P; ++p)
+      for (int q = 0; q < Q; ++q)
+        for (int c = 0; c < C; ++c) {
+          const int g = c / Cg, cl = c - g * Cg, dgi = c / Cd;
+          const float* im = x + ((size_t)n * C + c) * H * W;
+          for (int i = 0; i < R; ++i)
+            for (int j = 0; j < S; ++j) {
+              float h, w;
+              const orc_dsample s = orc_deform_pos(offset, n, dg, dgi, R, S, P, Q, i, j, p, q, stride, pad, dil, H,
+                                                   W, &h, &w);
+              float v1 = 0.f, v2 = 0.f, v3 = 0.f, v4 = 0.f, val = 0.f;
+              const int h1 = s.h0 + 1, w1 = s.w0 + 1;
+              const float hh = 1.f - s.lh, hw = 1.f - s.lw;
+              if (s.ok) {
+                if (s.h0 >= 0 && s.w0 >= 0) v1 = im[s.h0 * W + s.w0];
+                if (s.h0 >= 0 && w1 <= W - 1) v2 = im[s.h0 * W + w1];
+                if (h1 <= H - 1 && s.w0 >= 0) v3 = im[h1 * W + s.w0];
+                if (h1 <= H - 1 && w1 <= W - 1) v4 = im[h1 * W + w1];
+                val = hh * hw * v1 + hh * s.lw * v2 + s.lh * hw * v3 + s.lh * s.lw * v4;
+              }
+              double gcol = 0.0;
+              for (int kl = 0; kl < Kg; ++kl) {
+                const int k = g * Kg + kl;
+                const size_t wi = (((size_t)k * Cg + cl) * R + i) * S + j;
+                const size_t yi = (((size_t)n * K + k) * P + p) * Q + q;
+                if (mode == 0) {
+                  y[yi] += wt[wi] * val;
+                } else {
+                  y[yi] += wt[wi] * val;
+                  gcol += (double)wt[wi] * dy[yi];
+                  dw[wi] += dy[yi] * val;
+                }
+              }
+              if (mode == 1 && s.ok) {
+                const float gc = (float)gcol;
+                float* dim = dx + ((size_t)n * C + c) * H * W;
+                if (s.h0 >= 0 && s.w0 >= 0) dim[s.h0 * W + s.w0] += hh * hw * gc;
+                if (s.h0 >= 0 && w1 <= W - 1) dim[s.h0 * W + w1] += hh * s.lw * gc;
+                if (h1 <= H - 1 && s.w0 >= 0) dim[h1 * W + s.w0] += s.lh * hw * gc;
+                if (h1 <= H - 1 && w1 <= W - 1) dim[h1 * W + w1] += s.lh * s.lw * gc;
+                if (offset) {
+                  const int ch = ((n * dg + dgi) * R * S + i * S + j) * 2;
+                  /* get_coordinate_weight, bp_dir 0 (rows) and 1 (columns) */
+                  const float ch_w = -hw * v1 - s.lw * v2 + hw * v3 + s.lw * v4;
+                  const float cw_w = -hh * v1 + hh * v2 - s.lh * v3 + s.lh * v4;
+                  doffset[((size_t)ch * P + p) * Q + q] += ch_w * gc;
+                  doffset[((size_t)(ch + 1) * P + p) * Q + q] += cw_w * gc;
+                }
+              }
+            }
+        }
 }

@@ -71,6 +71,55 @@ def backbone(sd, x, layers=(3, 4, 6, 3)):
     return outs
 
 
+class _DeformConvCPU(torch.autograd.Function):
+    """pet/lib/ops/deform_conv.py:13-145 over the C oracle (orc_deform_conv)."""
+
+    @staticmethod
+    def forward(ctx, x, offset, w, stride, pad, dil, groups, dg):
+        ctx.cfg = (stride, pad, dil, groups, dg)
+        ctx.save_for_backward(x, offset, w)
+        return torch.from_numpy(O.deform_conv(x.detach().numpy(), offset.detach().numpy(), w.detach().numpy(),
+                                              stride, pad, dil, groups, dg))
+
+    @staticmethod
+    def backward(ctx, g):
+        x, offset, w = ctx.saved_tensors
+        stride, pad, dil, groups, dg = ctx.cfg
+        _, dx, doff, dw = O.deform_conv(x.detach().numpy(), offset.detach().numpy(), w.detach().numpy(), stride,
+                                        pad, dil, groups, dg, dy=g.contiguous().numpy())
+        return torch.from_numpy(dx), torch.from_numpy(doff), torch.from_numpy(dw), None, None, None, None, None
+
+
+def resnext_bottleneck(sd, p, x, stride, groups):
+    """Bottleneck.forward, pet/models/imagenet/resnext.py:61-83: stride on the grouped 3x3; that conv is a
+    DeformConvPack (deform_conv.py:500-512) when the block has a conv_offset child."""
+    out = F.relu(_aff(sd, p + ".bn1", F.conv2d(x, sd[p + ".conv1.weight"])))
+    if p + ".conv2.conv_offset.weight" in sd:
+        off = F.conv2d(out, sd[p + ".conv2.conv_offset.weight"], sd[p + ".conv2.conv_offset.bias"], stride, 1)
+        out = _DeformConvCPU.apply(out, off, sd[p + ".conv2.weight"], stride, 1, 1, groups, 1)
+    else:
+        out = F.conv2d(out, sd[p + ".conv2.weight"], None, stride, 1, 1, groups)
+    out = F.relu(_aff(sd, p + ".bn2", out))
+    out = _aff(sd, p + ".bn3", F.conv2d(out, sd[p + ".conv3.weight"]))
+    res = x
+    if p + ".downsample.0.weight" in sd:
+        res = _aff(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride))
+    return F.relu(out + res)
+
+
+def resnext_backbone(sd, x, layers=(3, 4, 23, 3), groups=64):
+    """ResNeXt.forward, pet/rcnn/modeling/backbone/ResNeXt.py:107-132."""
+    x = F.relu(_aff(sd, "Conv_Body.bn1", F.conv2d(x, sd["Conv_Body.conv1.weight"], None, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    outs = []
+    for li, n in enumerate(layers):
+        for b in range(n):
+            x = resnext_bottleneck(sd, "Conv_Body.layer%d.%d" % (li + 1, b), x, 2 if (b == 0 and li > 0) else 1,
+                                   groups)
+        outs.append(x)
+    return outs
+
+
 def fpn(sd, c):
     """fpn.forward, pet/rcnn/modeling/fpn/FPN.py:96-121."""
     P = "Conv_Body_FPN."

@@ -182,3 +182,26 @@ def grid_anchors(grid_hw, stride, cell):
     yy, xx = np.meshgrid(sy, sx, indexing="ij")
     shifts = np.stack([xx.ravel(), yy.ravel(), xx.ravel(), yy.ravel()], 1)
     return (shifts[:, None, :] + cell[None, :, :]).reshape(-1, 4)
+
+
+def deform_conv(x, offset, weight, stride=1, pad=1, dil=1, groups=1, deformable_groups=1, dy=None):
+    """Deformable conv v1 (NCHW).  Returns y, or (y, dx, doffset, dw) when dy is given.  offset may be None."""
+    x, weight = _f32(x), _f32(weight)
+    N, C, H, W = x.shape
+    K, _, R, S = weight.shape
+    P = (H + 2 * pad - dil * (R - 1) - 1) // stride + 1
+    Q = (W + 2 * pad - dil * (S - 1) - 1) // stride + 1
+    off = _f32(offset) if offset is not None else None
+    y = np.zeros((N, K, P, Q), np.float32)
+    null = ctypes.c_void_p(0)
+    if dy is None:
+        lib().orc_deform_conv(_p(x), _p(off) if off is not None else null, _p(weight), null, N, C, H, W, K, R, S,
+                              stride, pad, dil, groups, deformable_groups, 0, _p(y), null, null, null)
+        return y
+    dy = _f32(dy)
+    dx = np.zeros_like(x)
+    doff = np.zeros((N, deformable_groups * 2 * R * S, P, Q), np.float32)
+    dw = np.zeros_like(weight)
+    lib().orc_deform_conv(_p(x), _p(off) if off is not None else null, _p(weight), _p(dy), N, C, H, W, K, R, S,
+                          stride, pad, dil, groups, deformable_groups, 1, _p(y), _p(dx), _p(doff), _p(dw))
+    return y, dx, doff, dw

@@ -306,10 +306,27 @@ def gen_model(out, meta):
         out["m_grad::" + k] = gq.numpy().reshape(-1)[::max(1, gq.numel() // 4096)]
 
 
+def gen_x101_meta():
+    """State-dict ABI of BASELINE config #5 (X-101-64x4d-FPN + DCN): names, shapes, trainable set.  Structure only:
+    the reference's deformable conv is CUDA-only, so no forward can be run here."""
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/backbone/"
+             "e2e_grid_cascade@567_rcnn_X-101b-64x4d-FPN-DCN_2x.yaml").DEVICE = "cpu"
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True), merge=True)
+    meta = {"state_dict": [[k, list(v.shape)] for k, v in model.state_dict().items()],
+            "trainable": [k for k, p in model.named_parameters() if p.requires_grad]}
+    with open(os.path.join(HERE, "model_x101_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("x101:", len(meta["state_dict"]), "keys,", len(meta["trainable"]), "trainable")
+
+
 def main():
     ref_ext = build_ref()
     assert ref_ext is not None, "needs /root/reference"
     install_standins(ref_ext)
+    if sys.argv[1:] == ["x101"]:
+        return gen_x101_meta()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
     cfg.DEVICE = "cpu"
     ops = {}

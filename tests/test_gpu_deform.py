@@ -1,0 +1,157 @@
+"""GPU: deformable conv v1 / narrow-group conv (cpm_deform_* + the grouped 1x1 igemm) through the C-ABI vs the C
+oracle (orc_deform_conv, pinned in tests/test_deform_oracle.py) and the ResNeXt-DCN body vs oracle/cpu_model."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = [  # N, C, H, W, K, stride, pad, dil, groups, dg
+    (2, 8, 7, 9, 8, 1, 1, 1, 2, 1),
+    (1, 16, 10, 8, 32, 2, 1, 1, 4, 1),
+    (1, 8, 9, 9, 8, 1, 2, 2, 1, 2),
+    (2, 12, 6, 11, 6, 2, 1, 1, 3, 1),
+    (1, 256, 20, 28, 256, 1, 1, 1, 64, 1),      # X-101 layer1 shape class: 4 channels per group
+    (2, 512, 25, 21, 512, 2, 1, 1, 64, 1),      # layer2 block 0: stride 2, 8 per group
+    (1, 128, 13, 17, 128, 1, 1, 1, 4, 4),       # 32 per group (layer4 class), 4 deformable groups
+    (1, 100, 9, 10, 50, 1, 1, 1, 5, 2),         # channel counts that are not multiples of 64
+]
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def _cl(t):
+    return t.cuda().contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("with_offset", [True, False])
+def test_cols_conv_vs_oracle(oracle, case, with_offset):
+    import pet.lib.ops as ops
+    N, C, H, W, K, stride, pad, dil, groups, dg = case
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C // groups, 3, 3, generator=g) * (2.0 / (9 * C // groups)) ** 0.5
+    P = (H + 2 * pad - dil * 2 - 1) // stride + 1
+    Q = (W + 2 * pad - dil * 2 - 1) // stride + 1
+    off = (torch.rand(N, dg * 18, P, Q, generator=g) * 6 - 3) if with_offset else None
+    dy = torch.randn(N, K, P, Q, generator=g)
+    want = oracle.deform_conv(x.numpy(), None if off is None else off.numpy(), w.numpy(), stride, pad, dil, groups,
+                              dg, dy=dy.numpy())
+    xg, wg = _cl(x).requires_grad_(True), _cl(w).requires_grad_(True)
+    og = _cl(off).requires_grad_(True) if with_offset else None
+    y = ops.cols_conv(xg, og, wg, None, None, stride, pad, dil, groups, dg)
+    y.backward(_cl(dy))
+    assert _rel(y.detach().cpu().numpy(), want[0]) < TOL
+    assert _rel(xg.grad.cpu().numpy(), want[1]) < TOL
+    assert _rel(wg.grad.cpu().numpy(), want[3]) < TOL
+    if with_offset:
+        assert _rel(og.grad.cpu().numpy(), want[2]) < 5 * TOL
+
+
+def test_zero_offset_equals_grouped_conv_kernel():
+    """Known answer inside the HIP path: zero offsets through the sampler == the implicit-GEMM grouped conv."""
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(4)
+    x = _cl(torch.randn(2, 128, 19, 23, generator=g))
+    w = _cl(torch.randn(128, 32, 3, 3, generator=g) * 0.05)
+    off = _cl(torch.zeros(2, 18, 10, 12))
+    a = ops.cols_conv(x, off, w, None, None, 2, 1, 1, 4, 1)
+    b = ops.conv2d(x, w, None, None, None, 2, 1, 1, 4)
+    c = ops.cols_conv(x, None, w, None, None, 2, 1, 1, 4, 1)
+    assert _rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+    assert torch.equal(a, c)
+
+
+def test_deform_conv_pack_module_fused_epilogue():
+    """DeformConvPack (offset predictor + sampler + affine + ReLU) vs torch-CPU conv_offset + the oracle."""
+    import pet.lib.ops as ops
+    from oracle import pyoracle as O
+    torch.manual_seed(5)
+    m = ops.DeformConvPack(64, 64, 3, stride=2, padding=1, groups=16, bias=False)
+    assert float(m.conv_offset.weight.detach().abs().max()) == 0          # deform_conv.py:496-497
+    with torch.no_grad():
+        m.conv_offset.weight.normal_(0, 0.05)
+        m.conv_offset.bias.normal_(0, 0.5)
+    x = torch.randn(2, 64, 15, 18)
+    scale, shift = torch.rand(64) + 0.5, torch.randn(64) * 0.1
+    off = TF.conv2d(x, m.conv_offset.weight.detach(), m.conv_offset.bias.detach(), 2, 1)
+    want = O.deform_conv(x.numpy(), off.numpy(), m.weight.detach().numpy(), 2, 1, 1, 16, 1)
+    want = np.maximum(want * scale.view(1, -1, 1, 1).numpy() + shift.view(1, -1, 1, 1).numpy(), 0)
+    mg = m.cuda().to(memory_format=torch.channels_last)
+    y = mg(_cl(x), scale=scale.cuda(), shift=shift.cuda(), relu=True)
+    assert _rel(y.detach().cpu().numpy(), want) < 5e-4                      # offsets themselves carry 1e-6 noise
+    y.sum().backward()
+    for p in (mg.weight, mg.conv_offset.weight, mg.conv_offset.bias):
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()) and float(p.grad.abs().max()) > 0
+    with pytest.raises(RuntimeError):
+        ops.deform_conv(x, off, m.weight.detach().cpu())                    # CPU tensors are refused
+    with pytest.raises(RuntimeError):
+        ops.deform_conv(_cl(x), _cl(off[:, :16]), mg.weight)                # wrong offset channel count
+
+
+def test_narrow_group_conv2d_module_vs_torch():
+    """ops.Conv2d with 4 channels per group (ResNeXt 64x4d layer1) takes the column path; values + grads."""
+    import pet.lib.ops as ops
+    torch.manual_seed(6)
+    m = ops.Conv2d(256, 256, 3, 1, 1, groups=64, bias=False)
+    x = torch.randn(1, 256, 14, 22, requires_grad=True)
+    y = TF.conv2d(x, m.weight, None, 1, 1, 1, 64)
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    want_dw, want_dx = m.weight.grad.clone(), x.grad.clone()
+    m.zero_grad()
+    mg = m.cuda().to(memory_format=torch.channels_last)
+    xg = _cl(x.detach()).requires_grad_(True)
+    yg = mg(xg)
+    yg.backward(_cl(dy))
+    assert _rel(yg.detach().cpu().numpy(), y.detach().numpy()) < TOL
+    assert _rel(xg.grad.cpu().numpy(), want_dx.numpy()) < TOL
+    assert _rel(mg.weight.grad.cpu().numpy(), want_dw.numpy()) < TOL
+
+
+X_OPTS = ["BACKBONE.CONV_BODY", "resnext", "BACKBONE.RESNEXT.LAYERS", (3, 4, 6, 3),
+          "BACKBONE.RESNEXT.STAGE_WITH_CONV", ("normal", "deform", "deform", "deform"), "BACKBONE.RESNEXT.C", 64,
+          "BACKBONE.RESNEXT.WIDTH", 4, "GRID_RCNN.MAX_SAMPLE_NUM_GRID", 32]
+
+
+def test_resnext_dcn_body_vs_cpu_oracle():
+    """X-50-64x4d + DCN body (the X-101 block types at a depth the CPU oracle finishes quickly): C2..C5 and FPN
+    features vs oracle/cpu_model.resnext_backbone on the same name-seeded weights, with non-zero offsets."""
+    from test_host_logic import CPM_OPTS
+    from detfill import det_fill_
+    from oracle import cpu_model as M
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS + X_OPTS)
+    try:
+        model = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+        det_fill_(model)
+        sd = {k: v.detach().float().clone() for k, v in model.state_dict().items()}
+        model = model.cuda().to(memory_format=torch.channels_last)
+        rng = np.random.default_rng(7)
+        img = torch.from_numpy(rng.uniform(-100, 150, (1, 3, 96, 128)).astype(np.float32))
+        with torch.no_grad():
+            got_c = model.Conv_Body(_cl(img))
+            got_p = model.Conv_Body_FPN(got_c)
+            ref_c = M.resnext_backbone(sd, img, (3, 4, 6, 3), 64)
+            ref_p = M.fpn(sd, ref_c)
+        offs = [k for k in sd if k.endswith("conv_offset.weight")]
+        assert len(offs) == 13 and all(float(sd[k].abs().max()) > 0 for k in offs)
+        for a, b in zip(list(got_c) + list(got_p), ref_c + ref_p):
+            assert _rel(a.cpu().numpy(), b.numpy()) < 1e-3
+        # one backward through the trainable stages: every trainable tensor gets a finite gradient
+        model.train()
+        feats = model.Conv_Body_FPN(model.Conv_Body(_cl(img)))
+        sum(f.square().mean() for f in feats).backward()
+        for k, p in model.Conv_Body.named_parameters():
+            if p.requires_grad:
+                assert p.grad is not None and bool(torch.isfinite(p.grad).all()), k
+    finally:
+        config.reset_cfg()

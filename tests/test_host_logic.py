@@ -162,3 +162,30 @@ def test_model_state_dict_abi(cpm_cfg):
     assert [k for k, p in model.named_parameters() if p.requires_grad] == meta["trainable"]
     n = sum(p.numel() for p in model.parameters())
     assert abs(n - 153.89e6) < 0.02e6
+
+
+X101_OPTS = ["BACKBONE.CONV_BODY", "resnext", "BACKBONE.RESNEXT.LAYERS", (3, 4, 23, 3),
+             "BACKBONE.RESNEXT.STAGE_WITH_CONV", ("normal", "deform", "deform", "deform"), "BACKBONE.RESNEXT.C", 64,
+             "BACKBONE.RESNEXT.WIDTH", 4, "GRID_RCNN.MAX_SAMPLE_NUM_GRID", 32]
+
+
+def test_x101_dcn_state_dict_abi(cpm_cfg):
+    """BASELINE config #5 (X-101-64x4d-FPN + DCN): the module tree, every key / shape (incl. the
+    `conv2.conv_offset.{weight,bias}` children of DeformConvPack) and the trainable set equal the reference's
+    (tests/golden/model_x101_meta.json, dumped from the reference model by make_golden.py x101)."""
+    import json
+    from conftest import ROOT
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    import pet.lib.ops as ops
+    config.merge_cfg_from_list(X101_OPTS)
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_x101_meta.json")))
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+    got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+    assert got == meta["state_dict"]
+    assert [k for k, p in model.named_parameters() if p.requires_grad] == meta["trainable"]
+    packs = [m for m in model.modules() if isinstance(m, ops.DeformConvPack)]
+    assert len(packs) == 4 + 23 + 3
+    assert all(float(m.conv_offset.weight.detach().abs().max()) == 0 and float(m.conv_offset.bias.detach().abs().max()) == 0
+               for m in packs)                                    # resnext.py:248-252
