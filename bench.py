@@ -42,6 +42,12 @@ CPM_R50_OPTS = [  # cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_ca
     "TEST.SCALE", 800, "TEST.MAX_SIZE", 1333,
 ]
 
+X101_DCN_OPTS = [  # .../rescore/backbone/e2e_grid_cascade@567_rcnn_X-101b-64x4d-FPN-DCN_2x.yaml (BASELINE config #5)
+    "BACKBONE.CONV_BODY", "resnext", "BACKBONE.RESNEXT.LAYERS", (3, 4, 23, 3),
+    "BACKBONE.RESNEXT.STAGE_WITH_CONV", ("normal", "deform", "deform", "deform"), "BACKBONE.RESNEXT.C", 64,
+    "BACKBONE.RESNEXT.WIDTH", 4, "GRID_RCNN.MAX_SAMPLE_NUM_GRID", 32,
+]
+
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 
 
@@ -79,12 +85,13 @@ def calibrate_frozen_affine(model, images):
     import pet.lib.ops as ops
 
     def fit(conv, aff, x, relu, residual=None):
-        raw = ops.conv2d(x, conv.weight, None, None, None, conv.stride[0], conv.padding[0], conv.dilation[0], conv.groups)
+        raw = conv(x)                                  # the module's own kernel path (plain / grouped / deformable)
         mean = raw.mean(dim=(0, 2, 3))
         std = raw.var(dim=(0, 2, 3), unbiased=False).add(1e-5).sqrt()
         aff.weight.data.copy_(1.0 / std)
         aff.bias.data.copy_(-mean / std)
-        return conv(x, scale=aff.weight, shift=aff.bias, residual=residual, relu=relu)
+        kw = {} if residual is None else {"residual": residual}
+        return conv(x, scale=aff.weight, shift=aff.bias, relu=relu, **kw)
 
     body = model.Conv_Body
     x = images.contiguous(memory_format=torch.channels_last)
@@ -103,7 +110,7 @@ def calibrate_frozen_affine(model, images):
 class Trainer(object):
     """The reference's loop body (tools/rcnn/train_net.py:62-78) over the HIP model."""
 
-    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3)):
+    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3), body="resnet"):
         from pet.rcnn.core import config
         from pet.rcnn.modeling.model_builder import Generalized_RCNN
         from pet.utils.lr_scheduler import LearningRateScheduler
@@ -112,7 +119,10 @@ class Trainer(object):
         from pet.utils.parallel import FlatGradReducer
         config.reset_cfg()
         config.merge_cfg_from_list(CPM_R50_OPTS)
-        config.merge_cfg_from_list(["BACKBONE.RESNET.LAYERS", tuple(layers)])
+        if body == "x101dcn":
+            config.merge_cfg_from_list(X101_DCN_OPTS)
+        else:
+            config.merge_cfg_from_list(["BACKBONE.RESNET.LAYERS", tuple(layers)])
         self.cfg = config.cfg
         torch.manual_seed(seed_weights)                       # identical weights on every rank
         model = Generalized_RCNN(is_train=True)
@@ -170,7 +180,7 @@ def conv_roofline(trainer, images, targets, steps=2):
             "all_conv_kernels": {"ms_per_step": round(allms, 3), "tflops": round(allgf / allms, 2) if allms else 0.0}}
 
 
-def cpu_baseline(trainer, h, w, seed):
+def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3)):
     """oracle/cpu_model.py on the host cores: forward+backward conv/FC/RoIAlign work of one training iteration
     for ONE image (bounded sample), RoI counts = this run's per-image averages."""
     from oracle import cpu_model as M
@@ -197,13 +207,16 @@ def cpu_baseline(trainer, h, w, seed):
     per_img = {k: v / 2 for k, v in counts.items()}
     args = (rois(per_img.get("cls", 512)), [rois(per_img.get("grid_%d" % s, 16)) for s in range(3)],
             rois(per_img.get("rescore", 512)))
-    t0 = time.time()
-    M.train_step_compute(sd, img, *args)
-    dt = time.time() - t0
+    M.train_step_compute(sd, img, *args, layers=layers)             # untimed warm-up (allocator, oneDNN primitives)
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < 12.0 and n < 12):
+        M.train_step_compute(sd, img, *args, layers=layers)
+        n += 1
+    dt = (time.time() - t0) / n
     return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "1 image (bs=1) forward+backward of the conv/FC/RoIAlign stacks, RoIs per image: %s; "
-                      "torch-CPU fp32 convs + C-oracle RoIAlign; one un-warmed step, %.1f s"
-                      % ({k: int(v) for k, v in per_img.items()}, dt)}
+            "sample": "%d timed iterations (after 1 warm-up) of 1 image (bs=1): forward+backward of the "
+                      "conv/FC/RoIAlign stacks, RoIs per image: %s; torch-CPU fp32 convs + C-oracle RoIAlign; "
+                      "%.2f s per iteration" % (n, {k: int(v) for k, v in per_img.items()}, dt)}
 
 
 def main():
@@ -217,6 +230,9 @@ def main():
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--batch", type=int, default=2, help="images per GPU")
     ap.add_argument("--layers", type=str, default="3,4,6,3", help="ResNet depth: 3,4,6,3 (R-50) / 3,4,23,3 (R-101)")
+    ap.add_argument("--body", default="resnet", choices=["resnet", "x101dcn"],
+                    help="resnet (--layers picks R-50 / R-101) or x101dcn = X-101-64x4d + DCN, BASELINE config #5 "
+                         "(bs=1/GPU in the reference)")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
                     "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
@@ -238,7 +254,7 @@ def main():
     import __graft_entry__ as entry
     entry.ensure_built()
     layers = tuple(int(x) for x in a.layers.split(","))
-    trainer = Trainer(device, layers=layers)
+    trainer = Trainer(device, layers=layers, body=a.body)
     images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
     cal_img, _ = synthetic_batch(a.batch, a.height, a.width, 1, 4321, device)     # same on every rank
     calibrate_frozen_affine(trainer.model, cal_img.tensors)
@@ -274,14 +290,17 @@ def main():
         roof = conv_roofline(trainer, images, targets)
     if world > 1:
         dist.barrier()
-    if not a.no_cpu_baseline and rank == 0 and world == 1:
-        cpu = cpu_baseline(trainer, a.height, a.width, 99)
+    if not a.no_cpu_baseline and rank == 0 and world == 1 and a.body == "resnet":
+        cpu = cpu_baseline(trainer, a.height, a.width, 99, layers)   # (the scalar deformable-conv oracle is too
+        #                                                              slow to be a bounded sample for x101dcn)
 
     if rank == 0:
         n_img = a.batch * world * a.steps
         model_name = {(3, 4, 6, 3): "R-50-FPN", (3, 4, 23, 3): "R-101-FPN"}.get(layers, "R-%s-FPN" % a.layers)
+        if a.body == "x101dcn":
+            model_name = "X-101-64x4d-FPN-DCN"
         line = {
-            "metric": "img/sec training (R-50-FPN CPM, bs=2/GPU)", "value": round(n_img / elapsed, 3),
+            "metric": "img/sec training (%s CPM, bs=%d/GPU)" % (model_name, a.batch), "value": round(n_img / elapsed, 3),
             "unit": "img/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(1000.0 * elapsed / a.steps, 2), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",

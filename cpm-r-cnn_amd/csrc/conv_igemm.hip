@@ -634,7 +634,20 @@ Plan plan_igemm(const IgemmArgs& a) {
   static const int big_waves = env_int("CPM_IGEMM_BIG_WAVES", 4);      // 4: 2x2 waves, 8: 2x4 waves on 128x128
   Plan p;
   p.wm = 2; p.wn = 2; p.split = 1;
-  if (a.OCg <= 32) { p.bm = 128; p.bn = 32; p.wm = 4; p.wn = 1; return p; }
+  if (a.OCg <= 32) {
+    // narrow outputs (RPN heads, DCN offset predictors, grouped columns): 128x32 tile, 3 workgroups per CU (LDS).
+    // A thin grid with a long reduction (1024->18 3x3 on a stride-16 map: 33 tiles x 288 k-steps) splits the
+    // reduction until the chip is ~3 workgroups per CU deep, keeping >= 8 k-steps per workgroup.
+    p.bm = 128; p.bn = 32; p.wm = 4; p.wn = 1;
+    const int64_t t = tiles(128, 32), want = 3ll * num_cus();
+    if (t < want && a.ksteps >= 32) {
+      int64_t sp = (want + t - 1) / t;
+      if (sp > a.ksteps / 8) sp = a.ksteps / 8;
+      if (sp > 64) sp = 64;
+      if (sp > 1) p.split = (int)sp;
+    }
+    return p;
+  }
   if (const char* f = getenv("CPM_IGEMM_FORCE")) {          // experiments: "bm,bn,split"
     int bm, bn, sp;
     if (sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3) {
