@@ -1,0 +1,251 @@
+// Detection "glue" of the CPM training step as fused device kernels: RoI<->gt matching, the grid
+// heat-map loss with its targets rasterised on the fly, and the heat-map -> box decoder.  Each replaces a chain of
+// 25..60 small framework launches per image and stage in the reference (and its .cpu()/.cuda() round trips) with
+// ONE launch over all images of the batch.  HBM/latency-bound integer and index work: no MFMA here.
+//
+// Built with -ffp-contract=off: every threshold comparison and truncation below must see the same fp32 values
+// as the reference's op-by-op tensor arithmetic.
+//
+//   match   pet/utils/data/structures/boxlist_ops.py:123-158 (IoU, "+1" widths) + pet/rcnn/utils/matcher.py:48-111
+//   loss    pet/rcnn/modeling/grid_cascade_rcnn/loss.py:178-258 (targets) + :260-262 (BCE with logits, mean)
+//   decode  pet/rcnn/modeling/grid_cascade_rcnn/inference.py:189-279 (get_boxes), :281-290 (_filter_boxes)
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_POINTS = 16;
+
+__device__ __forceinline__ float iou_plus1(const float4 g, const float4 p) {
+  // box_iou_plus1(gt, prediction): the gt is "box1"
+  const float area1 = (g.z - g.x + 1.f) * (g.w - g.y + 1.f);
+  const float area2 = (p.z - p.x + 1.f) * (p.w - p.y + 1.f);
+  const float ltx = fmaxf(g.x, p.x), lty = fmaxf(g.y, p.y);
+  const float rbx = fminf(g.z, p.z), rby = fminf(g.w, p.w);
+  const float w = fmaxf(rbx - ltx + 1.f, 0.f), h = fmaxf(rby - lty + 1.f, 0.f);
+  const float inter = w * h;
+  return inter / (area1 + area2 - inter);
+}
+
+// per-gt maximum IoU over all predictions of its image (Matcher.set_low_quality_matches_, matcher.py:91-93);
+// IoU >= 0, so the int view of the float orders like the float
+__global__ __launch_bounds__(256) void match_rowmax_kernel(const float4* __restrict__ rois,
+                                                           const int* __restrict__ roi_img,
+                                                           const float4* __restrict__ gts,
+                                                           const int* __restrict__ gt_off, int R,
+                                                           int* __restrict__ row_max) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  const int img = roi_img ? roi_img[i] : 0;
+  const float4 p = rois[i];
+  for (int g = gt_off[img]; g < gt_off[img + 1]; ++g) {
+    const float v = iou_plus1(gts[g], p);
+    if (v > 0.f) atomicMax(row_max + g, __float_as_int(v));
+  }
+}
+
+__global__ __launch_bounds__(256) void match_kernel(const float4* __restrict__ rois, const int* __restrict__ roi_img,
+                                                    const float4* __restrict__ gts, const int* __restrict__ gt_off,
+                                                    int R, float high, float low, const int* __restrict__ row_max,
+                                                    int64_t* __restrict__ matched, float* __restrict__ max_iou) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= R) return;
+  const int img = roi_img ? roi_img[i] : 0;
+  const float4 p = rois[i];
+  const int g0 = gt_off[img], g1 = gt_off[img + 1];
+  float best = -1.f;
+  int arg = 0;
+  bool tied = false;
+  for (int g = g0; g < g1; ++g) {
+    const float v = iou_plus1(gts[g], p);
+    if (v > best) { best = v; arg = g - g0; }                  // first maximum wins
+    if (row_max && v == __int_as_float(row_max[g])) tied = true;
+  }
+  int64_t m = arg;
+  if (best < low) m = -1;                                       // BELOW_LOW_THRESHOLD
+  else if (best < high) m = -2;                                 // BETWEEN_THRESHOLDS
+  if (tied) m = arg;                                            // low-quality match restored
+  matched[i] = m;
+  if (max_iou) max_iou[i] = best;
+}
+
+struct GridGeom {
+  int P, gs, map, half;             // points, sqrt(points), whole map (56), sub-region side (28)
+  int sub_x[MAX_POINTS], sub_y[MAX_POINTS];
+  float fx[MAX_POINTS], fy[MAX_POINTS];
+  long sR, sC, sH, sW;              // element strides of the logits tensor [R, P, half, half]
+};
+
+// one wave per (RoI, point): BCE-with-logits against the point's rasterised target, summed into *loss_sum
+// (already divided by the element count and multiplied by `weight`), gradient written alongside
+__global__ __launch_bounds__(64) void grid_bce_kernel(const float* __restrict__ logits,
+                                                      const float4* __restrict__ rois,
+                                                      const float4* __restrict__ gt, GridGeom G, float ratio,
+                                                      int radius, float scale, float* __restrict__ loss_sum,
+                                                      float* __restrict__ grad) {
+  const int r = blockIdx.x / G.P, j = blockIdx.x - r * G.P;
+  const int lane = threadIdx.x;
+  const float4 b = rois[r], g = gt[r];
+  const float x1 = b.x - ratio * ((b.z - b.x) / 2.f), y1 = b.y - ratio * ((b.w - b.y) / 2.f);
+  const float x2 = b.z + ratio * ((b.z - b.x) / 2.f), y2 = b.w + ratio * ((b.w - b.y) / 2.f);
+  const float bw = x2 - x1, bh = y2 - y1;
+  const bool ok = !(bw <= (float)G.gs || bh <= (float)G.gs);                    // "ignore small bboxes"
+  int cx = 0, cy = 0;
+  if (ok) {
+    const float fx = G.fx[j], fy = G.fy[j];
+    const float gx = fx * g.x + (1.f - fx) * g.z, gy = fy * g.y + (1.f - fy) * g.w;
+    cx = (int)((gx - x1) / bw * (float)G.map);                                  // python int(): toward zero
+    cy = (int)((gy - y1) / bh * (float)G.map);
+  }
+  const float* src = logits + r * G.sR + j * G.sC;
+  float* dst = grad + r * G.sR + j * G.sC;
+  float acc = 0.f;
+  const int n = G.half * G.half;
+  for (int k = lane; k < n; k += 64) {
+    const int row = k / G.half, col = k - row * G.half;
+    const int dx = col + G.sub_x[j] - cx, dy = row + G.sub_y[j] - cy;
+    const float t = (ok && dx * dx + dy * dy <= radius * radius) ? 1.f : 0.f;
+    const long off = row * G.sH + col * G.sW;
+    const float x = src[off];
+    const float e = expf(-fabsf(x));
+    // (1 - t) * x - log_sigmoid(x),  log_sigmoid(x) = min(x, 0) - log1p(exp(-|x|))
+    acc += (1.f - t) * x - (fminf(x, 0.f) - log1pf(e));
+    const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    dst[off] = (sig - t) * scale;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) atomicAdd(loss_sum, acc * scale);
+}
+
+// one workgroup per RoI, one wave per point: first arg-max of sigmoid(logit) in the point's window, then the
+// score-weighted vote of the gs points on each box side; optional "coincides with a gt coordinate" filter
+__global__ __launch_bounds__(64 * MAX_POINTS) void grid_decode_kernel(
+    const float* __restrict__ logits, const float4* __restrict__ rois, GridGeom G, float ratio,
+    const int* __restrict__ roi_img, const float4* __restrict__ gts, const int* __restrict__ gt_off,
+    float4* __restrict__ out, unsigned char* __restrict__ keep) {
+  __shared__ float s_score[MAX_POINTS], s_ax[MAX_POINTS], s_ay[MAX_POINTS];
+  const int r = blockIdx.x, j = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const float4 b = rois[r];
+  const float wdt = b.z - b.x, hgt = b.w - b.y;
+  const float x1 = b.x - ratio * (wdt / 2.f), y1 = b.y - ratio * (hgt / 2.f);
+  if (j < G.P) {
+    const float* src = logits + r * G.sR + j * G.sC;
+    const int n = G.half * G.half;
+    float best = -1.f;
+    int bi = n;
+    for (int k = lane; k < n; k += 64) {
+      const int row = k / G.half, col = k - row * G.half;
+      const float x = src[row * G.sH + col * G.sW];
+      const float p = 1.f / (1.f + expf(-x));
+      if (p > best) { best = p; bi = k; }                        // ascending k per lane: first maximum
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) {
+      const int xs = bi % G.half + G.sub_x[j], ys = bi / G.half + G.sub_y[j];
+      s_score[j] = best;
+      s_ax[j] = ((float)xs + 0.5f) / (float)(2 * G.half) * (1.f + ratio) * wdt + x1;
+      s_ay[j] = ((float)ys + 0.5f) / (float)(2 * G.half) * (1.f + ratio) * hgt + y1;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float nx1 = 0, dx1 = 0, ny1 = 0, dy1 = 0, nx2 = 0, dx2 = 0, ny2 = 0, dy2 = 0;
+    for (int k = 0; k < G.gs; ++k) {
+      const int ix1 = k, iy1 = k * G.gs, ix2 = G.P - G.gs + k, iy2 = (k + 1) * G.gs - 1;
+      nx1 += s_ax[ix1] * s_score[ix1]; dx1 += s_score[ix1];
+      ny1 += s_ay[iy1] * s_score[iy1]; dy1 += s_score[iy1];
+      nx2 += s_ax[ix2] * s_score[ix2]; dx2 += s_score[ix2];
+      ny2 += s_ay[iy2] * s_score[iy2]; dy2 += s_score[iy2];
+    }
+    out[r] = make_float4(nx1 / dx1, ny1 / dy1, nx2 / dx2, ny2 / dy2);
+    if (keep) {
+      // inference.py:281-290: a coordinate equal to the same coordinate of ANY gt of the image becomes -1; the RoI
+      // survives while ((c0 + c1) + c2) + c3 > 0
+      const int img = roi_img ? roi_img[r] : 0;
+      float c0 = b.x, c1 = b.y, c2 = b.z, c3 = b.w;
+      for (int g = gt_off[img]; g < gt_off[img + 1]; ++g) {
+        const float4 t = gts[g];
+        if (b.x == t.x) c0 = -1.f;
+        if (b.y == t.y) c1 = -1.f;
+        if (b.z == t.z) c2 = -1.f;
+        if (b.w == t.w) c3 = -1.f;
+      }
+      keep[r] = (((c0 + c1) + c2) + c3 > 0.f) ? 1 : 0;
+    }
+  }
+}
+
+int fill_geom(GridGeom& G, int points, int map_size, const int* sub_xy, const int64_t* strides) {
+  if (points <= 0 || points > MAX_POINTS) return -1;
+  int gs = 1;
+  while (gs * gs < points) ++gs;
+  if (gs * gs != points || gs < 2) return -1;
+  G.P = points; G.gs = gs; G.map = map_size; G.half = map_size / 4 * 2;
+  for (int j = 0; j < points; ++j) {
+    G.sub_x[j] = sub_xy[2 * j];
+    G.sub_y[j] = sub_xy[2 * j + 1];
+    if (G.sub_x[j] < 0 || G.sub_y[j] < 0 || G.sub_x[j] + G.half > map_size || G.sub_y[j] + G.half > map_size) return -1;
+    G.fx[j] = (float)(1.0 - (double)(j / gs) / (gs - 1));       // loss.py:205-209
+    G.fy[j] = (float)(1.0 - (double)(j % gs) / (gs - 1));
+  }
+  G.sR = strides[0]; G.sC = strides[1]; G.sH = strides[2]; G.sW = strides[3];
+  return 0;
+}
+
+}  // namespace
+
+CPM_EXPORT int cpm_match_rois(const float* rois, const int* roi_img, const float* gts, const int* gt_off, int R,
+                              int num_gts, float high, float low, int allow_low_quality, int* row_max_ws,
+                              int64_t* matched, float* max_iou, void* stream) {
+  CPM_REQUIRE(R >= 0 && num_gts >= 0, "negative size");
+  if (R == 0) return CPM_OK;
+  CPM_REQUIRE(rois && gts && gt_off && matched, "null pointer");
+  CPM_REQUIRE((((uintptr_t)rois | (uintptr_t)gts) & 15) == 0, "boxes must be 16-byte aligned");
+  CPM_REQUIRE(!allow_low_quality || row_max_ws, "low-quality matching needs a [num_gts] int workspace");
+  hipStream_t s = (hipStream_t)stream;
+  const unsigned blocks = (unsigned)((R + 255) / 256);
+  if (allow_low_quality) {
+    if (hipMemsetAsync(row_max_ws, 0, sizeof(int) * (size_t)(num_gts > 0 ? num_gts : 1), s) != hipSuccess)
+      return CPM_ELAUNCH;
+    hipLaunchKernelGGL(match_rowmax_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)rois, roi_img,
+                       (const float4*)gts, gt_off, R, row_max_ws);
+  }
+  hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)rois, roi_img, (const float4*)gts,
+                     gt_off, R, high, low, allow_low_quality ? row_max_ws : nullptr, matched, max_iou);
+  return cpm::check_launch("match_rois");
+}
+
+CPM_EXPORT int cpm_grid_bce_loss(const float* logits, const int64_t* strides, const float* rois, const float* gt_boxes,
+                                 int R, int points, int map_size, const int* sub_xy, float mapping_ratio, int radius,
+                                 float weight, float* loss_sum, float* grad, void* stream) {
+  CPM_REQUIRE(R >= 0, "negative size");
+  if (R == 0) return CPM_OK;
+  CPM_REQUIRE(logits && strides && rois && gt_boxes && sub_xy && loss_sum && grad, "null pointer");
+  CPM_REQUIRE((((uintptr_t)rois | (uintptr_t)gt_boxes) & 15) == 0, "boxes must be 16-byte aligned");
+  GridGeom G;
+  CPM_REQUIRE(fill_geom(G, points, map_size, sub_xy, strides) == 0, "bad grid geometry");
+  const float scale = weight / ((float)R * (float)points * (float)(G.half * G.half));
+  hipLaunchKernelGGL(grid_bce_kernel, dim3((unsigned)(R * points)), dim3(64), 0, (hipStream_t)stream, logits,
+                     (const float4*)rois, (const float4*)gt_boxes, G, mapping_ratio, radius, scale, loss_sum, grad);
+  return cpm::check_launch("grid_bce_loss");
+}
+
+CPM_EXPORT int cpm_grid_decode(const float* logits, const int64_t* strides, const float* rois, int R, int points,
+                               int map_size, const int* sub_xy, float mapping_ratio, const int* roi_img,
+                               const float* gts, const int* gt_off, float* out_boxes, unsigned char* keep,
+                               void* stream) {
+  CPM_REQUIRE(R >= 0, "negative size");
+  if (R == 0) return CPM_OK;
+  CPM_REQUIRE(logits && strides && rois && sub_xy && out_boxes, "null pointer");
+  CPM_REQUIRE(!keep || (gts && gt_off), "the gt filter needs gts and their per-image offsets");
+  CPM_REQUIRE((((uintptr_t)rois | (uintptr_t)out_boxes | (uintptr_t)gts) & 15) == 0, "boxes must be 16-byte aligned");
+  GridGeom G;
+  CPM_REQUIRE(fill_geom(G, points, map_size, sub_xy, strides) == 0, "bad grid geometry");
+  hipLaunchKernelGGL(grid_decode_kernel, dim3((unsigned)R), dim3(64 * points), 0, (hipStream_t)stream, logits,
+                     (const float4*)rois, G, mapping_ratio, roi_img, (const float4*)gts, gt_off, (float4*)out_boxes,
+                     keep);
+  return cpm::check_launch("grid_decode");
+}

@@ -1,0 +1,113 @@
+"""Fused device kernels for the detection glue of the training step: RoI<->gt matching over all images
+of the batch, the grid heat-map loss with on-the-fly targets, and the heat-map -> box decoder.  Host wrappers of
+cpm_match_rois / cpm_grid_bce_loss / cpm_grid_decode (include/cpmrcnn_hip.h); the reference's per-image tensor-op
+formulations they replace stay available next to them (pet/rcnn/utils/matcher.py,
+grid_cascade_rcnn/{loss,inference}.py) and the GPU tests hold the two against each other."""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _hip as H
+
+
+def _boxes(t):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.shape[1] != 4:
+        raise RuntimeError("boxes must be float32 [R, 4]")
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _i32(t):
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+def match_rois(rois, roi_img, gts, gt_off, high, low, allow_low_quality=False):
+    """rois [R,4]; roi_img [R] int32 image index per RoI (None = one image); gts [G,4] concatenated over images with
+    gt_off [N+1] int32 (device).  Returns (matched int64 [R]: gt index within the RoI's image / -1 / -2, max IoU)."""
+    H.require_gpu(rois, gts)
+    rois, gts = _boxes(rois), _boxes(gts)
+    R, G = rois.shape[0], gts.shape[0]
+    if G == 0:
+        raise ValueError("No ground-truth boxes available for one of the images during training")
+    matched = torch.empty((R,), dtype=torch.int64, device=rois.device)
+    max_iou = torch.empty((R,), dtype=torch.float32, device=rois.device)
+    ws = torch.empty((G,), dtype=torch.int32, device=rois.device) if allow_low_quality else None
+    roi_img = _i32(roi_img) if roi_img is not None else None
+    gt_off = _i32(gt_off)
+    with torch.cuda.device(rois.device):
+        rc = H.lib().cpm_match_rois(H.ptr(rois), H.ptr(roi_img), H.ptr(gts), H.ptr(gt_off), R, G, H.f(high),
+                                    H.f(low), int(bool(allow_low_quality)), H.ptr(ws), H.ptr(matched),
+                                    H.ptr(max_iou), H.stream())
+    H.check(rc, "match_rois")
+    return matched, max_iou
+
+
+def _geom_args(logits, sub_regions):
+    if logits.dim() != 4 or logits.dtype != torch.float32:
+        raise RuntimeError("grid logits must be float32 [R, P, h, w]")
+    strides = (ctypes.c_int64 * 4)(*logits.stride())
+    pts = logits.shape[1]
+    sub = (ctypes.c_int * (2 * pts))(*[int(v) for s in sub_regions for v in s[:2]])
+    return strides, sub, pts
+
+
+class _GridBCEFn(Function):
+    @staticmethod
+    def forward(ctx, logits, rois, gt_boxes, map_size, sub_regions, ratio, radius, weight):
+        H.require_gpu(logits, rois, gt_boxes)
+        rois, gt_boxes = _boxes(rois), _boxes(gt_boxes)
+        R = logits.shape[0]
+        if rois.shape[0] != R or gt_boxes.shape[0] != R or logits.shape[2] != map_size // 4 * 2:
+            raise RuntimeError("grid loss: %d logits maps, %d rois, %d gts" % (R, rois.shape[0], gt_boxes.shape[0]))
+        strides, sub, pts = _geom_args(logits, sub_regions)
+        loss = torch.zeros((), dtype=torch.float32, device=logits.device)
+        grad = torch.empty_like(logits)                      # preserve_format: same strides as the logits
+        assert grad.stride() == logits.stride()
+        with torch.cuda.device(logits.device):
+            rc = H.lib().cpm_grid_bce_loss(H.ptr(logits), strides, H.ptr(rois), H.ptr(gt_boxes), R, pts,
+                                           int(map_size), sub, H.f(ratio), int(radius), H.f(weight), H.ptr(loss),
+                                           H.ptr(grad), H.stream())
+        H.check(rc, "grid_bce_loss")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None, None
+
+
+def grid_bce_loss(logits, rois, gt_boxes, map_size, sub_regions, mapping_ratio, radius, weight=1.0):
+    """weight * mean(BCEWithLogits(logits, rasterised point targets)); targets as GridLossComputation.prepare_target."""
+    return _GridBCEFn.apply(logits, rois, gt_boxes, map_size, sub_regions, float(mapping_ratio), int(radius),
+                            float(weight))
+
+
+def grid_decode(logits, rois, map_size, sub_regions, mapping_ratio, roi_img=None, gts=None, gt_off=None):
+    """Refined boxes [R,4] from the heat maps (GridPostProcessor.get_boxes); with gts also the boolean keep mask of
+    GridPostProcessor._filter_boxes evaluated on the incoming RoIs."""
+    H.require_gpu(logits, rois, gts)
+    rois = _boxes(rois)
+    R = rois.shape[0]
+    if logits.shape[0] != R:
+        raise RuntimeError("grid decode: %d logits maps for %d rois" % (logits.shape[0], R))
+    logits = logits.detach()
+    strides, sub, pts = _geom_args(logits, sub_regions)
+    out = torch.empty((R, 4), dtype=torch.float32, device=rois.device)
+    keep = None
+    if gts is not None:
+        gts = _boxes(gts)
+        keep = torch.empty((R,), dtype=torch.uint8, device=rois.device)
+        roi_img = _i32(roi_img) if roi_img is not None else None
+        gt_off = _i32(gt_off)
+    with torch.cuda.device(rois.device):
+        rc = H.lib().cpm_grid_decode(H.ptr(logits), strides, H.ptr(rois), R, pts, int(map_size), sub,
+                                     H.f(mapping_ratio), H.ptr(roi_img), H.ptr(gts), H.ptr(gt_off), H.ptr(out),
+                                     H.ptr(keep), H.stream())
+    H.check(rc, "grid_decode")
+    return (out, keep.bool()) if keep is not None else out

@@ -6,16 +6,26 @@ the stage's IoU, pool 14x14, 8 convs, 2 deconvs -> BCE against rasterised point 
 loss), decode refined boxes (no_grad) and append gts for the next stage; RSM: cls negatives + refined positives
 -> second cls head -> CE.  Testing: cls head -> ml_nms -> the stages refine the kept detections -> ISM / RSM
 re-scoring."""
+import os
+
+import numpy as np
 import torch
 from torch import nn
 
+import pet.lib.ops as ops
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
 from pet.rcnn.modeling.grid_cascade_rcnn.inference import post_processor
 from pet.rcnn.modeling.grid_cascade_rcnn.loss import loss_evaluator
 from pet.rcnn.modeling.grid_rcnn import heads, outputs  # noqa: F401  (populate the registries)
 from pet.rcnn.utils.misc import keep_only_positive_boxes
+from pet.utils.data.structures.bounding_box import BoxList
 from pet.utils.data.structures.boxlist_ops import cat_boxlist
+
+
+def _to_device_async(values, dtype, device):
+    """small host list -> device through pinned memory (an ordinary pageable copy would wait for the stream)"""
+    return torch.tensor(values, dtype=dtype).pin_memory().to(device, non_blocking=True)
 
 
 class GridCascadeRCNN(nn.Module):
@@ -44,6 +54,8 @@ class GridCascadeRCNN(nn.Module):
             self.Output_rescore = registry.ROI_CLS_OUTPUTS[G.ROI_CLS_OUTPUT](self.Head_rescore.dim_out)
             self.rescore_loss_evaluator = loss_evaluator(type="cls")
         self.last_counts = {}
+        # CPM_FUSED_GLUE=0 runs the per-image formulation (kept as the in-tree cross-check of the fused kernels)
+        self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
 
     def forward(self, features, proposals, targets=None):
         if self.training:
@@ -74,6 +86,9 @@ class GridCascadeRCNN(nn.Module):
 
     def _forward_train_cascade(self, features, proposals, targets):
         G = cfg.GRID_RCNN
+        if self.fused_glue and not (G.FUSED_ON or G.BETTER_ROI or G.TARGET_REFINE or G.ACROSS_SAMPLE
+                                    or G.CASCADE_MAPPING_OPTION.RESIZE_ROI):
+            return self._forward_train_cascade_fused(features, proposals, targets)
         losses, x = {}, None
         for s in range(self.stage_num):
             ev = self.grid_loss_evaluators[s]
@@ -94,6 +109,90 @@ class GridCascadeRCNN(nn.Module):
                 with torch.no_grad():
                     proposals = self.grid_post_processors[s](grid_logits, proposals, targets=targets, is_train=True)
         return x, proposals, losses
+
+    def _forward_train_cascade_fused(self, features, proposals, targets):
+        """Same computation as the loop above (grid_cascade_rcnn.py:117-160 in the reference), restated over the
+        whole batch: per stage ONE matching launch (cpm_match_rois), ONE loss launch with the targets rasterised on
+        the fly (cpm_grid_bce_loss) and ONE decode+filter launch (cpm_grid_decode), and one host round trip per
+        stage transition (the survivors' mask) instead of one per image, field and boolean index.  The RoIs of all
+        images travel concatenated; per-image BoxLists are rebuilt (as views) for the heads and at the end."""
+        G, M = cfg.GRID_RCNN, cfg.GRID_RCNN.CASCADE_MAPPING_OPTION
+        dev = features[0].device
+        n_img = len(proposals)
+        proposals = keep_only_positive_boxes(proposals, roi_batch_size=self.max_sample_num_grid, across_sample=False)
+        sizes = [p.size for p in proposals]
+        gt_counts = [len(t) for t in targets]
+        gt_off_h = np.concatenate([[0], np.cumsum(gt_counts)]).astype(np.int64)
+        n_gt = int(gt_off_h[-1])
+        gt_all = torch.cat([t.bbox for t in targets], dim=0)
+        gt_off = _to_device_async(gt_off_h.tolist(), torch.int32, dev)
+        counts = [len(p) for p in proposals]
+        rois = torch.cat([p.bbox for p in proposals], dim=0)
+        # per-RoI attributes that only ride along (the RSM stage reads them from the returned BoxLists)
+        labels = torch.cat([p.get_field("labels") for p in proposals] + [t.get_field("labels") for t in targets])
+        obj = torch.cat([p.get_field("objectness") for p in proposals] + [torch.ones_like(gt_all[:, 0])])
+        src = torch.arange(sum(counts), device=dev)        # row of (labels, obj) each current RoI came from
+        gt_src = torch.arange(sum(counts), sum(counts) + n_gt, device=dev)
+
+        def roi_img_and_base(cnts):
+            """image index and first-gt row of every RoI, built on the host (tiny) and copied asynchronously"""
+            im = np.repeat(np.arange(n_img), cnts)
+            return (_to_device_async(im.tolist(), torch.int32, dev),
+                    _to_device_async(gt_off_h[im].tolist(), torch.int64, dev))
+
+        img, base = roi_img_and_base(counts)
+        with torch.no_grad():
+            matched, max_iou = ops.match_rois(rois, img, gt_all, gt_off, M.FG_IOU_THRESHOLD[0], M.BG_IOU_THRESHOLD[0])
+            gt_boxes = gt_all[matched.clamp(min=0) + base]
+        losses, x = {}, None
+        for s in range(self.stage_num):
+            ev = self.grid_loss_evaluators[s]
+            last = s == self.stage_num - 1
+            self.last_counts["grid_%d" % s] = sum(counts)
+            boxlists = [BoxList(b, sz) for b, sz in zip(rois.split(counts), sizes)]
+            x, _ = getattr(self, "Head_grid_%d" % s)(features, boxlists)
+            grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
+            logits = grid_logits["unfused"]
+            ratio = M.STAGE_MAPPING_RATIO[s]
+            loss_grid = ops.grid_bce_loss(logits, rois, gt_boxes, ev.whole_map_size, ev.sub_regions, ratio,
+                                          ev.pos_radius, ev.loss_weight)
+            losses["loss_grid_%d" % (s + 1)] = loss_grid * self.stage_loss_weight[s]
+            if G.IOU_HELPER and last:
+                iou_target = torch.stack([1 - max_iou, max_iou], dim=1)
+                losses["loss_iou_%d" % (s + 1)] = ops.l2_loss(iou_logits, iou_target) * G.IOU_LOSS_WEIGHT
+            if last:
+                break
+            with torch.no_grad():
+                # GridPostProcessor.forward(is_train=True) + the next stage's subsample: drop RoIs coinciding with
+                # a gt, decode the rest, append the gts, keep what matches a gt at the next stage's IoU
+                refined, keep = ops.grid_decode(logits, rois, ev.whole_map_size, ev.sub_regions, ratio, img, gt_all,
+                                                gt_off)
+                m2, iou2 = ops.match_rois(refined, img, gt_all, gt_off, M.FG_IOU_THRESHOLD[s + 1],
+                                          M.BG_IOU_THRESHOLD[s + 1])
+                keep_h = (keep & (m2 >= 0)).cpu().numpy()                       # the stage's one host round trip
+                off = np.concatenate([[0], np.cumsum(counts)])
+                n_roi, index, counts = int(off[-1]), [], []
+                for i in range(n_img):
+                    kept = np.flatnonzero(keep_h[off[i]:off[i + 1]]) + off[i]
+                    index.extend(kept.tolist())
+                    index.extend(range(n_roi + int(gt_off_h[i]), n_roi + int(gt_off_h[i + 1])))
+                    counts.append(len(kept) + gt_counts[i])
+                index = _to_device_async(index, torch.int64, dev)
+                # every appended gt matches itself with IoU exactly 1 (inter == area)
+                rois = torch.cat([refined, gt_all], dim=0)[index]
+                gt_boxes = torch.cat([gt_all[m2.clamp(min=0) + base], gt_all], dim=0)[index]
+                max_iou = torch.cat([iou2, torch.ones_like(gt_all[:, 0])], dim=0)[index]
+                src = torch.cat([src, gt_src], dim=0)[index]
+                img, base = roi_img_and_base(counts)
+        result, o = [], 0
+        lab, ob = labels[src], obj[src]
+        for i in range(n_img):
+            bl = BoxList(rois[o:o + counts[i]], sizes[i], mode="xyxy")
+            bl.add_field("objectness", ob[o:o + counts[i]])
+            bl.add_field("labels", lab[o:o + counts[i]])
+            result.append(bl)
+            o += counts[i]
+        return x, result, losses
 
     def _forward_train_rescore(self, features, cls_proposals, grid_proposals, targets):
         with torch.no_grad():

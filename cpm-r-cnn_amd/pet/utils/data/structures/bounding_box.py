@@ -112,6 +112,8 @@ class BoxList(object):
         return out
 
     def __getitem__(self, item):
+        if isinstance(item, torch.Tensor) and item.dtype in (torch.bool, torch.uint8) and self.extra_fields:
+            item = item.nonzero().squeeze(1)       # one device->host size query instead of one per field
         out = BoxList(self.bbox[item], self.size, self.mode)
         for k, v in self.extra_fields.items():
             out.add_field(k, v[item])

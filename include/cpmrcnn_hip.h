@@ -163,6 +163,31 @@ int cpm_deform_coord_grad(const float* dcols, const float* x, const float* offse
                           int R, int S, int stride, int pad, int dilation, int groups, int deformable_groups, int P,
                           int Q, float* doffset, void* stream);
 
+/* ---- Detection glue of the training step ----------------------
+ * Fused replacements for per-image chains of small tensor ops in the reference's Python; all images of the batch
+ * in one launch.  Boxes are float4 (x1,y1,x2,y2), 16-byte aligned; gt_off [num_images+1] holds each image's
+ * slice of `gts`; roi_img [R] names each RoI's image (NULL = single image).
+ *
+ * cpm_match_rois: boxlist_iou ("+1" widths, pet/utils/data/structures/boxlist_ops.py:123-158) + Matcher.__call__
+ * (pet/rcnn/utils/matcher.py:48-111).  matched[i] = index of the best gt WITHIN its image (first maximum), -1
+ * below `low`, -2 between; max_iou[i] = that IoU (may be NULL).  allow_low_quality restores the arg-max of every
+ * RoI that ties some gt's best IoU (needs row_max_ws, [num_gts] ints). */
+int cpm_match_rois(const float* rois, const int* roi_img, const float* gts, const int* gt_off, int R, int num_gts,
+                   float high, float low, int allow_low_quality, int* row_max_ws, int64_t* matched, float* max_iou,
+                   void* stream);
+/* cpm_grid_bce_loss: GridLossComputation.prepare_target + loss_grid (grid_cascade_rcnn/loss.py:178-262): the
+ * 0/1 point targets are rasterised on the fly (never materialised).  logits [R,points,half,half] with element
+ * `strides` (host array of 4); sub_xy (host, 2*points) = x,y origin of each point's window in the whole map.
+ * *loss_sum += weight * mean(BCEWithLogits);  grad (same strides) = d(weight*mean)/d logits. */
+int cpm_grid_bce_loss(const float* logits, const int64_t* strides, const float* rois, const float* gt_boxes, int R,
+                      int points, int map_size, const int* sub_xy, float mapping_ratio, int radius, float weight,
+                      float* loss_sum, float* grad, void* stream);
+/* cpm_grid_decode: GridPostProcessor.get_boxes (grid_cascade_rcnn/inference.py:189-279; no clipping, as there) and,
+ * when `keep` is given, _filter_boxes (:281-290) on the UNdecoded RoIs.  */
+int cpm_grid_decode(const float* logits, const int64_t* strides, const float* rois, int R, int points, int map_size,
+                    const int* sub_xy, float mapping_ratio, const int* roi_img, const float* gts, const int* gt_off,
+                    float* out_boxes, unsigned char* keep, void* stream);
+
 /* ---- GroupNorm (+ReLU), NHWC ----------------------------------------------
  * Replaces nn.GroupNorm + nn.ReLU in grid_heads.py:47-55 and outputs.py:23,68.
  * x [N,HW,C]; mean/rstd [N,G] saved for backward; dgamma/dbeta accumulate.      */

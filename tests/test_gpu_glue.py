@@ -1,0 +1,163 @@
+"""GPU: the fused detection-glue kernels (cpm_match_rois / cpm_grid_bce_loss / cpm_grid_decode) through the C-ABI
+vs the C oracle (orc_boxlist_iou + orc_matcher, orc_grid_targets, orc_grid_decode -- all pinned by the
+reference's own outputs in tests/test_oracle_golden.py), and the batch-fused cascade path vs the per-image one."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as TF
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_boxes(rng, n, w=640, h=480, lo=8, hi=300):
+    xy = rng.uniform(0, [w - lo, h - lo], (n, 2))
+    wh = rng.uniform(lo, hi, (n, 2))
+    return np.concatenate([xy, np.minimum(xy + wh, [w - 1, h - 1])], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("low_quality", [False, True])
+@pytest.mark.parametrize("thr", [(0.5, 0.5), (0.7, 0.3)])
+def test_match_rois_bit_exact(oracle, low_quality, thr):
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(11)
+    gt_counts, roi_counts = [7, 1, 12], [900, 40, 1500]
+    gts = [_rand_boxes(rng, g) for g in gt_counts]
+    rois = []
+    for g, r in zip(gts, roi_counts):
+        b = _rand_boxes(rng, r)
+        b[: len(g)] = g                                              # exact copies: IoU exactly 1
+        j = rng.integers(0, len(g), r // 3)
+        b[len(g): len(g) + r // 3] = g[j] + rng.uniform(-12, 12, (r // 3, 4)).astype(np.float32)   # near misses
+        rois.append(b)
+    want_m, want_v = [], []
+    for g, b in zip(gts, rois):
+        q = oracle.boxlist_iou(g, b)
+        want_m.append(oracle.matcher(q, thr[0], thr[1], low_quality))
+        want_v.append(q.max(0))
+    dev = "cuda"
+    img = torch.from_numpy(np.repeat(np.arange(3), roi_counts).astype(np.int32)).to(dev)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(gt_counts)]), dtype=torch.int32, device=dev)
+    m, v = ops.match_rois(torch.from_numpy(np.concatenate(rois)).to(dev), img,
+                          torch.from_numpy(np.concatenate(gts)).to(dev), off, thr[0], thr[1], low_quality)
+    assert np.array_equal(m.cpu().numpy(), np.concatenate(want_m))
+    assert np.array_equal(v.cpu().numpy(), np.concatenate(want_v))
+    # and it is what the per-image tensor-op Matcher of the package computes
+    from pet.rcnn.utils.matcher import Matcher
+    from pet.utils.data.structures.boxlist_ops import box_iou_plus1
+    mm = Matcher(thr[0], thr[1], low_quality)(box_iou_plus1(torch.from_numpy(gts[2]).to(dev),
+                                                            torch.from_numpy(rois[2]).to(dev)))
+    assert torch.equal(mm, m[-roi_counts[2]:])
+
+
+@pytest.mark.parametrize("ratio", [1.0, 0.5, 0.25])
+def test_grid_bce_loss_vs_oracle_targets(oracle, ratio):
+    import pet.lib.ops as ops
+    from pet.rcnn.modeling.grid_rcnn.loss import calc_sub_regions
+    rng = np.random.default_rng(12)
+    R = 37
+    boxes = _rand_boxes(rng, R)
+    boxes[3] = [10, 10, 12.5, 200]                                   # narrower than the 3-point grid: all-zero target
+    gt = boxes + rng.uniform(-15, 15, (R, 4)).astype(np.float32)
+    tgt = oracle.grid_targets(boxes, gt, 9, 56, 1, ratio)
+    assert tgt[3].sum() == 0 and tgt.sum() > 0
+    x = torch.from_numpy(rng.normal(0, 2, (R, 9, 28, 28)).astype(np.float32))
+    xr = x.clone().requires_grad_(True)
+    want = 15 * TF.binary_cross_entropy_with_logits(xr, torch.from_numpy(tgt))
+    want.backward()
+    sub = calc_sub_regions(9, 3, 56)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        xg = x.cuda().contiguous(memory_format=fmt).requires_grad_(True)
+        got = ops.grid_bce_loss(xg, torch.from_numpy(boxes).cuda(), torch.from_numpy(gt).cuda(), 56, sub, ratio, 1, 15)
+        (got * 0.5).backward()
+        assert abs(float(got.detach()) - float(want.detach())) < 1e-5 * abs(float(want.detach()))
+        assert float((xg.grad.cpu() - 0.5 * xr.grad).abs().max()) < 1e-6 * float(xr.grad.abs().max()) + 1e-10
+
+
+@pytest.mark.parametrize("ratio", [1.0, 0.5])
+def test_grid_decode_vs_oracle(oracle, ratio):
+    import pet.lib.ops as ops
+    from pet.rcnn.modeling.grid_cascade_rcnn.inference import decode_grid_boxes
+    from pet.rcnn.modeling.grid_rcnn.loss import calc_sub_regions
+    rng = np.random.default_rng(13)
+    R = 29
+    boxes = _rand_boxes(rng, R)
+    logits = torch.from_numpy(rng.normal(0, 3, (R, 9, 28, 28)).astype(np.float32))
+    logits[0, 4] = 0.25                                              # a flat map: the FIRST maximum must win
+    logits[1, :, 5, 7] = 30.0
+    logits[1, :, 9, 2] = 30.0                                        # saturated tie (sigmoid == 1.0f twice)
+    want = oracle.grid_decode(boxes, torch.sigmoid(logits).numpy(), 9, 56, ratio)
+    sub = calc_sub_regions(9, 3, 56)
+    gts = np.stack([boxes[2], boxes[5] + [0, 1, 2, 3], [boxes[7][0], 1, 2, 3], [1, 2, 3, boxes[9][3]]]).astype(np.float32)
+    img = torch.zeros(R, dtype=torch.int32)
+    img[15:] = 1                                                     # gts 0..1 belong to image 0, 2..3 to image 1
+    off = torch.tensor([0, 2, 4], dtype=torch.int32)
+    for fmt in (torch.contiguous_format, torch.channels_last):
+        lg = logits.cuda().contiguous(memory_format=fmt)
+        got, keep = ops.grid_decode(lg, torch.from_numpy(boxes).cuda(), 56, sub, ratio, img.cuda(),
+                                    torch.from_numpy(gts).cuda(), off.cuda())
+        np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-5, atol=1e-3)
+        only = ops.grid_decode(lg, torch.from_numpy(boxes).cuda(), 56, sub, ratio)
+        assert torch.equal(only, got)
+    ref = decode_grid_boxes(torch.from_numpy(boxes).cuda(), logits.cuda(), ratio, 9, sub, 56)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    # _filter_boxes (inference.py:281-290), evaluated per image
+    want_keep = np.ones(R, bool)
+    for r in range(R):
+        g = gts[:2] if r < 15 else gts[2:]
+        c = np.where((boxes[r][None] == g).any(0), -1.0, boxes[r]).astype(np.float32)
+        want_keep[r] = ((c[0] + c[1]) + c[2]) + c[3] > 0
+    assert not want_keep[2] and want_keep[7] and want_keep[9]       # image-1 gts must not touch image-0 RoIs
+    assert np.array_equal(keep.cpu().numpy(), want_keep)
+
+
+def test_fused_cascade_equals_per_image_path():
+    """The batch-fused training path of the CMM cascade (3 kernels + 1 host round trip per stage) against the
+    per-image tensor-op formulation on the same RoIs: same RoI sets stage by stage, same losses, same gradients."""
+    from test_gpu_model import CPM_OPTS, synthetic_batch
+    from detfill import det_fill_
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS)
+    try:
+        m = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+        det_fill_(m)
+        m = m.cuda().to(memory_format=torch.channels_last).train()
+        images, targets = synthetic_batch(2, 256, 320, 6, seed=3)
+        targets = [t.to("cuda") for t in targets]
+        head = m.Grid_Cascade_RCNN
+        with torch.no_grad():
+            feats = m.Conv_Body_FPN(m.Conv_Body(images.cuda().contiguous(memory_format=torch.channels_last)))
+        feats = [f.detach().requires_grad_(True) for f in feats]
+        from pet.utils.data.structures.image_list import to_image_list
+        torch.manual_seed(0)
+        with torch.no_grad():
+            props, _ = m.RPN(to_image_list(images.cuda()), feats, targets)
+            props, _ = head._forward_train_cls(feats, props, targets)
+        outs = []
+        for fused in (True, False):
+            head.fused_glue = fused
+            for f in feats:
+                f.grad = None
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(1)                                     # keep_only_positive_boxes draws a randperm
+            _, result, losses = head._forward_train_cascade(feats, [p[torch.arange(len(p), device="cuda")] for p in props],
+                                                            targets)
+            sum(losses.values()).backward()
+            outs.append((result, {k: float(v.detach()) for k, v in losses.items()}, dict(head.last_counts),
+                         [f.grad.clone() for f in feats[:4]]))
+        head.fused_glue = True
+        (ra, la, ca, ga), (rb, lb, cb, gb) = outs
+        assert ca == cb and set(la) == set(lb) == {"loss_grid_1", "loss_grid_2", "loss_grid_3", "loss_iou_3"}
+        for k in la:
+            assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-7, (k, la[k], lb[k])
+        for a, b in zip(ra, rb):
+            assert len(a) == len(b) and set(a.fields()) == set(b.fields())
+            np.testing.assert_allclose(a.bbox.cpu().numpy(), b.bbox.cpu().numpy(), rtol=1e-5, atol=1e-3)
+            for f in a.fields():
+                assert torch.equal(a.get_field(f).float(), b.get_field(f).float()), f
+        for a, b in zip(ga, gb):
+            assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-9
+    finally:
+        config.reset_cfg()

@@ -57,3 +57,28 @@ ev = [e for e in prof.key_averages() if e.key.startswith("SEC_")]
 for e in ev:
     print("%-22s calls=%d cpu_total=%.2f ms/step  cuda_total=%.2f ms/step" % (e.key, e.count, e.cpu_time_total / 3e3,
                                                                             getattr(e, "device_time_total", 0) / 3e3))
+
+# launches and synchronising copies per section (host-side view: which glue is launch bound)
+evs = prof.events()
+secs = [e for e in evs if e.name.startswith("SEC_") and e.device_type.name == "CPU"]
+launch = [e for e in evs if e.name in ("hipLaunchKernel", "hipMemcpyWithStream", "hipMemsetAsync", "hipExtModuleLaunchKernel")]
+import collections  # noqa: E402
+per = collections.defaultdict(lambda: collections.Counter())
+for s in secs:
+    lo, hi = s.time_range.start, s.time_range.end
+    for e in launch:
+        if lo <= e.time_range.start <= hi:
+            per[s.name][e.name] += 1
+for k, v in per.items():
+    print("%-22s %s" % (k, {a: round(b / 3, 1) for a, b in v.items()}))
+ops_in = collections.defaultdict(lambda: collections.Counter())
+aten = [e for e in evs if e.name.startswith("aten::") and e.device_type.name == "CPU"]
+for s in secs:
+    if s.name not in ("SEC_cascade", "SEC_rpn_proposals", "SEC_rpn_loss", "SEC_cls"):
+        continue
+    lo, hi = s.time_range.start, s.time_range.end
+    for e in aten:
+        if lo <= e.time_range.start <= hi:
+            ops_in[s.name][e.name] += 1
+for k, v in ops_in.items():
+    print(k, [(a, round(b / 3)) for a, b in v.most_common(18)])
