@@ -4,14 +4,18 @@ CLSLossComputation is the usual Fast R-CNN sampler + cross-entropy.  GridLossCom
 heat-map targets.  The reference rasterises them in a Python triple loop on the CPU (loss.py:213-249, R*9*9
 iterations + .cpu()/.cuda() round trips per stage); here the same arithmetic (fp32, same operation order, int()
 truncation toward zero, radius-1 disc, 28x28 sub-region crop) is evaluated as whole-tensor ops on the device."""
+import os
+
 import numpy as np
 import torch
 from torch.nn import functional as F
 
+import pet.lib.ops as ops
 from pet.lib.ops import l2_loss
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling.grid_rcnn.loss import calc_sub_regions
 from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
+from pet.rcnn.utils.fused_sampling import batch_pos_neg_sample
 from pet.rcnn.utils.matcher import Matcher
 from pet.rcnn.utils.misc import cat
 from pet.utils.data.structures.boxlist_ops import boxlist_iou
@@ -22,6 +26,8 @@ class CLSLossComputation(object):
         self.proposal_matcher = proposal_matcher
         self.fg_bg_sampler = fg_bg_sampler
         self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
+        # CPM_FUSED_GLUE=0 runs the per-image formulation (the in-tree cross-check of the fused path)
+        self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
 
     def prepare_targets(self, proposals, targets):
         labels = []
@@ -33,7 +39,50 @@ class CLSLossComputation(object):
             labels.append(lab)
         return labels
 
+    def _subsample_fused(self, proposals, targets):
+        """prepare_targets + sampler + selection for all images at once: one cpm_match_rois launch, one batch-wide
+        sampler, ONE host round trip (the selection mask) instead of one per image and BoxList field."""
+        from pet.utils.data.structures.bounding_box import BoxList
+        n_img = len(proposals)
+        counts = [len(p) for p in proposals]
+        dev = proposals[0].bbox.device
+        rois = torch.cat([p.bbox for p in proposals], dim=0)
+        img_h = np.repeat(np.arange(n_img), counts)
+        img = torch.from_numpy(img_h.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
+        gt_off_h = np.concatenate([[0], np.cumsum([len(t) for t in targets])])
+        gt_off = torch.from_numpy(gt_off_h.astype(np.int32)).pin_memory().to(dev, non_blocking=True)
+        base = torch.from_numpy(gt_off_h[img_h].astype(np.int64)).pin_memory().to(dev, non_blocking=True)
+        gt_all = torch.cat([t.bbox for t in targets], dim=0)
+        gt_labels = torch.cat([t.get_field("labels") for t in targets], dim=0).to(torch.int64)
+        m = self.proposal_matcher
+        matched, _ = ops.match_rois(rois, img, gt_all, gt_off, m.high_threshold, m.low_threshold,
+                                    m.allow_low_quality_matches)
+        lab = gt_labels[matched.clamp(min=0) + base]
+        lab = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, 0, lab)
+        lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1, lab)
+        pos, neg = batch_pos_neg_sample(lab, img, n_img, self.fg_bg_sampler.batch_size_per_image,
+                                        self.fg_bg_sampler.positive_fraction)
+        take_h = (pos | neg).cpu().numpy()                                  # the one host round trip
+        idx_h = np.flatnonzero(take_h)
+        new_counts = np.bincount(img_h[idx_h], minlength=n_img).tolist()
+        idx = torch.from_numpy(idx_h).pin_memory().to(dev, non_blocking=True)
+        fields = {f: torch.cat([p.get_field(f) for p in proposals], dim=0)[idx] for f in proposals[0].fields()
+                  if f != "labels"}
+        fields["labels"] = lab[idx]
+        out, o = [], 0
+        sel = rois[idx]
+        for i in range(n_img):
+            bl = BoxList(sel[o:o + new_counts[i]], proposals[i].size, proposals[i].mode)
+            for f, v in fields.items():
+                bl.add_field(f, v[o:o + new_counts[i]])
+            out.append(bl)
+            o += new_counts[i]
+        self._proposals = out
+        return out
+
     def subsample(self, proposals, targets):
+        if self.fused_glue and proposals[0].bbox.is_cuda:
+            return self._subsample_fused(proposals, targets)
         labels = self.prepare_targets(proposals, targets)
         pos_masks, neg_masks = self.fg_bg_sampler(labels)
         proposals = list(proposals)

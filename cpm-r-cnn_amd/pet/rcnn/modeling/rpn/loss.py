@@ -1,14 +1,18 @@
 """RPN loss (counterpart of pet/rcnn/modeling/rpn/loss.py:18-153): IoU(+1) matching with low-quality matches,
 visibility / between-threshold discards, 256 samples per image at 50 % positives, BCE-with-logits over the
 sample and smooth-L1(beta=1/9, sum) over its positives divided by the sample size."""
+import os
+
 import torch
 from torch.nn import functional as F
 
+import pet.lib.ops as ops
 from pet.lib.ops import smooth_l1_loss
 from pet.rcnn.core.config import cfg
 from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from pet.rcnn.utils.matcher import Matcher
 from pet.rcnn.utils.misc import concat_box_prediction_layers
+from pet.rcnn.utils.fused_sampling import batch_pos_neg_sample
 from pet.utils.data.structures.boxlist_ops import box_iou_plus1
 
 
@@ -19,6 +23,8 @@ class RPNLossComputation(object):
         self.box_coder = box_coder
         self.generate_labels_func = generate_labels_func
         self.discard_cases = ["not_visibility", "between_thresholds"]
+        # CPM_FUSED_GLUE=0 runs the per-image formulation below (the in-tree cross-check of the fused path)
+        self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
 
     def prepare_targets(self, anchors, targets):
         """anchors: list (per image) of (bbox [A,4], visibility [A]); targets: list[BoxList]."""
@@ -35,7 +41,46 @@ class RPNLossComputation(object):
             regression_targets.append(self.box_coder.encode(t.bbox[matched.clamp(min=0)], abox))
         return labels, regression_targets
 
+    def _call_fused(self, anchors, objectness, box_regression, targets):
+        """The same loss over the whole batch with no host round trip: one cpm_match_rois launch for every anchor of
+        every image (IoU + thresholds + low-quality matches), one batch-wide sampler, and the two reductions taken
+        over all anchors under the sample masks instead of over nonzero()-gathered subsets (identical values and
+        gradients: a gather's backward scatters into zeros exactly where the mask is zero)."""
+        n_img = len(anchors)
+        abox = torch.cat([a.bbox for per_img in anchors for a in per_img], dim=0)
+        vis = torch.cat([a.get_field("visibility") for per_img in anchors for a in per_img], dim=0)
+        per = abox.shape[0] // n_img
+        assert all(sum(len(a) for a in per_img) == per for per_img in anchors)
+        dev = abox.device
+        img = torch.arange(n_img, device=dev).repeat_interleave(per)
+        gt_all = torch.cat([t.bbox for t in targets], dim=0)
+        gt_off = torch.tensor([0] + [len(t) for t in targets]).cumsum(0).to(torch.int32).pin_memory().to(
+            dev, non_blocking=True)
+        m = self.proposal_matcher
+        matched, _ = ops.match_rois(abox, img.to(torch.int32), gt_all, gt_off, m.high_threshold, m.low_threshold,
+                                    m.allow_low_quality_matches)
+        lab = self.generate_labels_func(matched).to(dtype=torch.float32)
+        if "between_thresholds" in self.discard_cases:
+            lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1.0, lab)
+        if "not_visibility" in self.discard_cases:
+            lab = torch.where(vis, lab, -1.0)
+        pos, neg = batch_pos_neg_sample(lab, img, n_img, self.fg_bg_sampler.batch_size_per_image,
+                                        self.fg_bg_sampler.positive_fraction)
+        sampled = pos | neg
+        n_sampled = sampled.sum()
+        objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
+        objectness = objectness.squeeze(1)
+        target = self.box_coder.encode(gt_all[matched.clamp(min=0) + gt_off.long()[img]], abox)
+        target = torch.where(pos[:, None], target, 0.0)       # unsampled rows never reach the loss (nor its gradient)
+        box_loss = torch.where(pos[:, None], smooth_l1_loss(box_regression, target, beta=cfg.RPN.SMOOTH_L1_BETA),
+                               0.0).sum() / n_sampled
+        bce = F.binary_cross_entropy_with_logits(objectness, lab.clamp(min=0), reduction="none")
+        objectness_loss = (bce * sampled.to(torch.float32)).sum() / n_sampled
+        return objectness_loss, box_loss
+
     def __call__(self, anchors, objectness, box_regression, targets):
+        if self.fused_glue:
+            return self._call_fused(anchors, objectness, box_regression, targets)
         flat = [(torch.cat([a.bbox for a in per_img], 0), torch.cat([a.get_field("visibility") for a in per_img], 0))
                 for per_img in anchors]
         labels, regression_targets = self.prepare_targets(flat, targets)
