@@ -35,14 +35,36 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
 constexpr int BK = 32;
 constexpr int LDP = 36;  // LDS row pitch in floats
+
+// 3-term split-bf16 arithmetic (SURVEY "numerics": fp32-accumulate with a split-bf16 scheme): x = hi + lo with
+// hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32), and a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms are <= 2^-16 |a b| (measured <= 1e-5 relative
+// on the conv outputs, the parity bar is 1e-3), bf16 keeps fp32's exponent range so no scaling is involved, and
+// three bf16 MFMAs cost 3/16 of the fp32 MFMA they replace.
+__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
+  const bf16x2 h01 = {(__bf16)v.x, (__bf16)v.y}, h23 = {(__bf16)v.z, (__bf16)v.w};
+  hi.x = __builtin_bit_cast(unsigned, h01);
+  hi.y = __builtin_bit_cast(unsigned, h23);
+  const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
+  const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
+  const bf16x2 l01 = {(__bf16)r0, (__bf16)r1}, l23 = {(__bf16)r2, (__bf16)r3};
+  lo.x = __builtin_bit_cast(unsigned, l01);
+  lo.y = __builtin_bit_cast(unsigned, l23);
+}
 
 // 16-byte load through a buffer descriptor: an offset at or beyond num_records returns zeros WITHOUT touching
 // memory.  Masked gather lanes (padding, row/channel tails) are simply given OOB_OFF: no branch around the load
 // (hipcc drains vmcnt(0) inside such branches), no select, and no hot cache line as with a dummy address.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 constexpr unsigned OOB_OFF = 0xFFFFFFF0u;
+// base offset of a weight row that does not exist: weights stay below 2 GiB (validate()), so base + tap offset
+// is still beyond num_records and the load returns zeros
+constexpr unsigned B_INVALID = 0x80000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)bytes, 0x00020000);
 }
@@ -87,8 +109,8 @@ struct IgemmArgs {
   int m_base;          // first GEMM row of this launch (rows [m_base, M) are tiled)
 };
 
-template <int BM, int BN, int WM, int WN, bool VEC>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
+template <int BM, int BN, int WM, int WN, bool VEC, bool SPLIT>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(IgemmArgs a) {
   constexpr int NT = 64 * WM * WN;              // threads
   constexpr int RPP = NT / 8;                   // rows per load pass (8 threads x float4 cover a 32-float row)
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
@@ -97,7 +119,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile shape");
 
   constexpr int CP = BN + 4;                    // epilogue staging pitch (floats)
-  constexpr int LDS_AB = 2 * (BM + BN) * LDP, LDS_C = BM * CP;
+  constexpr int LDS_AB = SPLIT ? 2 * (BM + BN) * 32 : 2 * (BM + BN) * LDP, LDS_C = BM * CP;
   __shared__ __attribute__((aligned(16))) float smem[LDS_AB > LDS_C ? LDS_AB : LDS_C];
   float (*As)[BM][LDP] = reinterpret_cast<float (*)[BM][LDP]>(smem);
   float (*Bs)[BN][LDP] = reinterpret_cast<float (*)[BN][LDP]>(smem + 2 * BM * LDP);
@@ -119,28 +141,31 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
   const int m0 = a.m_base + tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-thread load geometry --------------------------------------------------------------
+  // Everything a load needs per k-step is (row byte offset + one uniform tap offset) and two range checks; the
+  // offsets are pinned in registers (the empty asm) -- otherwise the compiler re-derives them from n/h/w with
+  // integer multiplies inside every k-step and sinks each load under its own exec-masked branch.
   const int lrow = tid >> 3;        // 0..RPP-1
   const int lcol = (tid & 7) * 4;   // 0,4,..,28
-  int a_base[AP], a_h[AP], a_w[AP];
-  bool a_ok[AP];
+  unsigned a_off[AP];
+  int a_h[AP], a_w[AP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
     const int m = m0 + i * RPP + lrow;
-    a_ok[i] = m < a.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
     const int jj = mm % a.OWp, t = mm / a.OWp;
     const int ii = t % a.OHp, n = t / a.OHp;
-    a_h[i] = ii * a.ihmul + a.ihadd;
+    a_h[i] = ok ? ii * a.ihmul + a.ihadd : -(1 << 28);      // a row past M never passes the range check
     a_w[i] = jj * a.iwmul + a.iwadd;
-    a_base[i] = ((n * a.IH + a_h[i]) * a.IW + a_w[i]) * a.Ctot + g * a.CgR;
+    a_off[i] = (unsigned)(((n * a.IH + (ok ? a_h[i] : 0)) * a.IW + a_w[i]) * a.Ctot + g * a.CgR + lcol) * 4u;
+    asm volatile("" : "+v"(a_off[i]), "+v"(a_h[i]), "+v"(a_w[i]));
   }
-  int b_base[BP];
-  bool b_ok[BP];
+  unsigned b_off[BP];
 #pragma unroll
   for (int i = 0; i < BP; ++i) {
     const int oc = n0 + i * RPP + lrow;
-    b_ok[i] = oc < a.OCg;
-    b_base[i] = (g * a.OCg + (b_ok[i] ? oc : 0)) * a.R * a.S * a.CgR;
+    b_off[i] = oc < a.OCg ? (unsigned)((g * a.OCg + oc) * a.R * a.S * a.CgR + lcol) * 4u : B_INVALID;
+    asm volatile("" : "+v"(b_off[i]));
   }
 
   // k-step range of this split
@@ -155,47 +180,78 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 
   auto load_tile = [&](int kt, float4 (&ra)[AP], float4 (&rb)[BP]) {
     const int tap = kt / a.ksteps_per_tap;
-    const int c0 = (kt - tap * a.ksteps_per_tap) * BK + lcol;
+    const int cb = (kt - tap * a.ksteps_per_tap) * BK;      // first reduction channel of this k-step (uniform)
     const int tr = tap / a.ns, ts = tap - tr * a.ns;
     const int dh = tr * a.hstep, dw = ts * a.wstep;
-    const int wtap = ((a.r0 + tr * a.rstep) * a.S + a.s0 + ts * a.sstep) * a.CgR;
-    const int aoff = (dh * a.IW + dw) * a.Ctot + c0;
-    const bool c_ok = c0 < a.CgR;
+    const unsigned wtap = (unsigned)(((a.r0 + tr * a.rstep) * a.S + a.s0 + ts * a.sstep) * a.CgR + cb) * 4u;
+    const unsigned aoff = (unsigned)((dh * a.IW + dw) * a.Ctot + cb) * 4u;
+    const bool c_ok = cb + lcol < a.CgR;
+    if (VEC) {
+      // branch-free: all the step's loads issue back to back; a masked lane gets an out-of-range offset
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const bool ok = c_ok & ((unsigned)(a_h[i] + dh) < (unsigned)a.IH) & ((unsigned)(a_w[i] + dw) < (unsigned)a.IW);
+        ra[i] = bload4(rs_in, ok ? a_off[i] + aoff : OOB_OFF);
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = bload4(rs_wm, c_ok ? b_off[i] + wtap : OOB_OFF);
+      return;
+    }
+    const int c0 = cb + lcol;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int ih = a_h[i] + dh, iw = a_w[i] + dw;
-      const bool ok = a_ok[i] && c_ok && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW;
+      const bool ok = c_ok && (unsigned)(a_h[i] + dh) < (unsigned)a.IH && (unsigned)(a_w[i] + dw) < (unsigned)a.IW;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (VEC) {
-        // branch-free: all the step's loads issue back to back (a branch per load makes hipcc wait vmcnt(0)
-        // inside each branch)
-        v = bload4(rs_in, ok ? (unsigned)(a_base[i] + aoff) * 4u : OOB_OFF);
-      } else if (ok) {
-        const int off = a_base[i] + aoff;
-        v.x = a.in[off];
-        if (c0 + 1 < a.CgR) v.y = a.in[off + 1];
-        if (c0 + 2 < a.CgR) v.z = a.in[off + 2];
-        if (c0 + 3 < a.CgR) v.w = a.in[off + 3];
+      if (ok) {
+        const float* src = a.in + ((a_off[i] + aoff) >> 2);
+        v.x = src[0];
+        if (c0 + 1 < a.CgR) v.y = src[1];
+        if (c0 + 2 < a.CgR) v.z = src[2];
+        if (c0 + 3 < a.CgR) v.w = src[3];
       }
       ra[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      const bool ok = b_ok[i] && c_ok;
-      if (VEC) {
-        v = bload4(rs_wm, ok ? (unsigned)(b_base[i] + wtap + c0) * 4u : OOB_OFF);
-      } else if (ok) {
-        const int off = b_base[i] + wtap + c0;
-        v.x = a.wm[off];
-        if (c0 + 1 < a.CgR) v.y = a.wm[off + 1];
-        if (c0 + 2 < a.CgR) v.z = a.wm[off + 2];
-        if (c0 + 3 < a.CgR) v.w = a.wm[off + 3];
+      if (c_ok && b_off[i] != B_INVALID) {
+        const float* src = a.wm + ((b_off[i] + wtap) >> 2);
+        v.x = src[0];
+        if (c0 + 1 < a.CgR) v.y = src[1];
+        if (c0 + 2 < a.CgR) v.z = src[2];
+        if (c0 + 3 < a.CgR) v.w = src[3];
       }
       rb[i] = v;
     }
   };
+  // SPLIT LDS image: four planes A_hi | A_lo | B_hi | B_lo, each [2 buffers][rows][32 bf16 = 64 B], no padding.
+  // A row's four 16-byte chunks are stored at chunk ^ ((row >> 2) & 3): the 16 lanes of a ds_read_b128 group (16
+  // consecutive rows, same chunk) then hit 16 distinct 4-bank groups, and so do the ds_write_b64 of two rows.
+  // hi and lo live in different planes (kilobytes apart), so the compiler cannot fuse them into one ds_write2.
+  unsigned* const sm = reinterpret_cast<unsigned*>(smem);
+  constexpr int PA_HI = 0, PA_LO = 2 * BM * 16, PB_HI = 4 * BM * 16, PB_LO = 4 * BM * 16 + 2 * BN * 16;
+  static_assert(!SPLIT || (RPP % 16 == 0 && WTM % 32 == 0), "swizzle assumes row blocks of 16");
+  const int w_sw = ((((lcol >> 3) ^ ((lrow >> 2) & 3)) << 2) | ((lcol >> 1) & 2));   // dword offset inside the row
   auto store_tile = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP]) {
+    if (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        uint2 hi, lo;
+        split4(ra[i], hi, lo);
+        const int o = (buf * BM + i * RPP + lrow) * 16 + w_sw;
+        *(uint2*)(sm + PA_HI + o) = hi;
+        *(uint2*)(sm + PA_LO + o) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        uint2 hi, lo;
+        split4(rb[i], hi, lo);
+        const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
+        *(uint2*)(sm + PB_HI + o) = hi;
+        *(uint2*)(sm + PB_LO + o) = lo;
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AP; ++i) *(float4*)&As[buf][i * RPP + lrow][lcol] = ra[i];
 #pragma unroll
@@ -212,6 +268,33 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(IgemmArgs a) {
 
   const int frow = lane & 31, fk = (lane >> 5) * 4;
   auto mma_half = [&](int cur, int kb0) {
+    if (SPLIT) {
+      // one 32x32x16 step: the lane's 8 consecutive reduction elements (k = 16*half + 8*(lane>>5) ..) are ONE
+      // ds_read_b128 from the hi plane and one from the lo plane
+      const int r_sw = ((((kb0 >> 1) * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
+      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
+        ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+        al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+        bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+        bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        }
+      return;
+    }
 #pragma unroll
     for (int kb = kb0; kb < kb0 + BK / 16; ++kb) {
       float4 fa[TM], fb[TN];
@@ -620,6 +703,9 @@ struct ProfScope {
   }
 };
 
+// conv arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 3-term split-bf16 MFMA (fp32 accumulate)
+static int g_conv_split = 0;
+
 struct Plan { int bm, bn, wm, wn, split; };
 
 int env_int(const char* name, int dflt) {
@@ -700,10 +786,14 @@ int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t
 #define LAUNCH(BM, BN, WM, WN)                                                                       \
   do {                                                                                               \
     dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);          \
-    if (vec)                                                                                         \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true>), grid, dim3(64 * WM * WN), 0, s, a);   \
-    else                                                                                             \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false>), grid, dim3(64 * WM * WN), 0, s, a);  \
+    if (vec && g_conv_split)                                                                               \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, dim3(64 * WM * WN), 0, s, a);   \
+    else if (vec)                                                                                          \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false>), grid, dim3(64 * WM * WN), 0, s, a);  \
+    else if (g_conv_split)                                                                                 \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, true>), grid, dim3(64 * WM * WN), 0, s, a);  \
+    else                                                                                                   \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false>), grid, dim3(64 * WM * WN), 0, s, a); \
   } while (0)
   if (bm == 128 && bn == 128 && wn == 4) LAUNCH(128, 128, 2, 4);
   else if (bm == 128 && bn == 128) LAUNCH(128, 128, 2, 2);
@@ -755,7 +845,7 @@ int validate(const cpm_conv_desc* d) {
   if (P != d->P || Q != d->Q) return CPM_EINVAL;
   // byte offsets travel as 32-bit buffer offsets: every tensor must stay below 2^30 floats (4 GiB - 16)
   if ((int64_t)d->N * d->H * d->W * d->C >= (1ll << 30) - 4 || (int64_t)d->N * d->P * d->Q * d->K >= (1ll << 30) - 4 ||
-      (int64_t)d->K * d->R * d->S * (d->C / d->groups) >= (1ll << 30) - 4)
+      (int64_t)d->K * d->R * d->S * (d->C / d->groups) >= (1ll << 29) - 4)     // weights < 2 GiB: B_INVALID
     return CPM_EINVAL;
   return CPM_OK;
 }
@@ -969,6 +1059,14 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
 }
 
 // ---- profiling hooks (bench.py roofline leg) -----------------------------------------------------------
+CPM_EXPORT int cpm_set_conv_math(int mode) {
+  CPM_REQUIRE(mode == CPM_MATH_F32 || mode == CPM_MATH_BF16X3, "unknown conv math mode");
+  g_conv_split = mode == CPM_MATH_BF16X3;
+  return CPM_OK;
+}
+
+CPM_EXPORT int cpm_get_conv_math(void) { return g_conv_split ? CPM_MATH_BF16X3 : CPM_MATH_F32; }
+
 CPM_EXPORT int cpm_prof_enable(int on) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
   g_prof.clear();

@@ -40,8 +40,29 @@ def lib():
                 L.cpm_last_error.restype = ctypes.c_char_p
                 for name in ("cpm_nms_workspace_bytes", "cpm_conv2d_workspace_bytes"):
                     getattr(L, name).restype = c_size_t
+                mode = os.environ.get("CPM_CONV_MATH", "").lower()
+                if mode:
+                    if mode not in CONV_MATH:
+                        raise RuntimeError("CPM_CONV_MATH must be one of %s" % sorted(CONV_MATH))
+                    L.cpm_set_conv_math(CONV_MATH[mode])
                 _lib = L
     return _lib
+
+
+CONV_MATH = {"f32": 0, "bf16x3": 1}
+
+
+def set_conv_math(mode):
+    """'f32' = exact fp32 MFMA; 'bf16x3' = 3-term split-bf16 MFMA with fp32 accumulation (cpmrcnn_hip.h)."""
+    if mode not in CONV_MATH:
+        raise RuntimeError("conv math must be one of %s" % sorted(CONV_MATH))
+    rc = lib().cpm_set_conv_math(CONV_MATH[mode])
+    check(rc, "set_conv_math")
+
+
+def get_conv_math():
+    v = lib().cpm_get_conv_math()
+    return [k for k, c in CONV_MATH.items() if c == v][0]
 
 
 def check(rc, what):

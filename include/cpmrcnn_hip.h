@@ -113,6 +113,17 @@ typedef struct {
   int P, Q;              /* output [N,P,Q,K]  */
 } cpm_conv_desc;
 
+/* Arithmetic of the conv family (process-wide; set before launching, not thread-safe against running calls):
+ *   CPM_MATH_F32    v_mfma_f32_32x32x2_f32: an exact fp32 fmaf chain per output.
+ *   CPM_MATH_BF16X3 every fp32 operand split as hi + lo bf16 (x - bf16(x) is exact), a*b = ah*bh + ah*bl + al*bh on
+ *                   v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-17 relative error per product (the
+ *                   north_star tolerance for conv tensors is 1e-3), fp32 exponent range, 3/16 of the MFMA time.
+ * Forward and data-gradient kernels honour it; the weight-gradient kernel is fp32 MFMA in both modes. */
+#define CPM_MATH_F32 0
+#define CPM_MATH_BF16X3 1
+int cpm_set_conv_math(int mode);
+int cpm_get_conv_math(void);
+
 size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d);
 int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,
                        const float* shift, const float* residual, int res_mode, int relu, float* y,

@@ -10,6 +10,18 @@ CL = torch.channels_last
 TOL = 1e-4
 
 
+@pytest.fixture(autouse=True, params=["f32", "bf16x3"])
+def conv_math(request):
+    """Every test of this file runs under both conv arithmetics (include/cpmrcnn_hip.h: CPM_MATH_*): the exact
+    fp32 MFMA and the 3-term split-bf16 MFMA (fp32 accumulate).  Same tolerance for both: 1e-4 of the tensor
+    maximum, a decade inside north_star's 1e-3."""
+    from pet.lib.ops import _hip
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math(request.param)
+    yield request.param
+    _hip.set_conv_math(prev)
+
+
 def relerr(a, b):
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))

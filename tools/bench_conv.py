@@ -59,7 +59,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--filter", default="")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
     a = ap.parse_args()
+    from pet.lib.ops import _hip
+    _hip.set_conv_math(a.math)
     tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
     print("%-20s %9s | %8s %7s | %8s %7s | %8s %7s" % ("layer", "GFLOP", "fwd us", "TF/s", "dgrad us", "TF/s",
                                                        "wgrad us", "TF/s"))
@@ -72,11 +75,21 @@ def main():
         dy = torch.randn(N, K, P, Q, device="cuda").contiguous(memory_format=CL)
         dw = torch.zeros_like(w)
         gf = 2.0 * N * P * Q * K * R * R * (C // g) / 1e9
+        err = ""
+        if a.math != "f32":
+            y1 = ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g)
+            d1 = ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g)
+            _hip.set_conv_math("f32")
+            y0 = ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g)
+            d0 = ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g)
+            _hip.set_conv_math(a.math)
+            err = "  err fwd %.1e dgrad %.1e" % (float((y1 - y0).abs().max() / y0.abs().max()),
+                                               float((d1 - d0).abs().max() / d0.abs().max()))
         t_f = timeit(lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g), a.iters)
         t_d = timeit(lambda: ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g), a.iters)
         t_w = timeit(lambda: ops.conv2d_backward_weight(x, dy, w, st, pad, 1, g, out=dw), a.iters)
         print("%-20s %9.1f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (
-            name, gf, t_f * 1e3, gf / t_f, t_d * 1e3, gf / t_d, t_w * 1e3, gf / t_w))
+            name, gf, t_f * 1e3, gf / t_f, t_d * 1e3, gf / t_d, t_w * 1e3, gf / t_w) + err)
         for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
             tot[k][0] += gf * cnt
             tot[k][1] += t * cnt
