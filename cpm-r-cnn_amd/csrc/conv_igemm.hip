@@ -677,6 +677,188 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
   }
 }
 
+// ---- weight gradient, 3-term split-bf16 arithmetic -----------------------------------------------------
+// Same tiling as wgrad_kernel (BM output channels x BN input channels for ONE tap, pixels reduced in chunks of
+// 32), but the bf16 MFMA wants a lane's 8 reduction elements (pixels) CONTIGUOUS for its channel, i.e. a
+// channel-major LDS image, while memory is pixel-major (NHWC).  The transposition happens in registers: a thread
+// owns one 4-channel vector x 4 consecutive pixels (four 16-byte loads, each 16-lane group reading 256 contiguous
+// bytes), splits every value into hi/lo bf16 and writes, per channel, the 4 pixels as ONE 8-byte store.
+// Channel c of the tile lives in LDS row (c % 4) * (BM/4) + c / 4, so that the 16 lanes of a store group (16
+// consecutive channel vectors, same component) write 16 consecutive rows -- with the igemm chunk swizzle that is
+// conflict-free for the stores and for the ds_read_b128 operand fetches alike.  The accumulator tile comes out
+// row/column-permuted accordingly; it is un-permuted through LDS at the end so that the float atomics into dw
+// are 256-byte contiguous per wave instruction.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_split_kernel(WgradArgs a) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int QA = BM / 4, QB = BN / 4;              // channel vectors per tile
+  constexpr int CP = BN + 4;
+  constexpr int LDS_AB = 2 * (BM + BN) * 32, LDS_C = BM * CP;
+  static_assert(QA % 16 == 0 && QB % 16 == 0 && QA * 8 <= 256 && QB * 8 <= 256, "tile shape");
+  __shared__ __attribute__((aligned(16))) float smem[LDS_AB > LDS_C ? LDS_AB : LDS_C];
+  unsigned* const sm = reinterpret_cast<unsigned*>(smem);
+  constexpr int PA_HI = 0, PA_LO = 2 * BM * 16, PB_HI = 4 * BM * 16, PB_LO = 4 * BM * 16 + 2 * BN * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.Cg + BN - 1) / BN;
+  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
+  const int tap = blockIdx.y;
+  const int r = tap / a.S, s = tap - r * a.S;
+  const int g = blockIdx.z / a.split_k, split = blockIdx.z % a.split_k;
+  const int oc0 = tile_m * BM, c0 = tile_n * BN;
+
+  const int per = (a.chunks + a.split_k - 1) / a.split_k;
+  const int ch_begin = split * per, ch_end = min(a.chunks, ch_begin + per);
+  const int nk = ch_end - ch_begin;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
+
+  // slot of this thread: channel vector q (16 consecutive per 16-lane group) and pixel run (4 pixels)
+  const int grp = tid >> 4, l16 = tid & 15;
+  const int qa = (grp % (QA / 16)) * 16 + l16, pra = grp / (QA / 16);     // pra < 8 for the first QA*8 threads
+  const int qb = (grp % (QB / 16)) * 16 + l16, prb = grp / (QB / 16);
+  const bool a_act = pra < 8 && oc0 + 4 * qa < a.OCg;
+  const bool b_act = prb < 8 && c0 + 4 * qb < a.Cg;
+  unsigned a_off = (unsigned)((ch_begin * 32 + 4 * pra) * a.OCtot + g * a.OCg + oc0 + 4 * qa) * 4u;
+  const unsigned a_step = (unsigned)(32 * a.OCtot) * 4u, a_pix = (unsigned)a.OCtot * 4u;
+  const unsigned b_chan = (unsigned)(g * a.Cg + c0 + 4 * qb) * 4u;
+  asm volatile("" : "+v"(a_off));
+
+  // (n, oh, ow) of the thread's 4 pixels, stepped by 32 pixels per chunk without divisions
+  const int hw = a.OH * a.OW;
+  const int dn = 32 / hw, rem = 32 % hw;
+  const int dh = rem / a.OW, dwid = rem % a.OW;
+  int b_n[4], b_oh[4], b_ow[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = ch_begin * 32 + 4 * prb + i;
+    b_ow[i] = m % a.OW;
+    const int t = m / a.OW;
+    b_oh[i] = t % a.OH;
+    b_n[i] = t / a.OH;
+  }
+
+  float4 ra[4], rb[4];
+  auto load_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, a_act ? a_off + i * a_pix : OOB_OFF);   // rows >= M: beyond dy
+    a_off += a_step;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ih = b_oh[i] * a.stride - a.pad + r * a.dil, iw = b_ow[i] * a.stride - a.pad + s * a.dil;
+      const bool ok = b_act & (b_n[i] < a.N) & ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+      rb[i] = bload4(rs_x, ok ? (unsigned)(((b_n[i] * a.IH + ih) * a.IW + iw) * a.Ctot) * 4u + b_chan : OOB_OFF);
+      b_n[i] += dn; b_oh[i] += dh; b_ow[i] += dwid;
+      if (b_ow[i] >= a.OW) { b_ow[i] -= a.OW; ++b_oh[i]; }
+      if (b_oh[i] >= a.OH) { b_oh[i] -= a.OH; ++b_n[i]; }
+    }
+  };
+  // the 4 pixels of one channel -> one 8-byte hi store and one 8-byte lo store in the channel's row
+  const int wa_sw = (((pra >> 1) ^ ((qa >> 2) & 3)) << 2) | ((pra & 1) << 1);
+  const int wb_sw = (((prb >> 1) ^ ((qb >> 2) & 3)) << 2) | ((prb & 1) << 1);
+  auto store_chunk = [&](int buf) {
+    if (pra < 8) {
+      const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
+                            make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint2 hi, lo;
+        split4(ch[j], hi, lo);
+        const int o = (buf * BM + j * QA + qa) * 16 + wa_sw;        // row j*QA + qa: (row >> 2) & 3 == (qa >> 2) & 3
+        *(uint2*)(sm + PA_HI + o) = hi;
+        *(uint2*)(sm + PA_LO + o) = lo;
+      }
+    }
+    if (prb < 8) {
+      const float4 ch[4] = {make_float4(rb[0].x, rb[1].x, rb[2].x, rb[3].x), make_float4(rb[0].y, rb[1].y, rb[2].y, rb[3].y),
+                            make_float4(rb[0].z, rb[1].z, rb[2].z, rb[3].z), make_float4(rb[0].w, rb[1].w, rb[2].w, rb[3].w)};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        uint2 hi, lo;
+        split4(ch[j], hi, lo);
+        const int o = (buf * BN + j * QB + qb) * 16 + wb_sw;
+        *(uint2*)(sm + PB_HI + o) = hi;
+        *(uint2*)(sm + PB_LO + o) = lo;
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31;
+  auto mma_half = [&](int cur, int sub) {
+    const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
+    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
+      ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+      bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if (nk > 0) {
+    load_chunk();
+    store_chunk(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) load_chunk();
+    mma_half(cur, 0);
+    mma_half(cur, 1);
+    if (it + 1 < nk) store_chunk(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // un-permute through LDS: accumulator row R holds output channel (R % QA) * 4 + R / QA, column C input channel
+  // (C % QB) * 4 + C / QB
+  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem);
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int C = wn * WTN + j * 32 + ecol;
+      const int cl = (C % QB) * 4 + C / QB;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int R = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+        Cs[(R % QA) * 4 + R / QA][cl] = acc[i][j][e];
+      }
+    }
+  __syncthreads();
+  for (int idx = tid; idx < BM * BN; idx += 256) {
+    const int row = idx / BN, col = idx - row * BN;
+    const int ocl = oc0 + row, cl = c0 + col;
+    if (ocl < a.OCg && cl < a.Cg)
+      atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl, Cs[row][col]);
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 int num_cus() { return 256; }
 
@@ -844,7 +1026,7 @@ int validate(const cpm_conv_desc* d) {
   const int Q = (d->W + 2 * d->pad - d->dilation * (d->S - 1) - 1) / d->stride + 1;
   if (P != d->P || Q != d->Q) return CPM_EINVAL;
   // byte offsets travel as 32-bit buffer offsets: every tensor must stay below 2^30 floats (4 GiB - 16)
-  if ((int64_t)d->N * d->H * d->W * d->C >= (1ll << 30) - 4 || (int64_t)d->N * d->P * d->Q * d->K >= (1ll << 30) - 4 ||
+  if ((int64_t)d->N * d->H * d->W * d->C >= (1ll << 30) - (1 << 17) || (int64_t)d->N * d->P * d->Q * d->K >= (1ll << 30) - (1 << 17) ||
       (int64_t)d->K * d->R * d->S * (d->C / d->groups) >= (1ll << 29) - 4)     // weights < 2 GiB: B_INVALID
     return CPM_EINVAL;
   return CPM_OK;
@@ -1040,7 +1222,10 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   do {                                                                                               \
     a.split_k = split_for(blocks(BM, BN), (BM) * (BN) >= 128 * 128 ? 2 : 4);                          \
     dim3 grid((unsigned)(cpm::cdiv(a.OCg, BM) * cpm::cdiv(a.Cg, BN)), taps, a.groups * a.split_k);  \
-    if (wvec)                                                                                        \
+    if (wvec && g_conv_split && (BM) % 64 == 0 && (BN) % 64 == 0)                                    \
+      hipLaunchKernelGGL((wgrad_split_kernel<(BM) % 64 == 0 ? BM : 64, (BN) % 64 == 0 ? BN : 64, 2, 2>), grid, \
+                         dim3(256), 0, s, a);                                                        \
+    else if (wvec)                                                                                   \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
     else                                                                                             \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);           \
@@ -1051,6 +1236,10 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
     else WLAUNCH(64, 64, 2, 2);
   } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && a.chunks >= 64) {
     WLAUNCH(128, 128, 2, 2);        // the reduction (pixels) is split until the grid fills the chip
+  } else if (g_conv_split && wvec && a.OCg >= 96 && a.Cg >= 96 && (a.chunks >= 64 || blocks(128, 128) >= 384)) {
+    // the split-bf16 kernel only pays off on the 128x128 tile (the 64x64 one is LDS/convert bound): ragged channel
+    // counts (576 = 4.5 tiles) and short reductions with many tiles (FC layers) take it with masked edges
+    WLAUNCH(128, 128, 2, 2);
   } else {
     WLAUNCH(64, 64, 2, 2);
   }

@@ -34,9 +34,24 @@ __global__ __launch_bounds__(256) void match_rowmax_kernel(const float4* __restr
                                                            const int* __restrict__ gt_off, int R,
                                                            int* __restrict__ row_max) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= R) return;
-  const int img = roi_img ? roi_img[i] : 0;
-  const float4 p = rois[i];
+  const bool live = i < R;
+  const int img = live ? (roi_img ? roi_img[i] : 0) : -1;
+  // 268 k anchors per image against <= ~100 gts: one atomic per (lane, gt) would serialise on a few dozen
+  // addresses.  A wave whose lanes all belong to one image reduces each gt's maximum across its 64 lanes first and
+  // issues ONE atomic per gt; a wave straddling an image boundary (one per image) falls back to per-lane atomics.
+  const int img0 = __shfl(img, 0, 64);
+  const bool uniform = __all(img == img0 || !live) && img0 >= 0;
+  const float4 p = live ? rois[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  if (uniform) {
+    const int lane = threadIdx.x & 63;
+    for (int g = gt_off[img0]; g < gt_off[img0 + 1]; ++g) {
+      float v = live ? iou_plus1(gts[g], p) : 0.f;
+      for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+      if (lane == 0 && v > 0.f) atomicMax(row_max + g, __float_as_int(v));
+    }
+    return;
+  }
+  if (!live) return;
   for (int g = gt_off[img]; g < gt_off[img + 1]; ++g) {
     const float v = iou_plus1(gts[g], p);
     if (v > 0.f) atomicMax(row_max + g, __float_as_int(v));

@@ -118,7 +118,7 @@ typedef struct {
  *   CPM_MATH_BF16X3 every fp32 operand split as hi + lo bf16 (x - bf16(x) is exact), a*b = ah*bh + ah*bl + al*bh on
  *                   v_mfma_f32_32x32x16_bf16 with fp32 accumulation: ~2^-17 relative error per product (the
  *                   north_star tolerance for conv tensors is 1e-3), fp32 exponent range, 3/16 of the MFMA time.
- * Forward and data-gradient kernels honour it; the weight-gradient kernel is fp32 MFMA in both modes. */
+ * All three conv kernels honour it (narrow <=32-channel weight-gradient tiles stay on the fp32 MFMA). */
 #define CPM_MATH_F32 0
 #define CPM_MATH_BF16X3 1
 int cpm_set_conv_math(int mode);

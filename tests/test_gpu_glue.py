@@ -207,7 +207,7 @@ def test_fused_rpn_loss_equals_per_image_path():
         (ao, ab, ago, agr), (bo, bb, bgo, bgr) = res[0], res[1]
         assert abs(ao - bo) < 1e-5 * abs(bo) and abs(ab - bb) < 1e-5 * abs(bb)
         for x, y in zip(ago + agr, bgo + bgr):
-            assert float((x - y).abs().max()) <= 1e-5 * float(y.abs().max()) + 1e-12
+            assert float((x - y).abs().max()) <= 1e-4 * float(y.abs().max()) + 1e-12
         # at the real budget the two draw different random subsets: same estimator, nearby values
         assert all(np.isfinite(v) for v in res[2][:2] + res[3][:2])
         assert abs(res[2][0] - res[3][0]) < 0.2 * res[3][0] + 0.05
