@@ -374,7 +374,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
       const int m = m0 + r;
       if (m >= a.M || ocl >= a.OCg) continue;
       int orow = m, oh = 0, ow = 0, n = 0;
-      if (!dense_rows || a.res_mode == 1) {
+      if (!dense_rows || (a.res && a.res_mode == 1)) {
         const int jj = m % a.OWp, t = m / a.OWp;
         const int ii = t % a.OHp;
         n = t / a.OHp;
@@ -385,18 +385,21 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
       float4 v = *(const float4*)&Cs[r][cv];
       v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
       float* dst = a.out + (size_t)orow * a.OCtot + oc;
-      const float* rp = a.res_mode == 0
+      const float* rp = !a.res ? nullptr
+                        : a.res_mode == 0
                             ? a.res + (size_t)orow * a.OCtot + oc
                             : a.res + ((size_t)(n * ((a.OH + 1) / 2) + oh / 2) * ((a.OW + 1) / 2) + ow / 2) * a.OCtot + oc;
       if (vec_out) {
-        const float4 rv = *(const float4*)rp;
-        v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        if (rp) {
+          const float4 rv = *(const float4*)rp;
+          v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w;
+        }
         if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
         *(float4*)dst = v;
       } else {
         float* vp = &v.x;
         for (int k = 0; k < 4 && ocl + k < a.OCg; ++k) {
-          float o = vp[k] + rp[k];
+          float o = vp[k] + (rp ? rp[k] : 0.f);
           dst[k] = a.relu ? fmaxf(o, 0.f) : o;
         }
       }
@@ -1236,7 +1239,7 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
     else WLAUNCH(64, 64, 2, 2);
   } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && a.chunks >= 64) {
     WLAUNCH(128, 128, 2, 2);        // the reduction (pixels) is split until the grid fills the chip
-  } else if (g_conv_split && wvec && a.OCg >= 96 && a.Cg >= 96 && (a.chunks >= 64 || blocks(128, 128) >= 384)) {
+  } else if (g_conv_split && wvec && a.OCg >= 96 && a.Cg >= 96 && a.chunks >= 16) {
     // the split-bf16 kernel only pays off on the 128x128 tile (the 64x64 one is LDS/convert bound): ragged channel
     // counts (576 = 4.5 tiles) and short reductions with many tiles (FC layers) take it with masked edges
     WLAUNCH(128, 128, 2, 2);
