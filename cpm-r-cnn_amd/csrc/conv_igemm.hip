@@ -313,6 +313,34 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         }
     }
   };
+  // SPLIT: operand fetch and MFMAs as separate pieces, so that a k-step can fetch BOTH 16-deep halves first and
+  // then run its 24 MFMAs with the next tile's bf16 split + LDS stores laid into their issue gaps
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto fetch = [&](int cur, int sub, Frag& f) {
+    const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+    }
+  };
+  auto mfma3 = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
   // One k-step: issue the loads of tile t+2, multiply the first half of tile t, move tile t+1 (loaded a whole
   // step ago, so its wait is short) from registers to the other LDS buffer, multiply the second half, barrier.
   // The store sits in the MIDDLE of the MFMA stream so that the wait + ds_writes of this wave overlap the
@@ -320,9 +348,29 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
   auto step = [&](int it, int cur, float4 (&la)[AP], float4 (&lb)[BP], const float4 (&sa)[AP],
                   const float4 (&sb)[BP]) {
     if (it + 2 < nk) load_tile(k_begin + it + 2, la, lb);
-    mma_half(cur, 0);
-    if (it + 1 < nk) store_tile(cur ^ 1, sa, sb);
-    mma_half(cur, BK / 16);
+    if (SPLIT) {
+      Frag f0, f1;
+      fetch(cur, 0, f0);
+      fetch(cur, 1, f1);
+      mfma3(f0);
+      // unconditional (the last step re-stores a stale tile into the idle buffer): one straight-line region
+      store_tile(cur ^ 1, sa, sb);
+      mfma3(f1);
+      constexpr int NM = TM * TN * 3 * 2;                      // MFMAs of the step
+      constexpr int VPM = (AP + BP) * 12 / NM > 0 ? (AP + BP) * 12 / NM : 1;   // split VALU ops per MFMA gap
+      constexpr int WEVERY = NM / (AP + BP) > 0 ? NM / (AP + BP) : 1;
+      __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+      for (int m = 0; m < NM; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        if (m % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      }
+    } else {
+      mma_half(cur, 0);
+      if (it + 1 < nk) store_tile(cur ^ 1, sa, sb);
+      mma_half(cur, BK / 16);
+    }
     __syncthreads();
   };
 
