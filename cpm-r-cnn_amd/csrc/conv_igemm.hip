@@ -1169,6 +1169,14 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   Plan p = plan_igemm(whole);
   a.split_k = p.split;
   a.atomic_out = (a.split_k > 1) || accumulate;
+  // accumulate without split-K: read-add-write through the (LDS-staged, 16-byte) residual epilogue with dx as its
+  // own residual -- two streaming passes over dx instead of one float atomic per element
+  const bool acc_via_res = accumulate && a.split_k == 1 && !shift && !relu;
+  if (acc_via_res) {
+    a.atomic_out = 0;
+    a.res = dx;
+    a.res_mode = 0;
+  }
   if (a.atomic_out && !accumulate) {
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
@@ -1190,7 +1198,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
       a.osh = a.osw = st; a.oah = pa; a.oaw = pb;
       a.M = d->N * a.OHp * a.OWp;
       a.ksteps = a.nr * a.ns * a.ksteps_per_tap;
-      if (a.ksteps == 0 && a.atomic_out) continue;      // nothing to add
+      if (a.ksteps == 0 && (a.atomic_out || acc_via_res)) continue;      // nothing to add
       Plan pp = plan_igemm(a);
       pp.split = a.split_k;
       if (a.ksteps < a.split_k) { a.split_k = 1; pp.split = 1; }

@@ -15,6 +15,19 @@ from . import _hip as H
 CL = torch.channels_last
 
 
+def mark_shared_grad(t):
+    """Opt a multi-consumer activation into in-place gradient accumulation: the first of this package's consumers to
+    run its backward hands autograd its gradient tensor and parks it in the holder; every later consumer adds into
+    that same tensor (residual epilogue of the data-gradient kernel / RoIAlign atomics) and reports None, instead of
+    returning a fresh tensor for autograd to sum with an extra elementwise pass.  Only for tensors whose consumers
+    created before any foreign (non-accumulating) consumer are all from this package -- block inputs of the
+    ResNet/ResNeXt bottlenecks and the FPN maps (their one foreign consumer, the P6 subsample, is created first and
+    therefore differentiated last)."""
+    if torch.is_grad_enabled() and t.requires_grad:
+        t._cpm_gacc = {}
+    return t
+
+
 def nhwc(t):
     """Return `t` with NHWC memory (no copy when it already is)."""
     if t.dim() != 4:
@@ -61,9 +74,22 @@ def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, di
     return y
 
 
-def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups):
+def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_into=None):
+    """dx = conv^T(dy, w); with `accumulate_into` (an NHWC tensor of x's shape) the result is ADDED to it instead."""
     n, c, h, wd = x_shape
     k, _, r, s = w.shape
+    if accumulate_into is not None:
+        acc = accumulate_into
+        assert tuple(acc.shape) == tuple(x_shape) and acc.is_contiguous(memory_format=CL)
+        if dy.numel() == 0 or acc.numel() == 0:
+            return acc
+        d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
+        ws = _ws(d, dy.device)
+        with torch.cuda.device(dy.device):
+            rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(acc), 1, H.ptr(ws),
+                                                  H.c_size_t(ws.numel()), H.stream())
+        H.check(rc, "conv2d_backward_data(accumulate)")
+        return acc
     if (r, s) == (h, wd) and pad == 0 and stride == 1 and dil == 1 and groups == 1 and (r > 1 or s > 1):
         # full-window conv (an FC over a flattened NHWC map): every input pixel sees exactly one tap, so the data
         # gradient is the plain GEMM dy[N,K] x W[K, R*S*C] -- run it as a 1x1 problem over R*S*C "channels"
@@ -129,6 +155,7 @@ class _ConvFn(Function):
     @staticmethod
     def forward(ctx, x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode):
         H.require_gpu(x, w, scale, shift, residual)
+        x_in = x
         x = nhwc(x)
         w_in = w
         w = _wmem(w)
@@ -140,6 +167,8 @@ class _ConvFn(Function):
         if ctx.wparam is not None:
             w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
         y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
+        ctx.x_holder = getattr(x_in, "_cpm_gacc", None)
+        ctx.res_holder = getattr(residual, "_cpm_gacc", None) if residual is not None else None
         ctx.cfg = (stride, pad, dil, groups, relu, res_mode, tuple(x.shape),
                    None if residual is None else tuple(residual.shape))
         ctx.has = (scale is not None, shift is not None, residual is not None)
@@ -169,7 +198,22 @@ class _ConvFn(Function):
         gres = None
         if want_res:
             gres = g if res_mode == 0 else upsample2x_add_backward(g, res_shape)
-        dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups) if need_x else None
+            h = ctx.res_holder
+            if h is not None:
+                if "acc" in h:
+                    h["acc"].add_(gres)
+                    gres = None
+                else:
+                    h["acc"] = gres
+        dx = None
+        if need_x:
+            h = ctx.x_holder
+            if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(x_shape):
+                conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, accumulate_into=h["acc"])
+            else:
+                dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups)
+                if h is not None:
+                    h["acc"] = dx
         dw = None
         if need_w:
             wp = ctx.wparam

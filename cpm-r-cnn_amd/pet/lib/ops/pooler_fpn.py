@@ -46,6 +46,7 @@ class _RoIAlignFPN(Function):
                                                    int(sampling_ratio), H.f(lvl_min), H.f(lvl_max), H.f(s0),
                                                    H.f(l0), H.f(eps), H.ptr(out), H.ptr(levels), H.stream())
         H.check(rc, "roi_align_fpn_forward")
+        ctx.holders = [getattr(f, "_cpm_gacc", None) for f in feats]      # see conv.mark_shared_grad
         ctx.save_for_backward(r)
         ctx.meta = (output_size, tuple(float(s) for s in scales), int(sampling_ratio), lvl_min, lvl_max, canonical,
                     [tuple(f.shape) for f in feats])
@@ -58,8 +59,19 @@ class _RoIAlignFPN(Function):
         r, = ctx.saved_tensors
         (ph, pw), scales, ratio, lvl_min, lvl_max, (s0, l0, eps), shapes = ctx.meta
         g = _nhwc(grad_out)
-        grads = [torch.empty(s, dtype=torch.float32, device=g.device, memory_format=torch.channels_last).zero_()
-                 for s in shapes]
+        # the kernel accumulates with atomics: a level whose feature map is opted into shared gradient accumulation
+        # and already has an accumulator gets this call's contribution added there (and reports None to autograd)
+        grads, fresh = [], []
+        for s, h in zip(shapes, ctx.holders):
+            if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(s):
+                grads.append(h["acc"])
+                fresh.append(False)
+            else:
+                t = torch.empty(s, dtype=torch.float32, device=g.device, memory_format=torch.channels_last).zero_()
+                if h is not None:
+                    h["acc"] = t
+                grads.append(t)
+                fresh.append(True)
         n = len(grads)
         hs, ws, sc = _tables(grads, scales)
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
@@ -69,7 +81,7 @@ class _RoIAlignFPN(Function):
                                                     int(shapes[0][1]), ph, pw, ratio, H.f(lvl_min), H.f(lvl_max),
                                                     H.f(s0), H.f(l0), H.f(eps), H.stream())
         H.check(rc, "roi_align_fpn_backward")
-        return (None, None, None, None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None, None, None) + tuple(t if f else None for t, f in zip(grads, fresh))
 
 
 def roi_align_fpn(feats, rois, output_size, scales, sampling_ratio, canonical_scale=224, canonical_level=4,

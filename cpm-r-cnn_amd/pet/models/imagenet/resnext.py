@@ -42,6 +42,7 @@ class Bottleneck(nn.Module):
         self.downsample = downsample
 
     def forward(self, x):
+        ops.mark_shared_grad(x)       # consumers: conv1, the downsample conv or conv3's residual -- all in-package
         s, b = _affine(self.bn1)
         out = self.conv1(x, scale=s, shift=b, relu=True)
         s, b = _affine(self.bn2)

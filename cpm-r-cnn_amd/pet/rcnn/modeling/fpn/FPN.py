@@ -4,6 +4,8 @@ Each lateral 1x1 conv adds the nearest-2x upsampled coarser map in its epilogue 
 reference's interpolate + add kernels disappear; P6 is the stride-2 subsample of P5 (MaxPool2d(1, 2))."""
 import torch.nn as nn
 
+import pet.lib.ops as ops
+
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
 from pet.utils.net import make_conv
@@ -46,7 +48,7 @@ class fpn(nn.Module):
                     nn.init.zeros_(m.bias)
 
     def forward(self, x):
-        px = self.p5_in(x[-1])
+        px = ops.mark_shared_grad(self.p5_in(x[-1]))
         outs = [self.p5_out(px)]
         for i in range(self.num_backbone_stages - 1):
             c = x[-i - 2]
@@ -56,7 +58,10 @@ class fpn(nn.Module):
                 px = self.fpn_in[i](c, residual=px, res_mode=1)      # lateral + nearest-2x(top), fused
             else:
                 px = self.fpn_in[i](c, residual=px, res_mode=0)
+            ops.mark_shared_grad(px)   # consumers: this level's output conv and the next lateral's top-down residual
             outs.insert(0, self.fpn_out[i](px))
+        for o in outs:                 # consumers: RPN head conv, the RoIAlign calls (and P6's subsample, created first)
+            ops.mark_shared_grad(o)
         if self.has_p6:
             outs.append(outs[-1][:, :, ::2, ::2].contiguous(memory_format=__import__("torch").channels_last))
         return outs
