@@ -90,6 +90,7 @@ struct IgemmArgs {
   const float* scale;  // [OCtot] or null
   const float* shift;  // [OCtot] or null
   const float* res;    // residual or null
+  const float* mask;   // [rows][OCtot] or null: output kept only where mask > 0 (ReLU gate of the consumer-side fusion)
   int N, IH, IW, Ctot;
   int OH, OW, OCtot;   // full output grid
   int OHp, OWp;        // row grid of this launch
@@ -490,6 +491,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
             }
           }
           if (a.relu) v = fmaxf(v, 0.f);
+          if (a.mask) v = a.mask[(size_t)orow * a.OCtot + oc] > 0.f ? v : 0.f;
           *dst = v;
         }
       }
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 // epilogue as a separate pass (after split-K atomics)
 __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const float* __restrict__ res, int64_t M, int OC,
-                                int OH, int OW, int res_mode, int relu) {
+                                int OH, int OW, int res_mode, int relu, const float* __restrict__ mask = nullptr) {
   const int64_t total = M * OC;
   for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (int64_t)gridDim.x * blockDim.x) {
@@ -521,6 +523,7 @@ __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict
       }
     }
     if (relu) v = fmaxf(v, 0.f);
+    if (mask) v = mask[idx] > 0.f ? v : 0.f;
     out[idx] = v;
   }
 }
@@ -1138,7 +1141,7 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
 
 static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
-                     const char* who) {
+                     const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr) {
   const size_t need = dgrad_weight_bytes(d);
   if (!workspace || workspace_bytes < need) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
@@ -1171,6 +1174,8 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   a.atomic_out = (a.split_k > 1) || accumulate;
   // accumulate without split-K: read-add-write through the (LDS-staged, 16-byte) residual epilogue with dx as its
   // own residual -- two streaming passes over dx instead of one float atomic per element
+  a.scale = out_scale;
+  a.mask = out_mask;
   const bool acc_via_res = accumulate && a.split_k == 1 && !shift && !relu;
   if (acc_via_res) {
     a.atomic_out = 0;
@@ -1208,12 +1213,12 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
     }
   }
   if (rc != CPM_OK) return rc;
-  if (a.atomic_out && (shift || relu)) {
+  if (a.atomic_out && (shift || relu || out_scale || out_mask)) {
     const int64_t total = (int64_t)whole.M * a.OCtot;
     int64_t b = (total + 255) / 256;
     hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, dx,
-                       (const float*)nullptr, shift, (const float*)nullptr, (int64_t)whole.M, a.OCtot, a.OH, a.OW, 0,
-                       relu);
+                       out_scale, shift, (const float*)nullptr, (int64_t)whole.M, a.OCtot, a.OH, a.OW, 0,
+                       relu, out_mask);
     rc = cpm::check_launch("dgrad epilogue");
   }
   return rc;
@@ -1226,6 +1231,16 @@ CPM_EXPORT int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy,
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
   return run_dgrad(d, dy, w, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
                    "cpm_conv2d_backward_data");
+}
+
+CPM_EXPORT int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const float* dy, const float* w, float* dx,
+                                              const float* in_scale, const float* in_act, void* workspace,
+                                              size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(dy && w && dx, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
+  return run_dgrad(d, dy, w, dx, 0, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
+                   "cpm_conv2d_backward_data_gated", in_scale, in_act);
 }
 
 CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float* x, const float* w,

@@ -111,6 +111,24 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
     return dx
 
 
+def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups):
+    """Data gradient with the producer's ReLU gate (x > 0) and frozen scale folded into the epilogue."""
+    n, c, h, wd = x.shape
+    k, _, r, s = w.shape
+    d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
+    dx = empty_nhwc((n, c, h, wd), dy)
+    if dx.numel() == 0:
+        return dx
+    if dy.numel() == 0:
+        return dx.zero_()
+    ws = _ws(d, dy.device)
+    with torch.cuda.device(dy.device):
+        rc = H.lib().cpm_conv2d_backward_data_gated(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), H.ptr(in_scale),
+                                                    H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+    H.check(rc, "conv2d_backward_data_gated")
+    return dx
+
+
 def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None):
     """dw (+)= x (*) dy.  `out` (same strides as the weight) is accumulated into when given."""
     n, c, h, wd = x.shape
@@ -153,7 +171,7 @@ class _ConvFn(Function):
     only when it is a trainable bias."""
 
     @staticmethod
-    def forward(ctx, x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode):
+    def forward(ctx, x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode, out_tag=None):
         H.require_gpu(x, w, scale, shift, residual)
         x_in = x
         x = nhwc(x)
@@ -167,6 +185,12 @@ class _ConvFn(Function):
         if ctx.wparam is not None:
             w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
         y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
+        # Epilogue-backward folded into the consumer: when the caller promises that y feeds exactly one consumer
+        # (bottleneck conv1 -> conv2 -> conv3) and y = relu(conv*scale + frozen shift), y carries a tag; a consuming
+        # _ConvFn gates its data gradient with (y > 0) * scale in the dgrad epilogue and flips `applied`, and this
+        # layer's backward then takes dy as the pre-activation gradient without a pass of its own.
+        ctx.in_tag = getattr(x_in, "_cpm_epi", None)
+        ctx.out_tag = out_tag                       # the same dict is attached to y by conv2d() after apply()
         ctx.x_holder = getattr(x_in, "_cpm_gacc", None)
         ctx.res_holder = getattr(residual, "_cpm_gacc", None) if residual is not None else None
         ctx.cfg = (stride, pad, dil, groups, relu, res_mode, tuple(x.shape),
@@ -185,6 +209,8 @@ class _ConvFn(Function):
         dy = nhwc(dy)
         # g = dy * [y > 0]  (gradient at the pre-activation sum);  dpre = g * scale;  dres = g;  dshift = sum g
         masked = relu or has_scale
+        if ctx.out_tag is not None and ctx.out_tag["applied"]:
+            masked = False                              # the consumer's dgrad epilogue already applied gate and scale
         want_shift = has_shift and need_shift
         want_res = has_res and need_res
         dpre, g, dshift = dy, dy, None
@@ -211,7 +237,13 @@ class _ConvFn(Function):
             if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(x_shape):
                 conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, accumulate_into=h["acc"])
             else:
-                dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups)
+                tag = ctx.in_tag
+                if tag is not None and not tag["applied"] and h is None and dil == 1 and \
+                        not ((w.shape[2], w.shape[3]) == (x_shape[2], x_shape[3]) and (w.shape[2] > 1 or w.shape[3] > 1)):
+                    dx = conv2d_backward_data_gated(dpre, w, x, tag["scale"], stride, pad, dil, groups)
+                    tag["applied"] = True
+                else:
+                    dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups)
                 if h is not None:
                     h["acc"] = dx
         dw = None
@@ -226,11 +258,19 @@ class _ConvFn(Function):
                         ready(wp)
             else:
                 dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups)
-        return dx, dw, None, dshift, gres, None, None, None, None, None, None
+        return dx, dw, None, dshift, gres, None, None, None, None, None, None, None
 
 
-def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, groups=1, relu=False, res_mode=0):
-    return _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode)
+def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, groups=1, relu=False, res_mode=0,
+           sole_consumer=False):
+    tag = None
+    if sole_consumer and relu and residual is None and not (shift is not None and shift.requires_grad) \
+            and torch.is_grad_enabled():
+        tag = {"scale": scale, "applied": False}
+    y = _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode, tag)
+    if tag is not None:
+        y._cpm_epi = tag
+    return y
 
 
 def linear(x, w, bias=None, relu=False):

@@ -10,7 +10,7 @@ from . import conv as F
 
 
 class Conv2d(nn.Conv2d):
-    def forward(self, x, scale=None, shift=None, residual=None, relu=False, res_mode=0):
+    def forward(self, x, scale=None, shift=None, residual=None, relu=False, res_mode=0, sole_consumer=False):
         assert self.padding[0] == self.padding[1] and self.stride[0] == self.stride[1] and self.padding_mode == "zeros"
         if shift is None:
             shift = self.bias
@@ -24,7 +24,7 @@ class Conv2d(nn.Conv2d):
             return cols_conv(x, None, self.weight, scale, shift, self.stride, self.padding, self.dilation,
                              self.groups, 1, relu)
         return F.conv2d(x, self.weight, scale, shift, residual, self.stride[0], self.padding[0], self.dilation[0],
-                        self.groups, relu, res_mode)
+                        self.groups, relu, res_mode, sole_consumer)
 
 
 class Linear(nn.Linear):

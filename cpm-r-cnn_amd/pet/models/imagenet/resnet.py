@@ -41,9 +41,9 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         ops.mark_shared_grad(x)       # consumers: conv1, the downsample conv or conv3's residual -- all in-package
         s, b = _affine(self.bn1)
-        out = self.conv1(x, scale=s, shift=b, relu=True)
+        out = self.conv1(x, scale=s, shift=b, relu=True, sole_consumer=True)       # consumed by conv2 only
         s, b = _affine(self.bn2)
-        out = self.conv2(out, scale=s, shift=b, relu=True)
+        out = self.conv2(out, scale=s, shift=b, relu=True, sole_consumer=True)     # consumed by conv3 only
         residual = x
         if self.downsample is not None:
             s, b = _affine(self.downsample[1])

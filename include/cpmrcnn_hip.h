@@ -132,6 +132,14 @@ int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy, const floa
                              void* workspace, size_t workspace_bytes, void* stream);
 int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* Data gradient with the epilogue-backward of the layer that PRODUCED x folded into its epilogue:
+ *   dx[m][c] = (in_act[m][c] > 0) * in_scale[c] * conv^T(dy, w)[m][c]
+ * i.e. when x = relu(prev*in_scale + shift) has this conv as its only consumer, dx is already the gradient at
+ * prev's pre-activation and prev's cpm_epilogue_backward pass (a read of dy and y, a write of dpre) disappears.
+ * in_act is x itself ([N,H,W,C]); in_scale [C] or NULL. */
+int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const float* dy, const float* w, float* dx,
+                                   const float* in_scale, const float* in_act, void* workspace,
+                                   size_t workspace_bytes, void* stream);
 
 /* nn.ConvTranspose2d forward (grid_rcnn/outputs.py:24-37,66-71) = the data gradient of the conv
  * described by `d` with a fused bias(+ReLU) epilogue: x [N,P,Q,K] -> y [N,H,W,C], w as for `d`

@@ -194,3 +194,37 @@ def test_conv_errors():
         ops.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 1, 1))          # CPU tensors: no fallback
     e = ops.conv2d(torch.zeros(0, 64, 7, 7, device="cuda"), torch.zeros(64, 64, 3, 3, device="cuda"), pad=1)
     assert e.shape == (0, 64, 7, 7)
+
+
+@pytest.mark.parametrize("stride2", [1, 2])
+def test_sole_consumer_chain_gated_dgrad(stride2):
+    """conv1 -> conv2 with `sole_consumer`: conv2's data gradient applies conv1's ReLU gate and frozen scale in its
+    epilogue (cpm_conv2d_backward_data_gated) and conv1 skips its epilogue-backward pass; gradients vs torch-CPU."""
+    import pet.lib.ops as ops
+    x = rnd(2, 32, 17, 19, seed=1)
+    w1, w2 = rnd(48, 32, 1, 1, seed=2, scale=0.2), rnd(40, 48, 3, 3, seed=3, scale=0.1)
+    s1, b1 = rnd(48, seed=4).abs() + 0.5, rnd(48, seed=5) * 0.1
+    s2, b2 = rnd(40, seed=6).abs() + 0.5, rnd(40, seed=7) * 0.1
+    xr, w1r, w2r = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+    h = F.relu(F.conv2d(xr, w1r) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    y = F.relu(F.conv2d(h, w2r, None, stride2, 1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1))
+    go = rnd(*y.shape, seed=8)
+    pre1 = (F.conv2d(x, w1) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1)).abs() < 1e-3
+    with torch.no_grad():                         # outputs whose pre-activation is ~0 may gate differently: no gradient
+        pre2 = F.conv2d(h, w2r, None, stride2, 1) * s2.view(1, -1, 1, 1) + b2.view(1, -1, 1, 1)
+        go = torch.where(pre2.abs() < 1e-3, torch.zeros_like(go), go)
+    y.backward(go)
+    cl = torch.channels_last
+    xg = x.cuda().contiguous(memory_format=cl).requires_grad_(True)
+    w1g = w1.cuda().contiguous(memory_format=cl).requires_grad_(True)
+    w2g = w2.cuda().contiguous(memory_format=cl).requires_grad_(True)
+    hg = ops.conv2d(xg, w1g, s1.cuda(), b1.cuda(), None, 1, 0, 1, 1, True, 0, True)
+    assert hasattr(hg, "_cpm_epi")
+    yg = ops.conv2d(hg, w2g, s2.cuda(), b2.cuda(), None, stride2, 1, 1, 1, True, 0, False)
+    yg.backward(go.cuda().contiguous(memory_format=cl))
+    assert hg._cpm_epi["applied"] is True
+    assert relerr(yg, y) < TOL
+    # hidden activations within 1e-3 of zero may gate differently on the two devices: bound their contribution
+    slack = 1e-3 * float(pre1.sum()) + TOL
+    assert relerr(xg.grad, xr.grad) < slack and relerr(w1g.grad, w1r.grad) < slack
+    assert relerr(w2g.grad, w2r.grad) < TOL
