@@ -257,6 +257,8 @@ def main():
                     help="conv arithmetic (include/cpmrcnn_hip.h CPM_MATH_*): bf16x3 = fp32 operands split into "
                          "hi+lo bf16, 3 bf16 MFMAs per product, fp32 accumulate (~5e-6 relative error, parity bar "
                          "1e-3); f32 = exact fp32 MFMA.  The other mode is timed too and reported beside.")
+    ap.add_argument("--no-other-math", action="store_true", help="skip the timing of the other conv arithmetic "
+                                                                  "(profiling runs)")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
                     "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
@@ -318,21 +320,23 @@ def main():
         dist.barrier()
     # the other conv arithmetic, timed the same way over a few steps (all ranks: the gradient all-reduce is collective)
     other = "f32" if a.conv_math == "bf16x3" else "bf16x3"
-    _hip.set_conv_math(other)
-    k_other = max(1, min(a.steps, 8))
-    for _ in range(2):
-        trainer.step(images, targets)
-    sync()
-    t1 = time.perf_counter()
-    for _ in range(k_other):
-        trainer.step(images, targets)
-    sync()
-    el_other = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([el_other], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el_other = float(t.item())
-    _hip.set_conv_math(a.conv_math)
+    k_other, el_other = 0, 0.0
+    if not a.no_other_math:
+        _hip.set_conv_math(other)
+        k_other = max(1, min(a.steps, 8))
+        for _ in range(2):
+            trainer.step(images, targets)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k_other):
+            trainer.step(images, targets)
+        sync()
+        el_other = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el_other], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_other = float(t.item())
+        _hip.set_conv_math(a.conv_math)
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.body == "resnet":
         cpu = cpu_baseline(trainer, a.height, a.width, 99, layers)   # (the scalar deformable-conv oracle is too
         #                                                              slow to be a bounded sample for x101dcn)
@@ -353,8 +357,9 @@ def main():
                                                 "lo*hi) with fp32 accumulation, ~5e-6 relative error per layer "
                                                 "(tests hold 1e-4; north_star bar 1e-3)",
                                      "f32": "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"}[a.conv_math],
-                       "other_conv_math": {"mode": other, "img_per_s": round(a.batch * world * k_other / el_other, 3),
-                                           "ms_per_step": round(1000.0 * el_other / k_other, 2), "steps": k_other},
+                       "other_conv_math": None if not k_other else {
+                           "mode": other, "img_per_s": round(a.batch * world * k_other / el_other, 3),
+                           "ms_per_step": round(1000.0 * el_other / k_other, 2), "steps": k_other},
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
