@@ -314,7 +314,8 @@ def main():
     counts = dict(trainer.model.Grid_Cascade_RCNN.last_counts)
 
     roof, cpu = None, None
-    if not a.no_roofline and rank == 0:
+    if not a.no_roofline:
+        # every rank runs the two instrumented steps (they contain the gradient all-reduce); rank 0 reports its own
         roof = conv_roofline(trainer, images, targets, math=a.conv_math)
     if world > 1:
         dist.barrier()
