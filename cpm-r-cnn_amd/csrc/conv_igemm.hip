@@ -111,7 +111,9 @@ struct IgemmArgs {
 };
 
 template <int BM, int BN, int WM, int WN, bool VEC, bool SPLIT>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(64 * WM * WN)
+    __attribute__((amdgpu_waves_per_eu(2, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))) void igemm_kernel(
+        IgemmArgs a) {
   constexpr int NT = 64 * WM * WN;              // threads
   constexpr int RPP = NT / 8;                   // rows per load pass (8 threads x float4 cover a 32-float row)
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
@@ -985,16 +987,22 @@ Plan plan_igemm(const IgemmArgs& a) {
   // small tile with the reduction split until the chip holds ~4 workgroups per CU, big ones the 128x128 tile
   // with the remainder of the last round re-tiled (launch_igemm).
   struct Cand { int bm, bn, per_cu; double eff; };
-  const Cand cands[3] = {{128, 128, 2, 1.00}, {128, 64, 2, 0.86}, {64, 64, 4, 0.78}};
+  // bf16x3: the MFMA part of a k-step is ~2.5x shorter, so the fixed per-tile work weighs more and the small tiles
+  // (3-4 workgroups per CU) lose less against the big one (tools/sweep_igemm.sh, MATH=bf16x3)
+  const Cand cands_f32[3] = {{128, 128, 2, 1.00}, {128, 64, 2, 0.86}, {64, 64, 4, 0.78}};
+  const Cand cands_split_short[3] = {{128, 128, 2, 1.00}, {128, 64, 3, 0.90}, {64, 64, 4, 0.95}};
+  const Cand* cands = (g_conv_split && a.ksteps <= 40) ? cands_split_short : cands_f32;   // short reductions (1x1)
+  const double fixed = (g_conv_split && a.ksteps <= 40) ? 10.0 : 5.0;
   double best = 1e300;
-  for (const Cand& c : cands) {
+  for (int ci = 0; ci < 3; ++ci) {
+    const Cand& c = cands[ci];
     if (c.bn == 128 && a.OCg < 128) continue;
     const int64_t t = tiles(c.bm, c.bn);
     const int64_t slots = (int64_t)c.per_cu * num_cus();
     const int max_split = a.ksteps >= 32 ? a.ksteps / 16 : 1;
     for (int sp = 1; sp <= max_split && sp <= 64; ++sp) {
       const int64_t blocks = t * sp;
-      const double per_block = ((double)c.bm * c.bn * ((double)a.ksteps / sp + 5.0)) / c.eff;
+      const double per_block = ((double)c.bm * c.bn * ((double)a.ksteps / sp + fixed)) / c.eff;
       const int64_t full = blocks / slots, tail = blocks % slots;
       double rounds = (double)full;
       if (tail) {
