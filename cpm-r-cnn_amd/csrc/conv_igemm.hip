@@ -915,6 +915,53 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---- weight gradient, one input channel per group -------------------------------------------------------
+// dw[oc][tap] += sum_m dy[m][oc] * x[gather(m, tap)][group(oc)]  for Cg == 1 (the grouped ConvTranspose2d 576 -> 9 of
+// Grid_output seen from its weight gradient: 9 groups x 64 outputs x 16 taps x ONE input channel).  The MFMA tile
+// kernels would pad the single input channel to 32; here a wave owns a run of pixels, lanes are the group's output
+// channels (coalesced dy rows), the tap's input value is a wave-uniform scalar, and each lane keeps R*S <= 16 sums.
+template <int TAPS>
+__global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per_block) {
+  __shared__ float red[4][TAPS][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = blockIdx.y;
+  const int taps = a.R * a.S;
+  const int m_begin = blockIdx.x * pix_per_block, m_end = min(a.M, m_begin + pix_per_block);
+  for (int oc0 = 0; oc0 < a.OCg; oc0 += 64) {
+    const int ocl = oc0 + lane;
+    const bool live = ocl < a.OCg;
+    float acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
+    for (int m = m_begin + wave; m < m_end; m += 4) {
+      const int ow = m % a.OW, t2 = m / a.OW;
+      const int oh = t2 % a.OH, n = t2 / a.OH;
+      const float dyv = live ? a.dy[(size_t)m * a.OCtot + g * a.OCg + ocl] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        if (t < taps) {
+          const int r = t / a.S, s = t - r * a.S;
+          const int ih = oh * a.stride - a.pad + r * a.dil, iw = ow * a.stride - a.pad + s * a.dil;
+          float xv = 0.f;
+          if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+            xv = a.x[((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g];
+          acc[t] += dyv * xv;
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) red[wave][t][lane] = acc[t];
+    __syncthreads();
+    if (wave == 0 && live) {
+      for (int t = 0; t < taps; ++t) {
+        const float v = red[0][t][lane] + red[1][t][lane] + red[2][t][lane] + red[3][t][lane];
+        atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * taps + t), v);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------
 int num_cus() { return 256; }
 
@@ -1298,6 +1345,12 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   ProfScope prof_scope(s, 2);
+  if (a.Cg == 1 && taps <= 16) {
+    const int ppb = 128;
+    dim3 grid((unsigned)cpm::cdiv(a.M, ppb), (unsigned)a.groups);
+    hipLaunchKernelGGL((wgrad_cg1_kernel<16>), grid, dim3(256), 0, s, a, ppb);
+    return cpm::check_launch("conv wgrad (one channel per group)");
+  }
   const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) &&
                     (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
 #define WLAUNCH(BM, BN, WM, WN)                                                                      \

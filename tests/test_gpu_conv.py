@@ -136,7 +136,7 @@ def test_linear_and_splitk():
         assert relerr(xd.grad, xr.grad) < TOL and relerr(wd.grad, wr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
 
 
-@pytest.mark.parametrize("cin,cout,groups,hw,n", [(576, 576, 9, 7, 6), (576, 9, 9, 14, 6), (64, 32, 1, 5, 2)])
+@pytest.mark.parametrize("cin,cout,groups,hw,n", [(576, 576, 9, 7, 6), (576, 9, 9, 14, 6), (64, 32, 1, 5, 2), (300, 3, 3, 6, 2)])
 def test_conv_transpose(cin, cout, groups, hw, n):
     """grouped ConvTranspose2d k4 s2 p1 (grid_rcnn/outputs.py:24-37) through the DGRAD-mode kernel."""
     from pet.lib.ops import conv as ops
