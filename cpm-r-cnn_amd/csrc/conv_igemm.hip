@@ -923,7 +923,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int TAPS>
 __global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per_block) {
   __shared__ float red[4][TAPS][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // pixel index math and x loads go scalar
   const int g = blockIdx.y;
   const int taps = a.R * a.S;
   const int m_begin = blockIdx.x * pix_per_block, m_end = min(a.M, m_begin + pix_per_block);

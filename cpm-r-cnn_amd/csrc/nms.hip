@@ -176,16 +176,15 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
     }
     nkeep += __popcll(kept);
     if (done) break;
-    // OR the kept rows into the words of the following blocks (lanes parallel over words)
-    for (int j = blk + 1 + lane; j < nblk; j += 64) {
-      uint64_t acc = remv[j];
-      uint64_t bits = kept;
-      while (bits) {
-        const int b = __ffsll((long long)bits) - 1;
-        bits &= bits - 1;
-        acc |= m[(int64_t)(blk * 64 + b) * nblk + j];
+    // OR the kept rows into the words of the following blocks: lane b owns kept row b and streams that row's
+    // remaining words (independent loads, all in flight together) into the LDS words with ds_or_b64 -- instead
+    // of one lane per word walking up to 64 dependent loads
+    if ((kept >> lane) & 1ull) {
+      const uint64_t* rowp = m + (int64_t)row_l * nblk;
+      for (int j = blk + 1; j < nblk; ++j) {
+        const uint64_t v = rowp[j];
+        if (v) atomicOr(reinterpret_cast<unsigned long long*>(&remv[j]), (unsigned long long)v);
       }
-      remv[j] = acc;
     }
     __syncthreads();
   }
