@@ -772,9 +772,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
 
   // slot of this thread: channel vector q (16 consecutive per 16-lane group) and pixel run (4 pixels)
-  const int grp = tid >> 4, l16 = tid & 15;
-  const int qa = (grp % (QA / 16)) * 16 + l16, pra = grp / (QA / 16);     // pra < 8 for the first QA*8 threads
-  const int qb = (grp % (QB / 16)) * 16 + l16, prb = grp / (QB / 16);
+  // lane bits: [3:0] channel vector inside a block of 16, [4] low bit of the pixel run, [5..] vector block and the
+  // run's high bits.  The 32 lanes one ds_write_b64 pass serves are then 16 consecutive rows x the two 8-byte
+  // halves of one chunk: with the chunk swizzle that is every bank exactly once (pixel run in bit 4 of the row
+  // index instead would put rows r and r+16 on the same banks: a 2-way conflict on every store).
+  const int l16 = tid & 15, half_run = (tid >> 4) & 1, hi = tid >> 5;
+  const int qa = (hi % (QA / 16)) * 16 + l16, pra = (hi / (QA / 16)) * 2 + half_run;   // pra < 8 <=> thread has an A slot
+  const int qb = (hi % (QB / 16)) * 16 + l16, prb = (hi / (QB / 16)) * 2 + half_run;
   const bool a_act = pra < 8 && oc0 + 4 * qa < a.OCg;
   const bool b_act = prb < 8 && c0 + 4 * qb < a.Cg;
   unsigned a_off = (unsigned)((ch_begin * 32 + 4 * pra) * a.OCtot + g * a.OCg + oc0 + 4 * qa) * 4u;
