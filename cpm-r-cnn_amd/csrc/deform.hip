@@ -121,10 +121,12 @@ __global__ __launch_bounds__(256) void deform_col2im_kernel(const float* __restr
     for (int c = dgi * Cd + lane; c < (dgi + 1) * Cd; c += 64) {
       const int g = c / Cg, cl = c - g * Cg;
       const float gv = cb[((int64_t)g * taps + t) * Cg + cl];
-      if (v1) atomicAdd(p1 + c, w1 * gv);
-      if (v2) atomicAdd(p1 + G.C + c, w2 * gv);
-      if (v3) atomicAdd(p1 + (int64_t)G.W * G.C + c, w3 * gv);
-      if (v4) atomicAdd(p1 + (int64_t)(G.W + 1) * G.C + c, w4 * gv);
+      // a corner with zero bilinear weight adds nothing: skipping it is exact, and with integer sampling positions
+      // (the zero-initialised offset predictor of DeformConvPack, or offset == NULL) it removes 3 of the 4 atomics
+      if (v1 && w1 != 0.f) atomicAdd(p1 + c, w1 * gv);
+      if (v2 && w2 != 0.f) atomicAdd(p1 + G.C + c, w2 * gv);
+      if (v3 && w3 != 0.f) atomicAdd(p1 + (int64_t)G.W * G.C + c, w3 * gv);
+      if (v4 && w4 != 0.f) atomicAdd(p1 + (int64_t)(G.W + 1) * G.C + c, w4 * gv);
     }
   }
 }
