@@ -59,7 +59,7 @@ class _ColsConvFn(Function):
     """y = relu?( contract(columns(x, offset), w) * scale + shift )"""
 
     @staticmethod
-    def forward(ctx, x, offset, w, scale, shift, stride, pad, dil, groups, dg, relu):
+    def forward(ctx, x, offset, w, scale, shift, stride, pad, dil, groups, dg, relu, out_tag=None):
         H.require_gpu(x, offset, w, scale, shift)
         x = F.nhwc(x)
         w_in = w
@@ -74,6 +74,7 @@ class _ColsConvFn(Function):
         cols = sample_columns(x, offset, geom)
         y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups)
         ctx.geom, ctx.relu = geom, relu
+        ctx.out_tag = out_tag                      # see conv._ConvFn: gate + scale applied by the sole consumer's dgrad
         ctx.has = (scale is not None, shift is not None)
         need_cols = ctx.needs_input_grad[2]
         ctx.save_for_backward(x, offset, w, scale, y if relu else None, cols if need_cols else None)
@@ -88,7 +89,8 @@ class _ColsConvFn(Function):
         need_x, need_off, need_w, _, need_shift = ctx.needs_input_grad[:5]
         dy = F.nhwc(dy)
         dpre, dshift = dy, None
-        if ctx.relu or has_scale or (has_shift and need_shift):
+        gated = ctx.out_tag is not None and ctx.out_tag["applied"]
+        if not gated and (ctx.relu or has_scale or (has_shift and need_shift)):
             dpre_k, _, dshift = F.epilogue_backward(dy, y, scale, ctx.relu, want_dpre=ctx.relu or has_scale,
                                                     want_dshift=has_shift and need_shift)
             dpre = dpre_k if dpre_k is not None else dy
@@ -124,7 +126,7 @@ class _ColsConvFn(Function):
                         rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(offset), *args, H.ptr(doff),
                                                            H.stream())
                         H.check(rc, "deform_coord_grad")
-        return dx, doff, dw, None, dshift, None, None, None, None, None, None
+        return dx, doff, dw, None, dshift, None, None, None, None, None, None, None
 
 
 def _one(v):
@@ -135,9 +137,15 @@ def _one(v):
 
 
 def cols_conv(x, offset, weight, scale=None, shift=None, stride=1, padding=0, dilation=1, groups=1,
-              deformable_groups=1, relu=False):
-    return _ColsConvFn.apply(x, offset, weight, scale, shift, _one(stride), _one(padding), _one(dilation),
-                             int(groups), int(deformable_groups), bool(relu))
+              deformable_groups=1, relu=False, sole_consumer=False):
+    tag = None
+    if sole_consumer and relu and not (shift is not None and shift.requires_grad) and torch.is_grad_enabled():
+        tag = {"scale": scale, "applied": False}
+    y = _ColsConvFn.apply(x, offset, weight, scale, shift, _one(stride), _one(padding), _one(dilation),
+                          int(groups), int(deformable_groups), bool(relu), tag)
+    if tag is not None:
+        y._cpm_epi = tag
+    return y
 
 
 def deform_conv(input, offset, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, deformable_groups=1,
@@ -171,16 +179,16 @@ class DeformConv(nn.Module):
         if self.bias is not None:
             nn.init.constant_(self.bias, 0)
 
-    def _run(self, x, offset, scale, shift, relu):
+    def _run(self, x, offset, scale, shift, relu, sole_consumer=False):
         if shift is None:
             shift = self.bias
         else:
             assert self.bias is None
         return cols_conv(x, offset, self.weight, scale, shift, self.stride, self.padding, self.dilation, self.groups,
-                         self.deformable_groups, relu)
+                         self.deformable_groups, relu, sole_consumer)
 
-    def forward(self, x, offset, scale=None, shift=None, relu=False):
-        return self._run(x, offset, scale, shift, relu)
+    def forward(self, x, offset, scale=None, shift=None, relu=False, sole_consumer=False):
+        return self._run(x, offset, scale, shift, relu, sole_consumer)
 
     def extra_repr(self):
         return ("in_channels={in_channels}, out_channels={out_channels}, kernel_size={kernel_size}, stride={stride}, "
@@ -202,6 +210,6 @@ class DeformConvPack(DeformConv):
         self.conv_offset.weight.data.zero_()
         self.conv_offset.bias.data.zero_()
 
-    def forward(self, x, scale=None, shift=None, relu=False):
+    def forward(self, x, scale=None, shift=None, relu=False, sole_consumer=False):
         offset = self.conv_offset(x)
-        return self._run(x, offset, scale, shift, relu)
+        return self._run(x, offset, scale, shift, relu, sole_consumer)

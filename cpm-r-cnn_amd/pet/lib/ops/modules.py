@@ -22,7 +22,7 @@ class Conv2d(nn.Conv2d):
             # deep instead of zero-padding every tap of every group to a 32-deep MFMA k-step
             from .deform_conv import cols_conv
             return cols_conv(x, None, self.weight, scale, shift, self.stride, self.padding, self.dilation,
-                             self.groups, 1, relu)
+                             self.groups, 1, relu, sole_consumer)
         return F.conv2d(x, self.weight, scale, shift, residual, self.stride[0], self.padding[0], self.dilation[0],
                         self.groups, relu, res_mode, sole_consumer)
 

@@ -46,7 +46,7 @@ class Bottleneck(nn.Module):
         s, b = _affine(self.bn1)
         out = self.conv1(x, scale=s, shift=b, relu=True)
         s, b = _affine(self.bn2)
-        out = self.conv2(out, scale=s, shift=b, relu=True)
+        out = self.conv2(out, scale=s, shift=b, relu=True, sole_consumer=True)     # consumed by conv3 only
         residual = x
         if self.downsample is not None:
             s, b = _affine(self.downsample[1])
