@@ -145,19 +145,41 @@ def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None):
     return dw
 
 
-def epilogue_backward(dy, y, scale, relu, want_dpre=True, want_dres=False, want_dshift=False):
-    """Backward of relu?(v*scale+shift+res): returns (dpre, dres, dshift)."""
+def epilogue_backward(dy, y, scale, relu, want_dpre=True, want_dres=False, want_dshift=False, dshift_out=None):
+    """Backward of relu?(v*scale+shift+res): returns (dpre, dres, dshift).  `dshift_out` ([K], accumulated into)
+    replaces the fresh zero-filled bias-gradient buffer."""
     k = dy.shape[1]
     m = dy.numel() // max(k, 1)
     dpre = torch.empty_like(dy) if want_dpre else None
     dres = torch.empty_like(dy) if want_dres else None
-    dshift = torch.zeros((k,), dtype=torch.float32, device=dy.device) if want_dshift else None
+    dshift = None
+    if want_dshift:
+        dshift = dshift_out if dshift_out is not None else torch.zeros((k,), dtype=torch.float32, device=dy.device)
     if dy.numel():
         with torch.cuda.device(dy.device):
             rc = H.lib().cpm_epilogue_backward(H.ptr(dy), H.ptr(y), H.ptr(scale), int(bool(relu)), H.c_int64(m), k,
                                                H.ptr(dpre), H.ptr(dres), H.ptr(dshift), H.stream())
         H.check(rc, "epilogue_backward")
     return dpre, dres, dshift
+
+
+def _sink_of(p, needed):
+    """The parameter's slice of the flat gradient buffer, when the flat optimizer owns it and a gradient is needed."""
+    if not needed or p is None:
+        return None
+    s = getattr(p, "_cpm_grad_sink", None)
+    if s is None or s.data_ptr() == 0 or not s.is_contiguous():
+        return None
+    p._cpm_uses = getattr(p, "_cpm_uses", 0) + 1
+    return p
+
+
+def _sink_done(p):
+    p._cpm_uses -= 1
+    if p._cpm_uses == 0:
+        ready = getattr(p, "_cpm_grad_ready", None)
+        if ready is not None:
+            ready(p)
 
 
 def _wmem(w):
@@ -184,6 +206,7 @@ class _ConvFn(Function):
         ctx.wparam = w_in if (ctx.needs_input_grad[1] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         if ctx.wparam is not None:
             w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+        ctx.bparam = _sink_of(shift, shift is not None and ctx.needs_input_grad[3])
         y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
         # Epilogue-backward folded into the consumer: when the caller promises that y feeds exactly one consumer
         # (bottleneck conv1 -> conv2 -> conv3) and y = relu(conv*scale + frozen shift), y carries a tag; a consuming
@@ -216,8 +239,13 @@ class _ConvFn(Function):
         dpre, g, dshift = dy, dy, None
         if masked or want_shift:
             split_res = want_res and has_scale          # g and g*scale are both needed
+            bp = ctx.bparam if want_shift else None
             dpre_k, dres_k, dshift = epilogue_backward(dy, y, scale, relu, want_dpre=masked, want_dres=split_res,
-                                                       want_dshift=want_shift)
+                                                       want_dshift=want_shift,
+                                                       dshift_out=bp._cpm_grad_sink if bp is not None else None)
+            if bp is not None:
+                dshift = None                   # accumulated in place
+                _sink_done(bp)
             if masked:
                 dpre = dpre_k
                 g = dres_k if split_res else (dpre_k if not has_scale else None)
@@ -353,6 +381,8 @@ class _GroupNormFn(Function):
                                                    H.stream())
             H.check(rc, "groupnorm_forward")
         ctx.cfg = (groups, relu)
+        ctx.gparam = _sink_of(gamma, ctx.needs_input_grad[1])
+        ctx.bparam = _sink_of(beta, ctx.needs_input_grad[2])
         ctx.save_for_backward(x, y, gamma, mean, rstd)
         return y
 
@@ -364,14 +394,21 @@ class _GroupNormFn(Function):
         dy = nhwc(dy)
         n, c, h, w = x.shape
         dx = torch.empty_like(x)
-        dgamma = torch.zeros_like(gamma)
-        dbeta = torch.zeros_like(gamma)
+        gp, bp = ctx.gparam, ctx.bparam
+        dgamma = gp._cpm_grad_sink if gp is not None else torch.zeros_like(gamma)     # the kernel accumulates
+        dbeta = bp._cpm_grad_sink if bp is not None else torch.zeros_like(gamma)
         if n:
             with torch.cuda.device(x.device):
                 rc = H.lib().cpm_groupnorm_backward(H.ptr(dy), H.ptr(x), H.ptr(y), H.ptr(gamma), H.ptr(mean),
                                                     H.ptr(rstd), n, h * w, c, int(groups), int(bool(relu)),
                                                     H.ptr(dx), H.ptr(dgamma), H.ptr(dbeta), H.stream())
             H.check(rc, "groupnorm_backward")
+        if gp is not None:
+            dgamma = None
+            _sink_done(gp)
+        if bp is not None:
+            dbeta = None
+            _sink_done(bp)
         return dx, dgamma, dbeta, None, None, None
 
 

@@ -73,8 +73,10 @@ class FlatSGD(torch.optim.Optimizer):
         dst.copy_(p.data)
         p.data = dst
         p.grad = self._view(self.flat_grad, p, off, n)
-        if p.dim() == 4:
-            p._cpm_grad_sink = p.grad          # conv weight gradients are accumulated in place by the HIP kernel
+        if p.dim() == 4 or p.dim() == 1:
+            # conv weights, biases and GroupNorm affine parameters: the HIP backward kernels accumulate straight into
+            # this slice of the flat gradient buffer (no temporary, no autograd add)
+            p._cpm_grad_sink = p.grad
             p._cpm_uses = 0
 
     def zero_grad(self, set_to_none=False):
