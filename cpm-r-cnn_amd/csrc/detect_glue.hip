@@ -193,6 +193,35 @@ __global__ __launch_bounds__(64 * MAX_POINTS) void grid_decode_kernel(
   }
 }
 
+// RPN candidates of one FPN level: gather the top-k regression rows and their anchors, BoxCoder.decode
+// (box_coder.py:51-94: pixel-inclusive widths, dw/dh clipped before exp, x2/y2 get the -1 back) and clip_to_image
+// (bounding_box.py:233-243, remove_empty=False) -- one launch per level instead of ~35 tensor ops
+struct ImSizes { float w[64], h[64]; };
+
+__global__ __launch_bounds__(256) void rpn_decode_kernel(const float4* __restrict__ reg, const int64_t* __restrict__ idx,
+                                                         const float4* __restrict__ anchors, int N, int A, int k,
+                                                         float wx, float wy, float ww, float wh, float clip,
+                                                         ImSizes sz, float4* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * k) return;
+  const int n = i / k;
+  const int64_t j = idx[i];
+  const float4 b = anchors[j], c = reg[(int64_t)n * A + j];
+  const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
+  const float cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+  const float dx = c.x / wx, dy = c.y / wy;
+  const float dw = fminf(c.z / ww, clip), dh = fminf(c.w / wh, clip);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  const float mx = sz.w[n] - 1.f, my = sz.h[n] - 1.f;
+  float4 o;
+  o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), mx);
+  o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), my);
+  o.z = fminf(fmaxf(pcx + 0.5f * pw - 1.f, 0.f), mx);
+  o.w = fminf(fmaxf(pcy + 0.5f * ph - 1.f, 0.f), my);
+  out[i] = o;
+}
+
 int fill_geom(GridGeom& G, int points, int map_size, const int* sub_xy, const int64_t* strides) {
   if (points <= 0 || points > MAX_POINTS) return -1;
   int gs = 1;
@@ -263,4 +292,20 @@ CPM_EXPORT int cpm_grid_decode(const float* logits, const int64_t* strides, cons
                      (const float4*)rois, G, mapping_ratio, roi_img, (const float4*)gts, gt_off, (float4*)out_boxes,
                      keep);
   return cpm::check_launch("grid_decode");
+}
+
+CPM_EXPORT int cpm_rpn_decode(const float* reg, const int64_t* topk_idx, const float* anchors, int N, int A, int k,
+                              const float* weights4, float clip, const float* im_w, const float* im_h,
+                              float* out_boxes, void* stream) {
+  CPM_REQUIRE(N >= 0 && A >= 0 && k >= 0 && N <= 64, "bad sizes (at most 64 images per call)");
+  if (N == 0 || k == 0) return CPM_OK;
+  CPM_REQUIRE(reg && topk_idx && anchors && weights4 && im_w && im_h && out_boxes, "null pointer");
+  CPM_REQUIRE((((uintptr_t)reg | (uintptr_t)anchors | (uintptr_t)out_boxes) & 15) == 0, "boxes must be 16-byte aligned");
+  ImSizes sz;
+  for (int n = 0; n < N; ++n) { sz.w[n] = im_w[n]; sz.h[n] = im_h[n]; }
+  const int total = N * k;
+  hipLaunchKernelGGL(rpn_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)reg, topk_idx, (const float4*)anchors, N, A, k, weights4[0], weights4[1],
+                     weights4[2], weights4[3], clip, sz, (float4*)out_boxes);
+  return cpm::check_launch("rpn_decode");
 }

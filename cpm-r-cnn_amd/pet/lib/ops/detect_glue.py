@@ -111,3 +111,23 @@ def grid_decode(logits, rois, map_size, sub_regions, mapping_ratio, roi_img=None
                                      H.ptr(keep), H.stream())
     H.check(rc, "grid_decode")
     return (out, keep.bool()) if keep is not None else out
+
+
+def rpn_decode(reg, topk_idx, anchors, weights, clip, image_sizes):
+    """reg [N, A, 4] (contiguous), topk_idx [N, k] int64, anchors [A, 4]; image_sizes list of (w, h).
+    Returns decoded + clipped boxes [N, k, 4]."""
+    H.require_gpu(reg, anchors)
+    N, A = reg.shape[0], reg.shape[1]
+    k = topk_idx.shape[1]
+    reg = reg if reg.is_contiguous() else reg.contiguous()
+    anchors = _boxes(anchors)
+    idx = topk_idx.contiguous()
+    out = torch.empty((N, k, 4), dtype=torch.float32, device=reg.device)
+    w4 = (ctypes.c_float * 4)(*[float(v) for v in weights])
+    iw = (ctypes.c_float * N)(*[float(s[0]) for s in image_sizes])
+    ih = (ctypes.c_float * N)(*[float(s[1]) for s in image_sizes])
+    with torch.cuda.device(reg.device):
+        rc = H.lib().cpm_rpn_decode(H.ptr(reg), H.ptr(idx), H.ptr(anchors), N, A, k, w4, H.f(clip), iw, ih, H.ptr(out),
+                                    H.stream())
+    H.check(rc, "rpn_decode")
+    return out

@@ -4,8 +4,12 @@ Same pipeline -- per level: sigmoid, top-k, BoxCoder.decode, clip, min-size filt
 cross-level top-k (per batch in training, per image in testing) and the GT append -- but the reference's
 N_images x N_levels separate NMS calls (each with a device->host mask copy) become ONE batched device NMS
 (cpm_nms_batched) over all (image, level) segments."""
+import os
+
+import numpy as np
 import torch
 
+import pet.lib.ops as ops
 from pet.lib.ops import nms_segments
 from pet.rcnn.core.config import cfg
 from pet.rcnn.utils.box_coder import BoxCoder
@@ -23,6 +27,8 @@ class RPNPostProcessor(torch.nn.Module):
         self.box_coder = box_coder if box_coder is not None else BoxCoder(weights=(1.0, 1.0, 1.0, 1.0))
         self.fpn_post_nms_top_n = post_nms_top_n if fpn_post_nms_top_n is None else fpn_post_nms_top_n
         self.fpn_post_nms_per_batch = fpn_post_nms_per_batch
+        # CPM_FUSED_GLUE=0 runs the per-level / per-image tensor-op formulation below (the in-tree cross-check)
+        self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
 
     def add_gt_proposals(self, proposals, targets):
         device = proposals[0].bbox.device
@@ -52,7 +58,88 @@ class RPNPostProcessor(torch.nn.Module):
             boxes[n, :, 3].clamp_(min=0, max=h - 1)
         return scores, boxes
 
+    def _forward_fused(self, anchors, objectness, box_regression, targets=None):
+        """Same selection as forward() below with the per-level decode in one kernel (cpm_rpn_decode), every
+        post-NMS gather done once for the whole batch from host-built index lists, and two host round trips in all
+        (NMS counts, cross-level top-k mask) instead of one per image and boolean index."""
+        num_levels, N = len(objectness), objectness[0].shape[0]
+        dev = objectness[0].device
+        sizes = [per_img[0].size for per_img in anchors]
+        seg_boxes, seg_scores, offsets, owner = [], [], [0], []
+        for lvl, (o, b) in enumerate(zip(objectness, box_regression)):
+            _, A, H, W = o.shape
+            scores = permute_and_flatten(o, N, A, 1, H, W).view(N, -1).sigmoid()
+            reg = permute_and_flatten(b, N, A, 4, H, W)
+            k = min(self.pre_nms_top_n, A * H * W)
+            scores, idx = scores.topk(k, dim=1, sorted=True)
+            boxes = ops.rpn_decode(reg, idx, anchors[0][lvl].bbox, self.box_coder.weights,
+                                   self.box_coder.bbox_xform_clip, sizes)
+            seg_boxes.append(boxes.view(N * k, 4))
+            seg_scores.append(scores.reshape(N * k))
+            for n in range(N):
+                offsets.append(offsets[-1] + k)
+                owner.append(n)
+        all_boxes, all_scores = torch.cat(seg_boxes, 0), torch.cat(seg_scores, 0)
+        keep, counts = nms_segments(all_boxes, all_scores, None, offsets, self.nms_thresh, 0)
+        counts = counts.tolist()                               # host round trip 1
+        # rows of `keep` to read, image-major then level-major (= cat_boxlist of the per-level lists), and the
+        # segment base to add to the segment-relative indices stored there
+        pos, base, per_image = [], [], [0] * N
+        for n in range(N):
+            for s_, own in enumerate(owner):
+                if own != n:
+                    continue
+                c = counts[s_] if self.post_nms_top_n <= 0 else min(counts[s_], self.post_nms_top_n)
+                pos.append(np.arange(offsets[s_], offsets[s_] + c))
+                base.append(np.full(c, offsets[s_]))
+                per_image[n] += c
+        pb = torch.from_numpy(np.stack([np.concatenate(pos), np.concatenate(base)])).pin_memory().to(dev, non_blocking=True)
+        sel = keep[pb[0]] + pb[1]                              # absolute rows of all_boxes / all_scores
+        obj = all_scores[sel]
+        if num_levels > 1:
+            if self.training and self.fpn_post_nms_per_batch:
+                k2 = min(self.fpn_post_nms_top_n, obj.numel())
+                _, inds = torch.topk(obj, k2, dim=0, sorted=True)
+                mask = torch.zeros(obj.numel(), dtype=torch.bool, device=dev)
+                mask[inds] = True
+                mask_h = mask.cpu().numpy()                    # host round trip 2
+                chosen, o_ = [], 0
+                for n in range(N):
+                    idx_n = np.flatnonzero(mask_h[o_:o_ + per_image[n]]) + o_
+                    o_ += per_image[n]
+                    per_image[n] = len(idx_n)
+                    chosen.append(idx_n)
+                ch = torch.from_numpy(np.concatenate(chosen)).pin_memory().to(dev, non_blocking=True)
+            else:
+                chosen, o_ = [], 0
+                for n in range(N):
+                    seg = obj[o_:o_ + per_image[n]]
+                    _, inds = torch.topk(seg, min(self.fpn_post_nms_top_n, seg.numel()), dim=0, sorted=True)
+                    chosen.append(inds + o_)
+                    o_ += per_image[n]
+                    per_image[n] = inds.numel()
+                ch = torch.cat(chosen)
+            sel, obj = sel[ch], obj[ch]
+        boxes = all_boxes[sel]
+        if self.training and targets is not None:              # add_gt_proposals: one cat per field for the batch
+            bparts, oparts, o_ = [], [], 0
+            for n in range(N):
+                bparts += [boxes[o_:o_ + per_image[n]], targets[n].bbox]
+                oparts += [obj[o_:o_ + per_image[n]], torch.ones(len(targets[n]), device=dev)]
+                o_ += per_image[n]
+                per_image[n] += len(targets[n])
+            boxes, obj = torch.cat(bparts, 0), torch.cat(oparts, 0)
+        out, o_ = [], 0
+        for n in range(N):
+            bl = BoxList(boxes[o_:o_ + per_image[n]], sizes[n], mode="xyxy")
+            bl.add_field("objectness", obj[o_:o_ + per_image[n]])
+            out.append(bl)
+            o_ += per_image[n]
+        return out
+
     def forward(self, anchors, objectness, box_regression, targets=None):
+        if self.fused_glue and self.min_size <= 0 and objectness[0].is_cuda and objectness[0].shape[0] <= 64:
+            return self._forward_fused(anchors, objectness, box_regression, targets)
         num_levels, N = len(objectness), objectness[0].shape[0]
         per_level_anchors = list(zip(*anchors))
         seg_boxes, seg_scores, offsets, owner = [], [], [0], []

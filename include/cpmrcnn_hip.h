@@ -207,6 +207,14 @@ int cpm_grid_decode(const float* logits, const int64_t* strides, const float* ro
                     const int* sub_xy, float mapping_ratio, const int* roi_img, const float* gts, const int* gt_off,
                     float* out_boxes, unsigned char* keep, void* stream);
 
+/* cpm_rpn_decode: one FPN level of RPNPostProcessor.forward_for_single_feature_map (rpn/inference.py:67-99) after
+ * the top-k: gather regression rows + anchors, BoxCoder.decode (utils/box_coder.py:51-94), clip_to_image.
+ * reg [N][A][4] (NHWC head output viewed per anchor), topk_idx [N][k] int64 into A, anchors [A][4] (shared by the
+ * images), weights4 / im_w / im_h HOST arrays (4 / N / N); out_boxes [N][k][4]. */
+int cpm_rpn_decode(const float* reg, const int64_t* topk_idx, const float* anchors, int N, int A, int k,
+                   const float* weights4, float clip, const float* im_w, const float* im_h, float* out_boxes,
+                   void* stream);
+
 /* ---- GroupNorm (+ReLU), NHWC ----------------------------------------------
  * Replaces nn.GroupNorm + nn.ReLU in grid_heads.py:47-55 and outputs.py:23,68.
  * x [N,HW,C]; mean/rstd [N,G] saved for backward; dgamma/dbeta accumulate.      */

@@ -249,3 +249,60 @@ def test_fused_cls_subsample_properties():
     finally:
         m.Grid_Cascade_RCNN.cls_loss_evaluator.fused_glue = True
         config.reset_cfg()
+
+
+def test_fused_rpn_proposals_equal_per_level_path(oracle):
+    """cpm_rpn_decode vs the C oracle's BoxCoder.decode, and the batch-fused proposal selection (one decode kernel
+    per level, batched gathers, 2 host round trips) vs the per-level / per-image formulation: same proposals."""
+    import pet.lib.ops as ops
+    from test_gpu_model import synthetic_batch
+    from pet.utils.data.structures.image_list import to_image_list
+    rng = np.random.default_rng(21)
+    A, N, k = 5000, 2, 700
+    anchors = _rand_boxes(rng, A, 800, 600, 8, 400)
+    reg = rng.normal(0, 0.5, (N, A, 4)).astype(np.float32)
+    reg[0, :50, 2:] = 9.0                                             # beyond the log(1000/16) clip
+    idx = np.stack([rng.permutation(A)[:k] for _ in range(N)]).astype(np.int64)
+    sizes = [(800, 600), (640, 480)]
+    got = ops.rpn_decode(torch.from_numpy(reg).cuda(), torch.from_numpy(idx).cuda(), torch.from_numpy(anchors).cuda(),
+                         (1.0, 1.0, 1.0, 1.0), float(np.log(1000. / 16)), sizes).cpu().numpy()
+    for n in range(N):
+        want = oracle.box_decode(reg[n][idx[n]], anchors[idx[n]])
+        w, h = sizes[n]
+        want = np.stack([want[:, 0].clip(0, w - 1), want[:, 1].clip(0, h - 1), want[:, 2].clip(0, w - 1),
+                         want[:, 3].clip(0, h - 1)], 1)
+        np.testing.assert_allclose(got[n], want, rtol=1e-5, atol=1e-3)
+    m, config = _small_model()
+    try:
+        images, targets = synthetic_batch(2, 256, 320, 6, seed=9)
+        targets = [t.to("cuda") for t in targets]
+        il = to_image_list(images.cuda())
+        with torch.no_grad():
+            feats = m.Conv_Body_FPN(m.Conv_Body(il.tensors.contiguous(memory_format=torch.channels_last)))
+            obj, reg_ = m.RPN.head(feats)
+            anc = m.RPN.anchor_generator(il, feats)
+            sel = m.RPN.box_selector_train
+            sel.train()
+            outs = []
+            for fused in (True, False):
+                sel.fused_glue = fused
+                outs.append(sel(anc, obj, reg_, targets))
+            sel.fused_glue = True
+        for a, b in zip(*outs):
+            assert len(a) == len(b) and a.fields() == b.fields() == ["objectness"]
+            np.testing.assert_allclose(a.bbox.cpu().numpy(), b.bbox.cpu().numpy(), rtol=1e-5, atol=1e-3)
+            np.testing.assert_allclose(a.get_field("objectness").cpu().numpy(), b.get_field("objectness").cpu().numpy(),
+                                       rtol=1e-6)
+        sel_t = m.RPN.box_selector_test
+        sel_t.eval()
+        with torch.no_grad():
+            outs = []
+            for fused in (True, False):
+                sel_t.fused_glue = fused
+                outs.append(sel_t(anc, obj, reg_))
+            sel_t.fused_glue = True
+        for a, b in zip(*outs):
+            assert len(a) == len(b)
+            np.testing.assert_allclose(a.bbox.cpu().numpy(), b.bbox.cpu().numpy(), rtol=1e-5, atol=1e-3)
+    finally:
+        config.reset_cfg()
