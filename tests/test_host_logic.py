@@ -189,3 +189,34 @@ def test_x101_dcn_state_dict_abi(cpm_cfg):
     assert len(packs) == 4 + 23 + 3
     assert all(float(m.conv_offset.weight.detach().abs().max()) == 0 and float(m.conv_offset.bias.detach().abs().max()) == 0
                for m in packs)                                    # resnext.py:248-252
+
+
+def test_batch_pos_neg_sample_quotas():
+    """pet/rcnn/utils/fused_sampling.py (pure torch, runs on the CPU): per image at most batch*fraction positives, the
+    rest negatives up to the batch size, never an ignored candidate, every bucket uniformly sampled."""
+    from pet.rcnn.utils.fused_sampling import batch_pos_neg_sample
+    g = torch.Generator().manual_seed(0)
+    n_img, R = 3, 6000
+    img = torch.randint(0, n_img, (R,), generator=g)
+    lab = torch.randint(-1, 3, (R,), generator=g)                       # -1 ignore, 0 negative, 1..2 positive
+    lab[(img == 1) & (lab >= 1)] = 0                                   # image 1: ...
+    lab[(img == 1) & (torch.arange(R) % 97 == 0)] = 2                  # ... only a handful of positives
+    torch.manual_seed(1)
+    pos, neg = batch_pos_neg_sample(lab, img, n_img, 512, 0.25)
+    assert not bool((pos & (lab < 1)).any()) and not bool((neg & (lab != 0)).any())
+    for i in range(n_img):
+        m = img == i
+        n_pos_avail, n_neg_avail = int(((lab >= 1) & m).sum()), int(((lab == 0) & m).sum())
+        n_pos, n_neg = int((pos & m).sum()), int((neg & m).sum())
+        assert n_pos == min(128, n_pos_avail)
+        assert n_neg == min(512 - n_pos, n_neg_avail)
+    # uniformity: over many draws every positive of image 0 is picked with probability 128 / available
+    m0 = (img == 0) & (lab >= 1)
+    hits = torch.zeros(R)
+    for s in range(60):
+        torch.manual_seed(100 + s)
+        p, _ = batch_pos_neg_sample(lab, img, n_img, 512, 0.25)
+        hits += p.float()
+    rate = hits[m0] / 60
+    expect = 128 / int(m0.sum())
+    assert abs(float(rate.mean()) - expect) < 1e-6 and float(rate.max()) < expect + 0.35 and float(rate.min()) >= 0
