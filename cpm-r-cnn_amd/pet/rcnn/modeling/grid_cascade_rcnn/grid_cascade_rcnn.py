@@ -159,7 +159,7 @@ class GridCascadeRCNN(nn.Module):
             losses["loss_grid_%d" % (s + 1)] = loss_grid * self.stage_loss_weight[s]
             if G.IOU_HELPER and last:
                 iou_target = torch.stack([1 - max_iou, max_iou], dim=1)
-                losses["loss_iou_%d" % (s + 1)] = ops.l2_loss(iou_logits, iou_target) * G.IOU_LOSS_WEIGHT
+                losses["loss_iou_%d" % (s + 1)] = ops.l2_loss_nosync(iou_logits, iou_target) * G.IOU_LOSS_WEIGHT
             if last:
                 break
             with torch.no_grad():
@@ -228,7 +228,11 @@ def get_full_sample_boxes(cls_proposals, grid_proposals):
     """RSM sample = negatives of the cls sample + the refined positives (grid_cascade_rcnn.py:231-245)."""
     out = []
     for c, g in zip(cls_proposals, grid_proposals):
-        inds = (c.get_field("labels") <= 0).nonzero().squeeze(1)
+        hl = getattr(c, "host_labels", None)
+        if hl is not None and len(hl) == len(c):
+            inds = torch.from_numpy(np.flatnonzero(hl <= 0)).pin_memory().to(c.bbox.device, non_blocking=True)
+        else:
+            inds = (c.get_field("labels") <= 0).nonzero().squeeze(1)
         if cfg.GRID_RCNN.RESCORE_OPTION.KEEP_RATIO:
             neg_num = g.bbox.shape[0] * 3
             if neg_num <= inds.shape[0]:

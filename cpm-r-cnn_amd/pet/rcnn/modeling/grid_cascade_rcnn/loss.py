@@ -62,8 +62,11 @@ class CLSLossComputation(object):
         lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1, lab)
         pos, neg = batch_pos_neg_sample(lab, img, n_img, self.fg_bg_sampler.batch_size_per_image,
                                         self.fg_bg_sampler.positive_fraction)
-        take_h = (pos | neg).cpu().numpy()                                  # the one host round trip
-        idx_h = np.flatnonzero(take_h)
+        # the one host round trip: the selection mask, carrying the labels of the selected rows along (-2 = not
+        # selected) so that later label-driven selections (positives for the grid branch, negatives for the RSM
+        # sample) are made on the host without another device query
+        lab_h = torch.where(pos | neg, lab, -2).cpu().numpy()
+        idx_h = np.flatnonzero(lab_h != -2)
         new_counts = np.bincount(img_h[idx_h], minlength=n_img).tolist()
         idx = torch.from_numpy(idx_h).pin_memory().to(dev, non_blocking=True)
         fields = {f: torch.cat([p.get_field(f) for p in proposals], dim=0)[idx] for f in proposals[0].fields()
@@ -75,6 +78,7 @@ class CLSLossComputation(object):
             bl = BoxList(sel[o:o + new_counts[i]], proposals[i].size, proposals[i].mode)
             for f, v in fields.items():
                 bl.add_field(f, v[o:o + new_counts[i]])
+            bl.host_labels = lab_h[idx_h[o:o + new_counts[i]]]       # numpy copy of the "labels" field
             out.append(bl)
             o += new_counts[i]
         self._proposals = out

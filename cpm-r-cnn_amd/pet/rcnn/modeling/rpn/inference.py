@@ -58,7 +58,7 @@ class RPNPostProcessor(torch.nn.Module):
             boxes[n, :, 3].clamp_(min=0, max=h - 1)
         return scores, boxes
 
-    def _forward_fused(self, anchors, objectness, box_regression, targets=None):
+    def start_fused(self, anchors, objectness, box_regression):
         """Same selection as forward() below with the per-level decode in one kernel (cpm_rpn_decode), every
         post-NMS gather done once for the whole batch from host-built index lists, and two host round trips in all
         (NMS counts, cross-level top-k mask) instead of one per image and boolean index."""
@@ -81,7 +81,21 @@ class RPNPostProcessor(torch.nn.Module):
                 owner.append(n)
         all_boxes, all_scores = torch.cat(seg_boxes, 0), torch.cat(seg_scores, 0)
         keep, counts = nms_segments(all_boxes, all_scores, None, offsets, self.nms_thresh, 0)
-        counts = counts.tolist()                               # host round trip 1
+        # host round trip 1, split in two: the kept counts travel to pinned memory behind the NMS kernels and an
+        # event marks the copy; the caller may queue unrelated device work (the RPN loss) before finish() waits for
+        # that event only -- the device then stays busy while the host builds the index lists below
+        counts_h = torch.empty(counts.shape, dtype=counts.dtype).pin_memory()
+        counts_h.copy_(counts, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return dict(num_levels=num_levels, N=N, dev=dev, sizes=sizes, offsets=offsets, owner=owner, all_boxes=all_boxes,
+                    all_scores=all_scores, keep=keep, counts_h=counts_h, event=ev)
+
+    def finish_fused(self, st, targets=None):
+        num_levels, N, dev, sizes, offsets, owner = (st[k] for k in ("num_levels", "N", "dev", "sizes", "offsets", "owner"))
+        all_boxes, all_scores, keep = st["all_boxes"], st["all_scores"], st["keep"]
+        st["event"].synchronize()
+        counts = st["counts_h"].tolist()
         # rows of `keep` to read, image-major then level-major (= cat_boxlist of the per-level lists), and the
         # segment base to add to the segment-relative indices stored there
         pos, base, per_image = [], [], [0] * N
@@ -137,9 +151,12 @@ class RPNPostProcessor(torch.nn.Module):
             o_ += per_image[n]
         return out
 
+    def can_fuse(self, objectness):
+        return self.fused_glue and self.min_size <= 0 and objectness[0].is_cuda and objectness[0].shape[0] <= 64
+
     def forward(self, anchors, objectness, box_regression, targets=None):
-        if self.fused_glue and self.min_size <= 0 and objectness[0].is_cuda and objectness[0].shape[0] <= 64:
-            return self._forward_fused(anchors, objectness, box_regression, targets)
+        if self.can_fuse(objectness):
+            return self.finish_fused(self.start_fused(anchors, objectness, box_regression), targets)
         num_levels, N = len(objectness), objectness[0].shape[0]
         per_level_anchors = list(zip(*anchors))
         seg_boxes, seg_scores, offsets, owner = [], [], [0], []

@@ -49,11 +49,21 @@ class RPNModule(nn.Module):
         return self._forward_test(anchors, objectness, rpn_box_regression)
 
     def _forward_train(self, anchors, objectness, rpn_box_regression, targets):
+        sel = self.box_selector_train
         if cfg.MODEL.RPN_ONLY:
             boxes = anchors
+        elif sel.can_fuse(objectness):
+            # proposals up to the NMS, then the (host-sync-free) loss kernels, then the rest of the selection: the
+            # loss runs on the device while the host waits for the NMS counts and builds the proposal lists
+            with torch.no_grad():
+                pending = sel.start_fused(anchors, objectness, rpn_box_regression)
+            loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+            with torch.no_grad():
+                boxes = sel.finish_fused(pending, targets)
+            return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
         else:
             with torch.no_grad():
-                boxes = self.box_selector_train(anchors, objectness, rpn_box_regression, targets)
+                boxes = sel(anchors, objectness, rpn_box_regression, targets)
         loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
         return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
 

@@ -32,6 +32,16 @@ def keep_only_positive_boxes(boxes, roi_batch_size=-1, across_sample=False):
     out = []
     if (not across_sample) or len(boxes) < 2:
         for b in boxes:
+            hl = getattr(b, "host_labels", None)
+            if hl is not None and len(hl) == len(b):
+                # labels already on the host (fused sampler): choose on the host, one asynchronous index upload
+                import numpy as np
+                inds_h = np.flatnonzero(hl > 0)
+                if 0 < roi_batch_size < len(inds_h):
+                    inds_h = inds_h[torch.randperm(len(inds_h))[:roi_batch_size].numpy()]
+                inds = torch.from_numpy(inds_h).pin_memory().to(b.bbox.device, non_blocking=True)
+                out.append(b[inds])
+                continue
             inds = (b.get_field("labels") > 0).nonzero().squeeze(1)
             if 0 < roi_batch_size < inds.shape[0]:
                 inds = inds[torch.randperm(inds.shape[0], device=inds.device)[:roi_batch_size]]

@@ -220,3 +220,23 @@ def test_batch_pos_neg_sample_quotas():
     rate = hits[m0] / 60
     expect = 128 / int(m0.sum())
     assert abs(float(rate.mean()) - expect) < 1e-6 and float(rate.max()) < expect + 0.35 and float(rate.min()) >= 0
+
+
+def test_l2_loss_nosync_matches_reference_quirk(golden_ops):
+    """The sync-free restatement of l2_loss (used by the fused cascade path) against the bit-exact one, including
+    the reference's row/column index quirk, on the golden input and on random targets with zeros."""
+    from pet.lib.ops.losses import l2_loss, l2_loss_nosync
+    g = golden_ops
+    x, t = torch.from_numpy(g["l2_x"]), torch.from_numpy(g["l2_t"])
+    assert abs(float(l2_loss_nosync(x, t)) - float(l2_loss(x, t))) <= 1e-6 * abs(float(l2_loss(x, t)))
+    gen = torch.Generator().manual_seed(3)
+    for _ in range(5):
+        x = torch.randn(37, 2, generator=gen)
+        fg = torch.rand(37, generator=gen)
+        fg[torch.rand(37, generator=gen) < 0.3] = 0.0
+        fg[torch.rand(37, generator=gen) < 0.1] = 1.0
+        t = torch.stack([1 - fg, fg], 1)
+        a, b = float(l2_loss_nosync(x, t)), float(l2_loss(x, t))
+        assert abs(a - b) <= 1e-5 * abs(b) + 1e-9
+    z = torch.zeros(5, 2)
+    assert float(l2_loss_nosync(torch.randn(5, 2, generator=gen), z)) == 0.0
