@@ -200,6 +200,61 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
             "all_conv_kernels": allc}
 
 
+def hbm_kernel_rooflines(device, batch, h, w, rois_per_head):
+    """the HBM-bound custom kernels against the ~8 TB/s HBM3E peak, timed with events on the launch
+    stream (the C-ABI launches run on torch's current stream).  Algorithmic bytes as defined there:
+    RoIAlign fwd = output + min(pyramid, 16 taps x output) + rois; bwd = the same with roles swapped + the zero-fill
+    of the gradient pyramid; NMS = 36 B per box (boxes, scores, labels-free -> 28 B here: 16 + 4 + 8 out)."""
+    import pet.lib.ops as ops
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    scales = (1 / 4., 1 / 8., 1 / 16., 1 / 32.)
+    feats = [torch.randn(batch, 256, hp // st, wp // st, generator=gen).to(device).contiguous(
+        memory_format=torch.channels_last).requires_grad_(True) for st in (4, 8, 16, 32)]
+    K = int(rois_per_head)
+    x1, y1 = torch.rand(K, generator=gen) * (w - 64), torch.rand(K, generator=gen) * (h - 64)
+    bw, bh = torch.rand(K, generator=gen) * 300 + 32, torch.rand(K, generator=gen) * 300 + 32
+    rois = torch.stack([torch.randint(0, batch, (K,), generator=gen).float(), x1, y1, (x1 + bw).clamp(max=w - 1),
+                        (y1 + bh).clamp(max=h - 1)], 1).to(device)
+    pyramid = sum(f.numel() for f in feats) * 4
+
+    def timed(fn, n=10):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e-3
+
+    out = {}
+    y = ops.roi_align_fpn(feats, rois, (7, 7), scales, 2)
+    out_bytes = y.numel() * 4
+    t = timed(lambda: ops.roi_align_fpn(feats, rois, (7, 7), scales, 2))
+    nb = out_bytes + min(pyramid, 16 * out_bytes) + 20 * K
+    out["roi_align_fwd (K=%d, 7x7, 4 levels)" % K] = (nb, t)
+    gy = torch.randn_like(y)
+
+    def bwd():
+        for f in feats:
+            f.grad = None
+        ops.roi_align_fpn(feats, rois, (7, 7), scales, 2).backward(gy)
+    t_fb = timed(bwd)
+    out["roi_align_bwd (same, incl. zero-fill of the gradient pyramid)"] = (nb + pyramid, max(t_fb - t, 1e-9))
+    n_seg, per = 10, 2000
+    xy = torch.rand(n_seg * per, 2, generator=gen) * torch.tensor([w - 64., h - 64.])
+    boxes = torch.cat([xy, xy + torch.rand(n_seg * per, 2, generator=gen) * 300 + 16], 1).to(device)
+    scores = torch.rand(n_seg * per, generator=gen).to(device)
+    offs = [i * per for i in range(n_seg + 1)]
+    t = timed(lambda: ops.nms_segments(boxes, scores, None, offs, 0.7, 0))
+    out["nms_batched (10 segments x 2000 boxes, thr 0.7)"] = (28 * n_seg * per, t)
+    return [{"kernel": k, "bound": "hbm", "algorithmic_bytes": int(b), "us": round(t * 1e6, 1),
+             "achieved": round(b / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(b / t / 8e12, 4)}
+            for k, (b, t) in out.items()]
+
+
 def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3)):
     """oracle/cpu_model.py on the host cores: forward+backward conv/FC/RoIAlign work of one training iteration
     for ONE image (bounded sample), RoI counts = this run's per-image averages."""
@@ -338,6 +393,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_other = float(t.item())
         _hip.set_conv_math(a.conv_math)
+    hbm = None
+    if not a.no_roofline and rank == 0:
+        hbm = hbm_kernel_rooflines(device, a.batch, a.height, a.width, counts.get("cls", 512 * a.batch))
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.body == "resnet":
         cpu = cpu_baseline(trainer, a.height, a.width, 99, layers)   # (the scalar deformable-conv oracle is too
         #                                                              slow to be a bounded sample for x101dcn)
@@ -364,7 +422,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:
