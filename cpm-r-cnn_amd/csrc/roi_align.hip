@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
                                                           int W, float scale, int PH, int PW, int sampling_ratio,
                                                           bool aligned, float* __restrict__ gin) {
   const int n = blockIdx.x;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const float* roi = rois + 5 * (size_t)n;
   if (FPN) {
     int lv = map_level(roi, L);
@@ -197,6 +197,39 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
     if (bin >= nbins) break;
     const int ph = bin / PW, pw = bin - ph * PW;
     const float* gsrc = grad + ((size_t)n * nbins + bin) * C;
+    if (INTERP == 0 && g.grid_h * g.grid_w <= 4) {
+      // The kernel runs at the chip's float-atomic rate, and the 2x2 samples of a bin sit half a bin apart: on the
+      // RoI's own pyramid level a 7x7 bin spans 1-2 pixels and a 14x14 bin half of that, so the samples' corner
+      // pixels overlap (typically 9 -- or 4 -- distinct pixels instead of 16).  All of this is wave-uniform:
+      // collect the (pixel, weight) pairs of the bin, merge equal pixels, drop zero weights, then one atomic per
+      // distinct pixel and channel.
+      int px[16];
+      float wt[16];
+      int ne = 0;
+      for (int iy = 0; iy < g.grid_h; ++iy) {
+        const float yy = g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
+        for (int ix = 0; ix < g.grid_w; ++ix) {
+          const float xx = g.start_w + (float)pw * g.bin_w + ((float)ix + .5f) * g.bin_w / (float)g.grid_w;
+          const Tap t = bilinear_tap(H, W, yy, xx);
+          if (!t.valid) continue;
+          const int tp[4] = {t.p0, t.p1, t.p2, t.p3};
+          const float tw[4] = {t.w0 / count, t.w1 / count, t.w2 / count, t.w3 / count};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (tw[k] == 0.f) continue;
+            bool merged = false;
+            for (int j = 0; j < ne; ++j)
+              if (px[j] == tp[k]) { wt[j] += tw[k]; merged = true; break; }
+            if (!merged) { px[ne] = tp[k]; wt[ne] = tw[k]; ++ne; }
+          }
+        }
+      }
+      for (int c = lane; c < C; c += 64) {
+        const float go = gsrc[c];
+        for (int j = 0; j < ne; ++j) atomicAdd(dst + (size_t)px[j] * C + c, go * wt[j]);
+      }
+      continue;
+    }
     for (int iy = 0; iy < g.grid_h; ++iy) {
       const float yy = g.start_h + (float)ph * g.bin_h + ((float)iy + .5f) * g.bin_h / (float)g.grid_h;
       for (int ix = 0; ix < g.grid_w; ++ix) {
