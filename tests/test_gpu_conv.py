@@ -228,3 +228,24 @@ def test_sole_consumer_chain_gated_dgrad(stride2):
     slack = 1e-3 * float(pre1.sum()) + TOL
     assert relerr(xg.grad, xr.grad) < slack and relerr(w1g.grad, w1r.grad) < slack
     assert relerr(w2g.grad, w2r.grad) < TOL
+
+
+def test_error_bound_of_both_arithmetics_wide_dynamic_range(conv_math):
+    """Error of a conv output against a float64 reference, measured against the natural scale sum|x||w| (so that
+    cancellation cannot hide it), on inputs spanning 8 decades: the exact-f32 MFMA chain stays at fp32 rounding
+    (<= 2e-6) and the 3-term split-bf16 scheme at its dropped lo*lo term + bf16 rounding of lo (<= 3e-5)."""
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 96, 13, 17, generator=g) * torch.pow(10.0, torch.randint(-4, 5, (2, 96, 13, 17), generator=g).float())
+    w = torch.randn(64, 96, 3, 3, generator=g) * torch.pow(10.0, torch.randint(-3, 2, (64, 96, 3, 3), generator=g).float())
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    scale = F.conv2d(x.double().abs(), w.double().abs(), None, 1, 1)
+    cl = torch.channels_last
+    y = ops.conv2d(x.cuda().contiguous(memory_format=cl), w.cuda().contiguous(memory_format=cl), None, None, None, 1, 1)
+    err = float(((y.cpu().double() - ref).abs() / scale).max())
+    assert err < (2e-6 if conv_math == "f32" else 3e-5), (conv_math, err)
+    dx = ops.conv.conv2d_backward_data(y.detach(), w.cuda().contiguous(memory_format=cl), tuple(x.shape), 1, 1, 1, 1)
+    ref_dx = F.conv_transpose2d(y.detach().cpu().double(), w.double(), None, 1, 1)
+    sc_dx = F.conv_transpose2d(y.detach().cpu().double().abs(), w.double().abs(), None, 1, 1)
+    err = float(((dx.cpu().double() - ref_dx).abs() / sc_dx).max())
+    assert err < (2e-6 if conv_math == "f32" else 3e-5), (conv_math, err)
