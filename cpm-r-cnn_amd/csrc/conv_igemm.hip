@@ -938,21 +938,19 @@ __global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per
     float acc[TAPS];
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) acc[t] = 0.f;
+    // lane t < taps fetches the pixel's tap-t input value (one vector load for all 16 taps instead of 16 dependent
+    // scalar loads); the values are then broadcast lane by lane
+    const int tr = lane / a.S, ts = lane - tr * a.S;
     for (int m = m_begin + wave; m < m_end; m += 4) {
       const int ow = m % a.OW, t2 = m / a.OW;
       const int oh = t2 % a.OH, n = t2 / a.OH;
       const float dyv = live ? a.dy[(size_t)m * a.OCtot + g * a.OCg + ocl] : 0.f;
+      const int ih = oh * a.stride - a.pad + tr * a.dil, iw = ow * a.stride - a.pad + ts * a.dil;
+      float xt = 0.f;
+      if (lane < taps && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+        xt = a.x[((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g];
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        if (t < taps) {
-          const int r = t / a.S, s = t - r * a.S;
-          const int ih = oh * a.stride - a.pad + r * a.dil, iw = ow * a.stride - a.pad + s * a.dil;
-          float xv = 0.f;
-          if ((unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
-            xv = a.x[((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g];
-          acc[t] += dyv * xv;
-        }
-      }
+      for (int t = 0; t < TAPS; ++t) acc[t] += dyv * __shfl(xt, t, 64);
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) red[wave][t][lane] = acc[t];
