@@ -28,33 +28,52 @@ __device__ __forceinline__ float iou_plus1(const float4 g, const float4 p) {
 
 // per-gt maximum IoU over all predictions of its image (Matcher.set_low_quality_matches_, matcher.py:91-93);
 // IoU >= 0, so the int view of the float orders like the float
+constexpr int RM_ITEMS = 8;     // predictions per thread in the row-maximum pass
+
 __global__ __launch_bounds__(256) void match_rowmax_kernel(const float4* __restrict__ rois,
                                                            const int* __restrict__ roi_img,
                                                            const float4* __restrict__ gts,
                                                            const int* __restrict__ gt_off, int R,
                                                            int* __restrict__ row_max) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const bool live = i < R;
-  const int img = live ? (roi_img ? roi_img[i] : 0) : -1;
-  // 268 k anchors per image against <= ~100 gts: one atomic per (lane, gt) would serialise on a few dozen
-  // addresses.  A wave whose lanes all belong to one image reduces each gt's maximum across its 64 lanes first and
-  // issues ONE atomic per gt; a wave straddling an image boundary (one per image) falls back to per-lane atomics.
-  const int img0 = __shfl(img, 0, 64);
-  const bool uniform = __all(img == img0 || !live) && img0 >= 0;
-  const float4 p = live ? rois[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+  // 268 k anchors per image against a few dozen gts whose maxima share ONE cache line: every atomic on it is
+  // serialised.  A thread therefore folds RM_ITEMS predictions per gt in registers, a wave whose predictions all
+  // belong to one image reduces across its 64 lanes, and only lane 0 issues the atomic (one per wave and gt for
+  // 512 predictions); a wave straddling an image boundary falls back to per-prediction atomics.
+  const int base = (blockIdx.x * 256 + (threadIdx.x & ~63)) * RM_ITEMS + (threadIdx.x & 63);
+  float4 p[RM_ITEMS];
+  int img[RM_ITEMS];
+  bool uniform = true;
+  int img0 = -1;
+#pragma unroll
+  for (int k = 0; k < RM_ITEMS; ++k) {
+    const int i = base + k * 64;
+    const bool live = i < R;
+    img[k] = live ? (roi_img ? roi_img[i] : 0) : -1;
+    p[k] = live ? rois[i] : make_float4(0.f, 0.f, -2.f, -2.f);       // dead slot: empty box, IoU 0 with anything
+    if (k == 0) img0 = __shfl(img[0], 0, 64);
+    uniform = uniform && __all(img[k] == img0 || !live);
+  }
+  uniform = uniform && img0 >= 0;
   if (uniform) {
     const int lane = threadIdx.x & 63;
     for (int g = gt_off[img0]; g < gt_off[img0 + 1]; ++g) {
-      float v = live ? iou_plus1(gts[g], p) : 0.f;
+      const float4 gt = gts[g];
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < RM_ITEMS; ++k)
+        if (img[k] >= 0) v = fmaxf(v, iou_plus1(gt, p[k]));
       for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
       if (lane == 0 && v > 0.f) atomicMax(row_max + g, __float_as_int(v));
     }
     return;
   }
-  if (!live) return;
-  for (int g = gt_off[img]; g < gt_off[img + 1]; ++g) {
-    const float v = iou_plus1(gts[g], p);
-    if (v > 0.f) atomicMax(row_max + g, __float_as_int(v));
+#pragma unroll
+  for (int k = 0; k < RM_ITEMS; ++k) {
+    if (img[k] < 0) continue;
+    for (int g = gt_off[img[k]]; g < gt_off[img[k] + 1]; ++g) {
+      const float v = iou_plus1(gts[g], p[k]);
+      if (v > 0.f) atomicMax(row_max + g, __float_as_int(v));
+    }
   }
 }
 
@@ -254,7 +273,8 @@ CPM_EXPORT int cpm_match_rois(const float* rois, const int* roi_img, const float
   if (allow_low_quality) {
     if (hipMemsetAsync(row_max_ws, 0, sizeof(int) * (size_t)(num_gts > 0 ? num_gts : 1), s) != hipSuccess)
       return CPM_ELAUNCH;
-    hipLaunchKernelGGL(match_rowmax_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)rois, roi_img,
+    hipLaunchKernelGGL(match_rowmax_kernel, dim3((unsigned)((R + 256 * RM_ITEMS - 1) / (256 * RM_ITEMS))), dim3(256),
+                       0, s, (const float4*)rois, roi_img,
                        (const float4*)gts, gt_off, R, row_max_ws);
   }
   hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)rois, roi_img, (const float4*)gts,
