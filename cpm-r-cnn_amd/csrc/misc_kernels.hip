@@ -225,6 +225,11 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
   for (int i = threadIdx.x; i < Cg; i += 256) { sg[i] = 0.f; sb[i] = 0.f; }
   __syncthreads();
   float s1 = 0.f, s2 = 0.f;
+  // When Cg divides 256 a thread meets the same channel on every trip (i % Cg == threadIdx.x % Cg): the per-channel
+  // sums stay in registers and are folded through LDS once; LDS float atomics (ds_add_f32 costs ~64 cycles per wave
+  // instruction, more with 256 threads on Cg addresses) are only the fallback for odd group widths.
+  const bool fixed_c = (256 % Cg) == 0;
+  float pg = 0.f, pb = 0.f;
   for (int i = threadIdx.x; i < cnt; i += 256) {
     const int c = i % Cg;
     const size_t off = base + (size_t)(i / Cg) * C + c;
@@ -234,8 +239,25 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
     const float dxh = go * gamma[g * Cg + c];
     s1 += dxh;
     s2 += dxh * xh;
-    atomicAdd(&sg[c], go * xh);
-    atomicAdd(&sb[c], go);
+    if (fixed_c) {
+      pg += go * xh;
+      pb += go;
+    } else {
+      atomicAdd(&sg[c], go * xh);
+      atomicAdd(&sb[c], go);
+    }
+  }
+  if (fixed_c) {
+    __shared__ float tg[256], tb[256];
+    tg[threadIdx.x] = pg;
+    tb[threadIdx.x] = pb;
+    __syncthreads();
+    if (threadIdx.x < Cg) {
+      float a = 0.f, b = 0.f;
+      for (int j = threadIdx.x; j < 256; j += Cg) { a += tg[j]; b += tb[j]; }
+      sg[threadIdx.x] = a;
+      sb[threadIdx.x] = b;
+    }
   }
   const float m1 = block_sum(s1, red) / (float)cnt;
   const float m2 = block_sum(s2, red) / (float)cnt;
