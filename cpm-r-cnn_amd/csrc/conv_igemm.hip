@@ -46,15 +46,21 @@ constexpr int LDP = 36;  // LDS row pitch in floats
 // v_mfma_f32_32x32x16_bf16 with fp32 accumulation.  The dropped terms are <= 2^-16 |a b| (measured <= 1e-5 relative
 // on the conv outputs, the parity bar is 1e-3), bf16 keeps fp32's exponent range so no scaling is involved, and
 // three bf16 MFMAs cost 3/16 of the fp32 MFMA they replace.
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+  // one v_cvt_pk_bf16_f32 (round to nearest even), pinned: written as casts the compiler re-derives the hi values
+  // through extra single-element conversions (6 instead of 4 per float4)
+  unsigned r;
+  asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& lo) {
-  const bf16x2 h01 = {(__bf16)v.x, (__bf16)v.y}, h23 = {(__bf16)v.z, (__bf16)v.w};
-  hi.x = __builtin_bit_cast(unsigned, h01);
-  hi.y = __builtin_bit_cast(unsigned, h23);
+  hi.x = cvt_pk_bf16(v.x, v.y);
+  hi.y = cvt_pk_bf16(v.z, v.w);
   const float r0 = v.x - __uint_as_float(hi.x << 16), r1 = v.y - __uint_as_float(hi.x & 0xFFFF0000u);
   const float r2 = v.z - __uint_as_float(hi.y << 16), r3 = v.w - __uint_as_float(hi.y & 0xFFFF0000u);
-  const bf16x2 l01 = {(__bf16)r0, (__bf16)r1}, l23 = {(__bf16)r2, (__bf16)r3};
-  lo.x = __builtin_bit_cast(unsigned, l01);
-  lo.y = __builtin_bit_cast(unsigned, l23);
+  lo.x = cvt_pk_bf16(r0, r1);
+  lo.y = cvt_pk_bf16(r2, r3);
 }
 
 // 16-byte load through a buffer descriptor: an offset at or beyond num_records returns zeros WITHOUT touching
