@@ -537,19 +537,35 @@ __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict
 }
 
 // KRSC [K][R][S][Cg] (K = groups*Kg)  ->  DGRAD operand [groups*Cg][R][S][Kg]
-__global__ void weight_to_dgrad(const float* __restrict__ w, int groups, int Kg, int RS, int Cg,
-                                float* __restrict__ wt) {
-  const int64_t total = (int64_t)groups * Kg * RS * Cg;
-  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (int64_t)gridDim.x * blockDim.x) {
-    // idx enumerates the destination: (((g*Cg + c)*RS + t)*Kg + k)
-    const int k = idx % Kg;
-    int64_t r = idx / Kg;
-    const int t = r % RS;
-    r /= RS;
-    const int c = r % Cg;
-    const int g = r / Cg;
-    wt[idx] = w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c];
+// Per (group, tap) this is a Kg x Cg transpose.  32x32 tiles through LDS: the reads run along c and the writes along
+// k, both as contiguous 128-byte rows (a thread-per-destination-element version reads with a stride of R*S*Cg floats
+// and ran at a fraction of the copy rate on the 12-29 M element FC weights).
+__global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__ w, int groups, int Kg, int RS, int Cg,
+                                                       float* __restrict__ wt) {
+  __shared__ float tile[32][33];
+  const int tiles_c = (Cg + 31) / 32, tiles_k = (Kg + 31) / 32;
+  const int64_t per_gt = (int64_t)tiles_c * tiles_k;
+  const int64_t total = per_gt * RS * groups;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
+  for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
+    const int tcx = (int)(b % tiles_c);
+    int64_t r = b / tiles_c;
+    const int tkx = (int)(r % tiles_k); r /= tiles_k;
+    const int t = (int)(r % RS);
+    const int g = (int)(r / RS);
+    const int k0 = tkx * 32, c0 = tcx * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+      const int k = k0 + ty + j, c = c0 + tx;
+      tile[ty + j][tx] = (k < Kg && c < Cg) ? w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+      const int c = c0 + ty + j, k = k0 + tx;
+      if (c < Cg && k < Kg) wt[(((int64_t)(g * Cg + c)) * RS + t) * Kg + k] = tile[tx][ty + j];
+    }
+    __syncthreads();
   }
 }
 
@@ -1214,9 +1230,8 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   float* wt = (float*)workspace;
   const int Cg = d->C / d->groups, Kg = d->K / d->groups;
   {
-    const int64_t total = (int64_t)d->K * d->R * d->S * Cg;
-    int64_t b = (total + 255) / 256;
-    hipLaunchKernelGGL(weight_to_dgrad, dim3((unsigned)(b > 8192 ? 8192 : b)), dim3(256), 0, s, w, d->groups, Kg,
+    const int64_t b = (int64_t)cpm::cdiv(Cg, 32) * cpm::cdiv(Kg, 32) * d->R * d->S * d->groups;
+    hipLaunchKernelGGL(weight_to_dgrad, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, s, w, d->groups, Kg,
                        d->R * d->S, Cg, wt);
   }
   IgemmArgs a = {};
