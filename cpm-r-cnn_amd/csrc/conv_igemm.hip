@@ -1,4 +1,5 @@
-// Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), NHWC, gfx950.
+// Implicit-GEMM convolution on the gfx950 matrix cores, NHWC: exact fp32 (v_mfma_f32_32x32x2_f32) or 3-term
+// split-bf16 with fp32 accumulation (v_mfma_f32_32x32x16_bf16), selected by cpm_set_conv_math.
 //
 // One kernel family serves conv2d forward, its data gradient (also = ConvTranspose2d forward) and
 // nn.Linear (a 1x1 conv on a 1x1 image); a second one serves the weight gradient.
@@ -10,17 +11,20 @@
 //     runs one launch per stride phase and uses the weight re-laid as Wm[c][r][s][k] (transform kernel below),
 //     so that both directions read the B operand as "row = output channel, 32 consecutive reduction elements".
 //   * workgroup = 256 threads = 4 waves (one per SIMD), tile BM x BN x 32, waves in a WM x WN grid,
-//     each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.  fp32 in / fp32 accumulate: results are
-//     an exact-fp32 fmaf chain per output (north_star tolerance 1e-3 holds with large margin).
-//   * LDS: A[2][BM][36], B[2][BN][36] floats; the 36-float row pitch (144 B) makes every
-//     ds_read_b128 of a 16-lane group hit 16 distinct 16-B slots (bank = dword mod 64).
-//     A lane reads 4 consecutive k for its row with ONE ds_read_b128 and feeds 4 MFMAs with them:
-//     the MFMA's two k-slots (lane>>5) therefore hold k = {j, 4+j} -- a permutation of the
-//     reduction order applied identically to A and B, which leaves the sum unchanged.
-//   * global->LDS through registers, issued one k-step ahead (loads for step t+1 are in flight while
-//     step t's 16..64 MFMAs run), one barrier per k-step, 2 workgroups per CU.
+//     each wave owns (BM/WM) x (BN/WN) as 32x32 MFMA tiles.
+//   * f32 mode: LDS A[2][BM][36], B[2][BN][36] floats; the 36-float row pitch (144 B) makes every
+//     ds_read_b128 of a 16-lane group hit 16 distinct 16-B slots (bank = dword mod 64).  A lane reads 4
+//     consecutive k for its row with ONE ds_read_b128 and feeds 4 MFMAs with them: the MFMA's two k-slots
+//     (lane>>5) therefore hold k = {j, 4+j} -- a permutation of the reduction order applied identically to A and
+//     B, which leaves the sum unchanged.  Results are an exact-fp32 fmaf chain per output.
+//   * bf16x3 mode: every fp32 value is split while it moves from registers to LDS (hi = bf16(x), lo = bf16(x - hi));
+//     LDS holds hi and lo planes of 64-byte rows with XOR-swizzled 16-byte chunks; a product is
+//     a_lo*b_hi + a_hi*b_lo + a_hi*b_hi on the bf16 MFMA (see split4 / store_tile / fetch / mfma3).
+//   * global->LDS through registers, issued two k-steps ahead (two register sets), one barrier per k-step,
+//     2 workgroups per CU for the 128x128 tile, 3-4 for the smaller ones.
 //   * epilogue fused: per-channel scale/shift (bias or frozen AffineChannel2d), residual add
-//     (same-shape or nearest-2x-upsampled, the FPN top-down path) and ReLU.
+//     (same-shape or nearest-2x-upsampled, the FPN top-down path; also used to accumulate a data gradient in
+//     place), ReLU, and the ReLU gate / scale of the layer that produced the input (gated data gradient).
 //   * split-K (grid.z) for skinny problems (FC layers, small RoI counts): partial sums are added with
 //     float atomics into a zeroed output and the epilogue runs as a second tiny kernel.
 //
@@ -276,34 +280,7 @@ __global__ __launch_bounds__(64 * WM * WN)
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int frow = lane & 31, fk = (lane >> 5) * 4;
-  auto mma_half = [&](int cur, int kb0) {
-    if (SPLIT) {
-      // one 32x32x16 step: the lane's 8 consecutive reduction elements (k = 16*half + 8*(lane>>5) ..) are ONE
-      // ds_read_b128 from the hi plane and one from the lo plane
-      const int r_sw = ((((kb0 >> 1) * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
-      bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
-        ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
-        al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
-        bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
-        bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-        }
-      return;
-    }
+  auto mma_half = [&](int cur, int kb0) {          // exact-f32 arithmetic (the bf16x3 path uses fetch / mfma3 below)
 #pragma unroll
     for (int kb = kb0; kb < kb0 + BK / 16; ++kb) {
       float4 fa[TM], fb[TN];
