@@ -484,6 +484,203 @@ __global__ __launch_bounds__(64 * WM * WN)
   }
 }
 
+// ---- 3x3 stride-1 convolution with the input patch staged ONCE per channel block (bf16x3 arithmetic) ----------
+// The generic kernel gathers (and splits, and stores to LDS) an A tile per tap: a 3x3 layer moves every input
+// element 9 x (K / BN) times through that path.  Here a workgroup owns an 8 x 16 patch of output pixels (128 GEMM
+// rows); per 32-channel block it stages the 10 x 18 input halo once and runs the 9 taps as shifted views of it:
+// A-side global loads, bf16 splits and LDS stores drop by 6.4x, the B (weight) path is unchanged.
+// Serves forward and the stride-1 data gradient (both are "output (y,x) reads input (y+dy, x+dx)", the gather
+// description supplies dy/dx per tap and the weight tap).  Conditions in halo_eligible().
+constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_ROWS = (HT_H + 2) * (HT_W + 2);     // 180 halo pixels
+
+template <int BN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm3x3_kernel(IgemmArgs a) {
+  constexpr int BM = HT_H * HT_W;                 // 128
+  constexpr int WM = 2, WN = 2, WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPP = 32, BP = BN / RPP;          // B load passes (8 threads x float4 per 32-float row)
+  constexpr int AL = (HALO_ROWS * 8 + 255) / 256; // A halo loads per thread per channel block (6)
+  constexpr int LDS_DW = 2 * HALO_ROWS * 32 + 2 * BN * 32;
+  __shared__ __attribute__((aligned(16))) unsigned sm[LDS_DW];
+  constexpr int PA_HI = 0, PA_LO = 2 * HALO_ROWS * 16, PB_HI = 4 * HALO_ROWS * 16, PB_LO = PB_HI + 2 * BN * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.OCg + BN - 1) / BN;
+  const int patches_x = (a.OW + HT_W - 1) / HT_W, patches_y = (a.OH + HT_H - 1) / HT_H;
+  int bid = blockIdx.x;
+  const int tile_n = bid % tiles_n; bid /= tiles_n;
+  const int pxi = bid % patches_x; bid /= patches_x;
+  const int pyi = bid % patches_y;
+  const int n = bid / patches_y;
+  const int oy0 = pyi * HT_H, ox0 = pxi * HT_W, n0 = tile_n * BN;
+
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
+  const int CB = a.Ctot / 32, T = CB * 9;
+
+  // ---- A: halo slots of this thread (halo pixel hp, channel quad cq), fixed over the channel blocks
+  unsigned ha_off[AL];
+  int ha_lds[AL];
+#pragma unroll
+  for (int j = 0; j < AL; ++j) {
+    const int id = tid + 256 * j;
+    const int hp = id >> 3, cq = id & 7;
+    const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+    const int iy = oy0 + hy - 1, ix = ox0 + hx - 1;
+    const bool ok = id < HALO_ROWS * 8 && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+    ha_off[j] = ok ? (unsigned)(((n * a.IH + iy) * a.IW + ix) * a.Ctot + cq * 4) * 4u : B_INVALID;
+    ha_lds[j] = id < HALO_ROWS * 8 ? hp * 16 + ((((cq >> 1) ^ ((hp >> 2) & 3)) << 2) | ((cq & 1) << 1)) : -1;
+    asm volatile("" : "+v"(ha_off[j]), "+v"(ha_lds[j]));
+  }
+  // ---- B: as in igemm_kernel
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  unsigned b_off[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int oc = n0 + i * RPP + lrow;
+    b_off[i] = oc < a.OCg ? (unsigned)(oc * 9 * a.CgR + lcol) * 4u : B_INVALID;
+    asm volatile("" : "+v"(b_off[i]));
+  }
+  const int w_sw = ((((lcol >> 3) ^ ((lrow >> 2) & 3)) << 2) | ((lcol >> 1) & 2));
+
+  float4 ha[AL], rb0[BP], rb1[BP];
+  auto load_a = [&](int cb) {
+#pragma unroll
+    for (int j = 0; j < AL; ++j) ha[j] = bload4(rs_in, ha_off[j] + (unsigned)cb * 128u);   // invalid base stays >= 2 GiB
+  };
+  auto store_a = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+      if (ha_lds[j] < 0) continue;
+      uint2 hi, lo;
+      split4(ha[j], hi, lo);
+      const int o = buf * HALO_ROWS * 16 + ha_lds[j];
+      *(uint2*)(sm + PA_HI + o) = hi;
+      *(uint2*)(sm + PA_LO + o) = lo;
+    }
+  };
+  auto load_b = [&](int t, float4 (&rb)[BP]) {
+    const int cb = t / 9, tap = t - cb * 9;
+    const int tr = tap / 3, ts = tap - tr * 3;
+    const unsigned wtap = (unsigned)(((a.r0 + tr * a.rstep) * a.S + a.s0 + ts * a.sstep) * a.CgR + cb * 32) * 4u;
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = bload4(rs_wm, b_off[i] + wtap);
+  };
+  auto store_b = [&](int buf, const float4 (&rb)[BP]) {
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      uint2 hi, lo;
+      split4(rb[i], hi, lo);
+      const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
+      *(uint2*)(sm + PB_HI + o) = hi;
+      *(uint2*)(sm + PB_LO + o) = lo;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // the lane's A rows as halo indices of the centre tap
+  const int frow = lane & 31, khalf = lane >> 5;
+  int mh[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int ml = wm * WTM + i * 32 + frow;
+    mh[i] = ((ml >> 4) + 1) * HALO_W + (ml & 15) + 1;
+  }
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto fetch = [&](int abuf, int bbuf, int hoff, int sub, Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int h = mh[i] + hoff;
+      const int o = (abuf * HALO_ROWS + h) * 16 + ((((sub * 2 + khalf) ^ ((h >> 2) & 3))) << 2);
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+    const int r_sw = (((sub * 2 + khalf) ^ ((frow >> 2) & 3)) << 2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = (bbuf * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+    }
+  };
+  auto mfma3 = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  // prologue: halo of channel block 0, B tiles of steps 0 and 1
+  load_a(0);
+  load_b(0, rb0);
+  store_a(0);
+  store_b(0, rb0);
+  if (T > 1) load_b(1, rb1);
+  __syncthreads();
+
+  auto step = [&](int t, float4 (&lb)[BP], const float4 (&sb)[BP]) {
+    const int cb = t / 9, tap = t - cb * 9;
+    const int tr = tap / 3, ts = tap - tr * 3;
+    const int hoff = (a.ihadd + tr * a.hstep) * HALO_W + (a.iwadd + ts * a.wstep);
+    if (t + 2 < T) load_b(t + 2, lb);
+    if (tap == 0 && cb + 1 < CB) load_a(cb + 1);            // lands while this block's first taps run
+    Frag f0, f1;
+    fetch(cb & 1, t & 1, hoff, 0, f0);
+    fetch(cb & 1, t & 1, hoff, 1, f1);
+    mfma3(f0);
+    store_b((t + 1) & 1, sb);                               // B tile of step t+1 (stale re-store on the last step)
+    if (tap == 4 && cb + 1 < CB) store_a((cb + 1) & 1);     // the other halo buffer: last read in block cb-1
+    mfma3(f1);
+    __syncthreads();
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, rb0, rb1);
+    if (t + 1 < T) step(t + 1, rb1, rb0);
+  }
+
+  // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+      const int oy = oy0 + (ml >> 4), ox = ox0 + (ml & 15);
+      if (oy >= a.OH || ox >= a.OW) continue;
+      const size_t orow = ((size_t)n * a.OH + oy) * a.OW + ox;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int oc = n0 + wn * WTN + j * 32 + ecol;
+        if (oc >= a.OCg) continue;
+        float v = acc[i][j][e];
+        if (a.scale) v *= a.scale[oc];
+        if (a.shift) v += a.shift[oc];
+        if (a.res) {
+          if (a.res_mode == 0) {
+            v += a.res[orow * a.OCtot + oc];
+          } else {
+            const int rh = (a.OH + 1) / 2, rw = (a.OW + 1) / 2;
+            v += a.res[((size_t)(n * rh + oy / 2) * rw + ox / 2) * a.OCtot + oc];
+          }
+        }
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.mask) v = a.mask[orow * a.OCtot + oc] > 0.f ? v : 0.f;
+        a.out[orow * a.OCtot + oc] = v;
+      }
+    }
+  }
+}
+
 // epilogue as a separate pass (after split-K atomics)
 __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const float* __restrict__ res, int64_t M, int OC,
@@ -1105,6 +1302,21 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
   a.xcd_swizzle = swz;
   a.m_base = 0;
   ProfScope prof_scope(s, prof_kind);
+  static const int use_halo = env_int("CPM_IGEMM_HALO", 1);
+  if (use_halo && g_conv_split && vec && a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 &&
+      a.ihmul == 1 && a.iwmul == 1 && (a.hstep == 1 || a.hstep == -1) && (a.wstep == 1 || a.wstep == -1) &&
+      a.osh == 1 && a.osw == 1 && a.oah == 0 && a.oaw == 0 && a.groups == 1 && a.CgR == a.Ctot && a.Ctot % 32 == 0 &&
+      a.OHp == a.OH && a.OWp == a.OW && a.IH == a.OH && a.IW == a.OW && a.split_k == 1 && !a.atomic_out &&
+      a.ihadd * a.hstep == -1 && a.iwadd * a.wstep == -1 && a.OCg >= 128 && a.OH >= 7 && a.OW >= 14 &&
+      a.in_bytes < 0x80000000u) {
+    const int64_t patches = (int64_t)a.N * cpm::cdiv(a.OH, HT_H) * cpm::cdiv(a.OW, HT_W);
+    const int64_t blocks = patches * cpm::cdiv(a.OCg, 128);
+    static const int halo_min = env_int("CPM_IGEMM_HALO_MIN", 128);
+    if (blocks >= halo_min) {
+      hipLaunchKernelGGL((igemm3x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      return cpm::check_launch("conv igemm 3x3 (halo)");
+    }
+  }
   // Wave quantisation: the big tiles run 2 workgroups per CU (LDS), i.e. 512 at a time.  When the tile count is a
   // little over a multiple of 512 the last round would keep a few CUs busy for a whole tile time while the rest
   // idle (2100 tiles = 4.1 rounds cost 5).  So the rows of the full rounds go to the big tile and the remaining

@@ -47,6 +47,7 @@ CASES = [
     ("grouped", 2, 64, 8, 8, 128, 3, 1, 1, 4),
     ("odd_c", 2, 36, 5, 6, 20, 3, 1, 1, 1),
     ("7x7_s2", 1, 32, 20, 24, 64, 7, 2, 3, 1),
+    ("3x3_patch", 2, 256, 101, 115, 192, 3, 1, 1, 1),      # large enough for the 3x3 patch kernel (bf16x3), ragged edges
 ]
 
 
