@@ -641,6 +641,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     store_b((t + 1) & 1, sb);                               // B tile of step t+1 (stale re-store on the last step)
     if (tap == 4 && cb + 1 < CB) store_a((cb + 1) & 1);     // the other halo buffer: last read in block cb-1
     mfma3(f1);
+    // lay the B split (48 VALU ops) and its stores into the issue gaps of the 24 MFMAs, as in igemm_kernel
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+    for (int m = 0; m < TM * TN * 6; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      if (m % 6 == 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
     __syncthreads();
   };
   for (int t = 0; t < T; t += 2) {
