@@ -1,0 +1,142 @@
+// Image preparation on the device: the reference transforms every image on the host
+//   Resize  -> PIL.Image.resize(BILINEAR): two separable uint8 passes with Q22 fixed-point taps
+//              (pet/utils/data/transforms/transforms.py:29-64 via torchvision F.resize; Pillow's ImagingResample)
+//   RandomHorizontalFlip (transforms.py:67-77), ToTensor (:99-101), Normalize + to_bgr255 (:104-115)
+//   zero padding into the batch (pet/utils/data/structures/image_list.py:56-66)
+// and ships 12.9 MB of floats per 800x1344 image over PCIe.  Here the decoded uint8 HWC image (~0.9 MB) is uploaded
+// and two launches produce the padded fp32 slot of the batch tensor.  Integer arithmetic throughout: the result is
+// bit-identical to the host pipeline (tests/test_gpu_image_prep.py checks against PIL itself).
+//
+// Tap tables (bounds + Q22 coefficients) are computed on the host in double precision exactly as Pillow's
+// precompute_coeffs / normalize_coeffs_8bpc do (pet/utils/data/transforms/device.py); the per-value arithmetic of
+// ToTensor/Normalize ((v / 255) * 255 - mean) / std is a 3 x 256 fp32 table built with the same fp32 operations.
+#include "common.h"
+
+namespace {
+
+constexpr int PRECISION_BITS = 32 - 8 - 2;      // Pillow Resample.c
+
+__device__ __forceinline__ int clip8(int v) {
+  v >>= PRECISION_BITS;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+// horizontal pass: src [H][W][3] u8 -> tmp [H][ow][3] u8.  One thread per output pixel; a wave covers 64 adjacent
+// output columns of one row, whose taps overlap -> the byte loads hit the same cache lines.
+__global__ void __launch_bounds__(256) resize_h_kernel(const uint8_t* __restrict__ src, int H, int W, int ow,
+                                                       const int32_t* __restrict__ bounds,
+                                                       const int32_t* __restrict__ kk, int ks,
+                                                       uint8_t* __restrict__ tmp) {
+  const int64_t total = (int64_t)H * ow;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / ow), xx = (int)(i - (int64_t)y * ow);
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int32_t* k = kk + (int64_t)xx * ks;
+    const uint8_t* p = src + ((int64_t)y * W + xmin) * 3;
+    int a0 = 1 << (PRECISION_BITS - 1), a1 = a0, a2 = a0;
+    for (int t = 0; t < n; ++t) {
+      const int c = k[t];
+      a0 += p[3 * t] * c;
+      a1 += p[3 * t + 1] * c;
+      a2 += p[3 * t + 2] * c;
+    }
+    uint8_t* o = tmp + i * 3;
+    o[0] = (uint8_t)clip8(a0);
+    o[1] = (uint8_t)clip8(a1);
+    o[2] = (uint8_t)clip8(a2);
+  }
+}
+
+// vertical pass + flip + channel order + value table + zero padding: tmp [Hs][ow][3] u8 -> dst slot.
+// One thread per destination pixel (all dstH x dstW of them: the padding is written here, the slot needs no
+// zero fill).  NHWC: a wave writes 768 contiguous bytes.
+template <bool NHWC>
+__global__ void __launch_bounds__(256) resize_v_kernel(const uint8_t* __restrict__ tmp, int ow, int oh,
+                                                       const int32_t* __restrict__ bounds,
+                                                       const int32_t* __restrict__ kk, int ks, int flip,
+                                                       const float* __restrict__ lut, int swap_rb,
+                                                       float* __restrict__ dst, int dstH, int dstW) {
+  __shared__ float s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += blockDim.x) s_lut[i] = lut[i];
+  __syncthreads();
+  const int64_t total = (int64_t)dstH * dstW;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int y = (int)(i / dstW), x = (int)(i - (int64_t)y * dstW);
+    float v[3] = {0.f, 0.f, 0.f};
+    if (y < oh && x < ow) {
+      const int xs = flip ? ow - 1 - x : x;
+      int a[3];
+      if (bounds) {
+        const int ymin = bounds[2 * y], n = bounds[2 * y + 1];
+        const int32_t* k = kk + (int64_t)y * ks;
+        const uint8_t* p = tmp + ((int64_t)ymin * ow + xs) * 3;
+        a[0] = a[1] = a[2] = 1 << (PRECISION_BITS - 1);
+        for (int t = 0; t < n; ++t) {
+          const int c = k[t];
+          a[0] += p[0] * c;
+          a[1] += p[1] * c;
+          a[2] += p[2] * c;
+          p += (int64_t)ow * 3;
+        }
+        a[0] = clip8(a[0]); a[1] = clip8(a[1]); a[2] = clip8(a[2]);
+      } else {
+        const uint8_t* p = tmp + ((int64_t)y * ow + xs) * 3;
+        a[0] = p[0]; a[1] = p[1]; a[2] = p[2];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const int o = swap_rb ? 2 - c : c;                  // image[[2, 1, 0]]: output channel o takes input channel c
+        v[o] = s_lut[o * 256 + a[c]];
+      }
+    }
+    if (NHWC) {
+      float* o = dst + i * 3;
+      o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
+    } else {
+      dst[i] = v[0];
+      dst[total + i] = v[1];
+      dst[2 * total + i] = v[2];
+    }
+  }
+}
+
+inline unsigned grid_of(int64_t total) {
+  int64_t b = (total + 255) / 256;
+  return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
+}
+
+}  // namespace
+
+CPM_EXPORT int cpm_image_prep(const uint8_t* src, int H, int W, const int32_t* hbounds, const int32_t* hcoef,
+                              int hksize, const int32_t* vbounds, const int32_t* vcoef, int vksize, int oh, int ow,
+                              int flip, const float* lut, int swap_rb, uint8_t* tmp, float* dst, int dstH, int dstW,
+                              int layout, void* stream) {
+  CPM_REQUIRE(src && lut && dst, "null pointer");
+  CPM_REQUIRE(H > 0 && W > 0 && oh > 0 && ow > 0, "bad image size");
+  CPM_REQUIRE(dstH >= oh && dstW >= ow, "destination slot smaller than the resized image");
+  CPM_REQUIRE((int64_t)H * W < (1ll << 28) && (int64_t)dstH * dstW < (1ll << 28), "image too large");
+  CPM_REQUIRE(layout == 0 || layout == 1, "layout must be 0 (NCHW) or 1 (NHWC)");
+  CPM_REQUIRE((hbounds != nullptr) == (hcoef != nullptr) && (vbounds != nullptr) == (vcoef != nullptr),
+              "bounds and coefficients come together");
+  CPM_REQUIRE(hbounds || ow == W, "no horizontal taps but ow != W");
+  CPM_REQUIRE(vbounds || oh == H, "no vertical taps but oh != H");
+  CPM_REQUIRE(!hbounds || (tmp && hksize > 0), "horizontal pass needs tmp and ksize");
+  CPM_REQUIRE(!vbounds || vksize > 0, "vertical pass needs ksize");
+  hipStream_t s = (hipStream_t)stream;
+  const uint8_t* mid = src;
+  if (hbounds) {
+    hipLaunchKernelGGL(resize_h_kernel, dim3(grid_of((int64_t)H * ow)), dim3(256), 0, s, src, H, W, ow, hbounds, hcoef,
+                       hksize, tmp);
+    int rc = cpm::check_launch("image_prep horizontal");
+    if (rc != CPM_OK) return rc;
+    mid = tmp;
+  }
+  const unsigned g = grid_of((int64_t)dstH * dstW);
+  if (layout == 1)
+    hipLaunchKernelGGL(resize_v_kernel<true>, dim3(g), dim3(256), 0, s, mid, ow, oh, vbounds, vcoef, vksize, flip, lut,
+                       swap_rb, dst, dstH, dstW);
+  else
+    hipLaunchKernelGGL(resize_v_kernel<false>, dim3(g), dim3(256), 0, s, mid, ow, oh, vbounds, vcoef, vksize, flip, lut,
+                       swap_rb, dst, dstH, dstW);
+  return cpm::check_launch("image_prep vertical");
+}

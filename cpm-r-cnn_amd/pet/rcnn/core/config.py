@@ -22,6 +22,8 @@ def _tree(d):
 _DEFAULTS = {
     "DEVICE": "cuda", "NUM_GPUS": 1, "DISPLAY_ITER": 20, "CKPT": "",                         # config.py:19-52
     "PIXEL_MEANS": np.array([102.9801, 115.9465, 122.7717]), "PIXEL_STDS": np.array([1.0, 1.0, 1.0]),
+    "TO_BGR255": True,                                                                       # :46
+    "DATALOADER": {"SAMPLER_TRAIN": "DistributedSampler", "ASPECT_RATIO_GROUPING": True},   # :205-211
     "MODEL": {                                                                               # :55-131
         "TYPE": "generalized_rcnn", "FPN_ON": False, "FASTER_RCNN": True, "GRID_ON": False, "CASCADE_ON": False,
         "MASK_ON": False, "SEMSEG_ON": False, "KEYPOINT_ON": False, "PARSING_ON": False, "UV_ON": False,
@@ -38,6 +40,7 @@ _DEFAULTS = {
     "TRAIN": {                                                                               # :203-290
         "WEIGHTS": "", "DATASETS": (), "SCALES": (600,), "MAX_SIZE": 1000, "SIZE_DIVISIBILITY": 32,
         "BATCH_SIZE": 16, "FREEZE_CONV_BODY": False, "LOADER_THREADS": 4, "AUTO_RESUME": True,
+        "BRIGHTNESS": 0.0, "CONTRAST": 0.0, "SATURATION": 0.0, "HUE": 0.0, "LEFT_RIGHT": (),          # :272-278
     },
     "TEST": {                                                                                # :293-335
         "WEIGHTS": "", "DATASETS": (), "SCALE": 600, "MAX_SIZE": 1000, "SIZE_DIVISIBILITY": 32,

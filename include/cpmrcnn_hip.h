@@ -229,6 +229,25 @@ int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, cons
 int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,
                                 void* stream);
 
+/* ---- image preparation on the device ---------------------------------
+ * Replaces, per image, the host transform chain of pet/rcnn/datasets/transform.py:6-50:
+ *   Resize (pet/utils/data/transforms/transforms.py:29-64 -> PIL.Image.resize(BILINEAR), i.e. Pillow's
+ *   ImagingResample: a horizontal then a vertical uint8 pass with Q22 fixed-point taps),
+ *   RandomHorizontalFlip (:67-77), ToTensor (:99-101), Normalize incl. to_bgr255 (:104-115)
+ * and the zero padding of to_image_list (pet/utils/data/structures/image_list.py:56-66).
+ * src: decoded RGB image [H][W][3] uint8 on the device.  hbounds [ow][2] (first source column, tap count) and
+ * hcoef [ow][hksize] int32 Q22 taps (both NULL when ow == W: Pillow skips the pass); vbounds / vcoef likewise
+ * over rows (NULL when oh == H).  The caller computes the tables in double precision as Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc do.  flip: mirror the RESIZED image.  lut [3][256] fp32: value of
+ * OUTPUT channel o for byte v, i.e. ((v/255)*255 - mean[o]) / std[o] evaluated in fp32; swap_rb: output
+ * channel o reads input channel 2-o (image[[2,1,0]]).  tmp: >= H*ow*3 bytes of scratch (horizontal result).
+ * dst: one slot of the batch tensor, [dstH][dstW][3] (layout 1, NHWC) or [3][dstH][dstW] (layout 0); every
+ * element of the slot is written (zeros outside oh x ow).  Results are bit-identical to the host chain. */
+int cpm_image_prep(const uint8_t* src, int H, int W, const int32_t* hbounds, const int32_t* hcoef, int hksize,
+                   const int32_t* vbounds, const int32_t* vcoef, int vksize, int oh, int ow, int flip,
+                   const float* lut, int swap_rb, uint8_t* tmp, float* dst, int dstH, int dstW, int layout,
+                   void* stream);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------
  * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and
  * remembers the launch's ALGORITHMIC flops (2*N*P*Q*K*R*S*C/groups); cpm_prof_enable(0) stops and

@@ -205,3 +205,80 @@ def deform_conv(x, offset, weight, stride=1, pad=1, dil=1, groups=1, deformable_
     lib().orc_deform_conv(_p(x), _p(off) if off is not None else null, _p(weight), _p(dy), N, C, H, W, K, R, S,
                           stride, pad, dil, groups, deformable_groups, 1, _p(y), _p(dx), _p(doff), _p(dw))
     return y, dx, doff, dw
+
+
+# ---- image preparation -------------------------------------------------------------------------------
+# The reference resizes with torchvision F.resize -> PIL.Image.resize(BILINEAR) (pet/utils/data/transforms/
+# transforms.py:60-64).  Pillow is a third-party dependency that is not vendored in /root/reference; this is a numpy
+# restatement of its published algorithm (Pillow src/libImaging/Resample.c: precompute_coeffs, normalize_coeffs_8bpc,
+# ImagingResampleHorizontal_8bpc / Vertical_8bpc; installed here: Pillow 12.2.0).  PINNED: tests/test_data_pipeline.py
+# checks it bit-for-bit against PIL.Image.resize itself (PIL is importable in this image, here and on the GPU box).
+_PB = 32 - 8 - 2
+
+
+def pil_bilinear_coeffs(in_size, out_size):
+    """Per output position: first tap, tap count, Q22 integer taps (bilinear / triangle filter, support scaled by the
+    down-sampling ratio; plain Python loops in C operation order)."""
+    import math
+    scale = float(in_size) / out_size
+    fs = scale if scale >= 1.0 else 1.0
+    support = 1.0 * fs
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / fs
+    bounds = np.zeros((out_size, 2), np.int64)
+    kk = np.zeros((out_size, ksize), np.int64)
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = [0.0] * ksize
+        ww = 0.0
+        for x in range(xmax):
+            t = (x + xmin - center + 0.5) * ss
+            t = -t if t < 0.0 else t
+            w[x] = 1.0 - t if t < 1.0 else 0.0
+            ww += w[x]
+        for x in range(xmax):
+            if ww != 0.0:
+                w[x] /= ww
+        for x in range(ksize):
+            kk[xx, x] = int(-0.5 + w[x] * (1 << _PB)) if w[x] < 0 else int(0.5 + w[x] * (1 << _PB))
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk
+
+
+def pil_resize_bilinear(img, oh, ow):
+    """uint8 [H,W,C] -> uint8 [oh,ow,C]: horizontal pass, then vertical pass on its uint8 result."""
+    x = np.asarray(img).astype(np.int64)
+    if ow != x.shape[1]:
+        b, kk = pil_bilinear_coeffs(x.shape[1], ow)
+        out = np.zeros((x.shape[0], ow, x.shape[2]), np.int64)
+        for xx in range(ow):
+            lo, n = b[xx]
+            acc = (1 << (_PB - 1)) + (x[:, lo:lo + n, :] * kk[xx, :n][None, :, None]).sum(1)
+            out[:, xx, :] = np.clip(acc >> _PB, 0, 255)
+        x = out
+    if oh != x.shape[0]:
+        b, kk = pil_bilinear_coeffs(x.shape[0], oh)
+        out = np.zeros((oh, x.shape[1], x.shape[2]), np.int64)
+        for yy in range(oh):
+            lo, n = b[yy]
+            acc = (1 << (_PB - 1)) + (x[lo:lo + n] * kk[yy, :n][:, None, None]).sum(0)
+            out[yy] = np.clip(acc >> _PB, 0, 255)
+        x = out
+    return x.astype(np.uint8)
+
+
+def image_prep(img, out_hw, flip, mean, std, to_bgr255, pad_hw):
+    """Resize -> hflip -> ToTensor -> Normalize -> zero pad (transforms.py:60-115, image_list.py:56-66) of one uint8 RGB
+    image; returns fp32 [3, pad_h, pad_w].  The value arithmetic is fp32: ((v / 255) * 255 - mean) / std."""
+    r = pil_resize_bilinear(img, out_hw[0], out_hw[1])
+    if flip:
+        r = r[:, ::-1, :]
+    t = np.ascontiguousarray(r.transpose(2, 0, 1)).astype(np.float32) / np.float32(255)
+    if to_bgr255:
+        t = t[[2, 1, 0]] * np.float32(255)
+    t = (t - np.asarray(mean, np.float32).reshape(3, 1, 1)) / np.asarray(std, np.float32).reshape(3, 1, 1)
+    out = np.zeros((3, pad_hw[0], pad_hw[1]), np.float32)
+    out[:, : t.shape[1], : t.shape[2]] = t
+    return out

@@ -321,12 +321,71 @@ def gen_x101_meta():
     print("x101:", len(meta["state_dict"]), "keys,", len(meta["trainable"]), "trainable")
 
 
+def _load_ref_file(rel, name):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def gen_data_pipeline():
+    """Index sequences of the reference's samplers and output sizes of its Resize for seeded cases (host logic of the
+    input pipeline).  torchvision.transforms is replaced by an inert stand-in: only Resize.get_size
+    (pure Python) is called."""
+    import random
+    tvt = types.ModuleType("torchvision.transforms")
+    tvt.ColorJitter = object
+    tvf = types.ModuleType("torchvision.transforms.functional")
+    tvt.functional = tvf
+    sys.modules["torchvision"].transforms = tvt
+    sys.modules["torchvision.transforms"] = tvt
+    sys.modules["torchvision.transforms.functional"] = tvf
+    T = _load_ref_file("pet/utils/data/transforms/transforms.py", "ref_transforms")
+    DS = _load_ref_file("pet/utils/data/samplers/distributed.py", "ref_distributed").DistributedSampler
+    GB = _load_ref_file("pet/utils/data/samplers/grouped_batch_sampler.py", "ref_grouped").GroupedBatchSampler
+    IB = _load_ref_file("pet/utils/data/samplers/iteration_based_batch_sampler.py", "ref_iter").IterationBasedBatchSampler
+    out = {"get_size": [], "distributed": [], "grouped": [], "iteration": []}
+    rng = random.Random(11)
+    for i in range(60):
+        w, h = rng.randint(60, 2000), rng.randint(60, 2000)
+        mins, mx = [(800,), (600,), (640, 672, 704, 736, 768, 800), (1200,)][i % 4], [1333, 1000, 1333, 2000][i % 4]
+        random.seed(100 + i)
+        out["get_size"].append([w, h, list(mins), mx, 100 + i, list(T.Resize(mins, mx).get_size((w, h)))])
+    out["get_size"].append([1333, 800, [800], 1333, 1, list(T.Resize((800,), 1333).get_size((1333, 800)))])
+    out["get_size"].append([640, 480, [800], 1333, 1, list(T.Resize((800,), 1333).get_size((640, 480)))])
+    for n, world, epoch, shuffle in [(23, 4, 0, True), (23, 4, 5, True), (16, 8, 2, True), (10, 3, 0, False)]:
+        for r in range(world):
+            smp = DS(list(range(n)), num_replicas=world, rank=r, shuffle=shuffle)
+            smp.set_epoch(epoch)
+            out["distributed"].append([n, world, r, epoch, shuffle, list(smp)])
+    for n, world, r, epoch, bs, drop, seed in [(37, 2, 1, 3, 2, False, 0), (37, 2, 0, 3, 3, True, 1), (19, 2, 1, 1, 2, False, 2),
+                                               (64, 1, 0, 7, 4, False, 3)]:
+        g = torch.Generator().manual_seed(seed)
+        gids = torch.randint(0, 2, (n,), generator=g).tolist()
+        smp = DS(list(range(n)), num_replicas=world, rank=r, shuffle=True)
+        smp.set_epoch(epoch)
+        b = GB(smp, gids, bs, drop_uneven=drop)
+        out["grouped"].append([n, world, r, epoch, bs, drop, gids, [list(map(int, x)) for x in b], len(b)])
+    for n, bs, iters, start, seed in [(13, 2, 25, 7, 4), (13, 3, 9, 0, 5)]:
+        g = torch.Generator().manual_seed(seed)
+        gids = torch.randint(0, 2, (n,), generator=g).tolist()
+        smp = DS(list(range(n)), num_replicas=1, rank=0, shuffle=True)
+        it = IB(GB(smp, gids, bs), iters, start)
+        out["iteration"].append([n, bs, iters, start, gids, [list(map(int, x)) for x in it]])
+    with open(os.path.join(HERE, "data_pipeline.json"), "w") as f:
+        json.dump(out, f)
+    print("data pipeline:", {k: len(v) for k, v in out.items()})
+
+
 def main():
     ref_ext = build_ref()
     assert ref_ext is not None, "needs /root/reference"
     install_standins(ref_ext)
     if sys.argv[1:] == ["x101"]:
         return gen_x101_meta()
+    if sys.argv[1:] == ["data"]:
+        return gen_data_pipeline()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
     cfg.DEVICE = "cpu"
     ops = {}
