@@ -15,6 +15,7 @@ class LearningRateScheduler(object):
         self.base_lr = self.new_lr = solver.BASE_LR
         self.iteration, self.iter_per_epoch, self.local_rank = start_iter, iter_per_epoch, local_rank
         self.max_iter, self.warm_up_iters, self.steps = solver.MAX_ITER, solver.WARM_UP_ITERS, solver.STEPS
+        self.info = dict(best_acc=0.0, best_epoch=1, cur_acc=0.0, cur_epoch=1)       # lr_scheduler.py:36 (save_best)
 
     def state_dict(self):
         return {k: v for k, v in self.__dict__.items() if k != "optimizer"}

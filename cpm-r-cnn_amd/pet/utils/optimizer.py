@@ -35,6 +35,8 @@ class FlatSGD(torch.optim.Optimizer):
             gidx.append(gi)
             off += (n + align - 1) // align * align
         self.names = [n for n, _, _ in named_params]
+        self._flat_order = params
+        self._seg_index = {id(p): si for si, p in enumerate(params)}
         self.seg_begin = torch.tensor(begins, dtype=torch.int64, device=device)
         self.seg_end = torch.tensor(ends, dtype=torch.int64, device=device)
         self.seg_group = torch.tensor(gidx, dtype=torch.int64, device=device)
@@ -78,6 +80,62 @@ class FlatSGD(torch.optim.Optimizer):
             # this slice of the flat gradient buffer (no temporary, no autograd add)
             p._cpm_grad_sink = p.grad
             p._cpm_uses = 0
+
+    # ---- serialisation in torch.optim.SGD's layout -----------------------------------------------------------
+    # The reference saves torch.optim.SGD.state_dict() (pet/utils/checkpointer.py:128-133): parameters numbered group by
+    # group (weights, biases, GroupNorm affine) in model.named_parameters() order, each with a 'momentum_buffer'.  The
+    # flat buffers here are laid out in REVERSE registration order, so the canonical numbering walks each group
+    # backwards.  Checkpoints therefore move between the two implementations unchanged.
+    def _canonical(self):
+        out = []
+        for g in self.param_groups:
+            out.append([self._seg_index[id(p)] for p in reversed(g["params"])])
+        return out
+
+    def state_dict(self):
+        begins, ends = self.seg_begin.tolist(), self.seg_end.tolist()
+        state, groups, idx = {}, [], 0
+        for g, segs in zip(self.param_groups, self._canonical()):
+            ids = []
+            for si in segs:
+                if self._steps > 0:
+                    p = self._flat_order[si]
+                    buf = self._view(self.flat_mom, p, begins[si], ends[si] - begins[si])
+                    state[idx] = {"momentum_buffer": buf.detach().cpu().contiguous()}
+                ids.append(idx)
+                idx += 1
+            meta = {k: v for k, v in g.items() if k != "params"}
+            meta["params"] = ids
+            groups.append(meta)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, state_dict):
+        saved = [g for g in state_dict["param_groups"] if len(g["params"])]
+        mine = self._canonical()
+        if [len(g["params"]) for g in saved] != [len(s) for s in mine]:
+            raise ValueError("optimizer state does not fit: saved groups %s, model groups %s"
+                             % ([len(g["params"]) for g in saved], [len(s) for s in mine]))
+        begins, ends = self.seg_begin.tolist(), self.seg_end.tolist()
+        state = state_dict["state"]
+        loaded = 0
+        self.flat_mom.zero_()
+        for g, sg, segs in zip(self.param_groups, saved, mine):
+            for k, v in sg.items():
+                if k != "params":
+                    g[k] = v
+            for idx, si in zip(sg["params"], segs):
+                st = state.get(idx, state.get(str(idx)))
+                if not st or st.get("momentum_buffer") is None:
+                    continue
+                p = self._flat_order[si]
+                if tuple(st["momentum_buffer"].shape) != tuple(p.shape):
+                    raise ValueError("momentum buffer %d has shape %s, parameter %s has %s"
+                                     % (idx, tuple(st["momentum_buffer"].shape), self.names[si], tuple(p.shape)))
+                self._view(self.flat_mom, p, begins[si], ends[si] - begins[si]).copy_(st["momentum_buffer"])
+                loaded += 1
+        # momentum buffers that exist mean "not the first step" (torch.optim.SGD initialises buf = d on first use;
+        # with a zero buffer momentum*0 + d is the same value, so a partially filled state is still exact)
+        self._steps = 1 if loaded else 0
 
     def zero_grad(self, set_to_none=False):
         self.flat_grad.zero_()                                       # one memset; .grad views stay attached

@@ -373,6 +373,23 @@ def gen_data_pipeline():
         smp = DS(list(range(n)), num_replicas=1, rank=0, shuffle=True)
         it = IB(GB(smp, gids, bs), iters, start)
         out["iteration"].append([n, bs, iters, start, gids, [list(map(int, x)) for x in it]])
+    # suffix matching of checkpoint keys (pet/utils/checkpointer.py:190-242): every tensor carries its own index
+    from pet.utils.checkpointer import align_and_update_state_dicts, strip_prefix_if_present
+    model_keys = ["Conv_Body.conv1.weight", "Conv_Body.bn1.weight", "Conv_Body.layer1.0.conv1.weight",
+                  "Conv_Body.layer1.0.bn1.running_mean", "Conv_Body.layer1.0.downsample.0.weight",
+                  "Conv_Body_FPN.p5_in.weight", "RPN.head.conv.weight", "Grid_Cascade_RCNN.Head_cls.fc6.weight",
+                  "Conv_Body.layer2.3.conv3.weight", "Conv_Body.layer1.0.conv1.bias"]
+    weight_keys = ["conv1.weight", "bn1.weight", "layer1.0.conv1.weight", "layer1.0.bn1.running_mean",
+                   "layer1.0.downsample.0.weight", "layer2.3.conv3.weight", "fc.weight", "0.conv1.weight", "weight",
+                   "fc6.weight", "head.conv.weight"]
+    msd = {k: torch.tensor(-1.0) for k in model_keys}
+    wd = {k: torch.tensor(float(i)) for i, k in enumerate(weight_keys)}
+    upd, mismatch = align_and_update_state_dicts(msd, wd, -1)
+    out["align"] = {"model_keys": model_keys, "weight_keys": weight_keys,
+                    "picked": {k: int(v) for k, v in upd.items()}, "mismatch": sorted(mismatch)}
+    pref = {"module.a.w": 1, "module.b": 2}
+    out["strip"] = [[list(pref), list(strip_prefix_if_present(dict(pref), "module."))],
+                    [["module.a", "b"], list(strip_prefix_if_present({"module.a": 1, "b": 2}, "module."))]]
     with open(os.path.join(HERE, "data_pipeline.json"), "w") as f:
         json.dump(out, f)
     print("data pipeline:", {k: len(v) for k, v in out.items()})
