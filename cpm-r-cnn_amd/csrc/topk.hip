@@ -1,0 +1,207 @@
+// Segmented top-k (k <= 2048) for the RPN proposal selection: per (image, level) the pre_nms_top_n best objectness
+// scores of up to ~200k anchors (pet/rcnn/modeling/rpn/inference.py:79-84 `objectness.topk(pre_nms_top_n, dim=1,
+// sorted=True)`), all rows of a level in ONE launch.
+//
+// One workgroup of 1024 lanes per segment.  Radix select on the order-preserving 32-bit image of the float: four
+// histogram passes of 8 bits pin the k-th largest key exactly.  Objectness scores crowd into a few exponent bins, so
+// a single LDS histogram would serialise 64 lanes on one address; each bin therefore has 32 lane-private copies
+// (bin*32 + lane%32: distinct banks, at most two lanes per address).  A fifth pass appends
+// every element above it (and the ties at it, lowest index first when there are more ties than places) to an LDS
+// list, which a bitonic network then orders by (score descending, index ascending) -- the same composite key the
+// NMS stage sorts by (nms.hip make_key), so equal scores keep a defined order end to end.  Traffic: 5 reads of
+// the segment, 12 bytes written per selected element.
+#include "common.h"
+
+namespace {
+
+constexpr int TOPK_MAX = 2048;
+constexpr int TOPK_THREADS = 1024;
+
+__device__ __forceinline__ uint32_t order_key(float v) {
+  uint32_t u = __float_as_uint(v);
+  if (u == 0x80000000u) u = 0;                            // -0 == +0
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);      // ascending in the float order
+}
+
+constexpr int COPIES = 32;
+
+// f(value, index) over one row, every element once.  16-byte loads, two in flight per lane, when the row is aligned:
+// a single workgroup per row lives on memory-level parallelism.
+template <class F>
+__device__ __forceinline__ void scan_row(const float* __restrict__ row, int n, F f) {
+  const int tid = threadIdx.x;
+  if ((((uintptr_t)row) & 15) == 0) {
+    const int n4 = n >> 2;
+    const float4* r4 = (const float4*)row;
+    int i = tid;
+    for (; i + 3 * TOPK_THREADS < n4; i += 4 * TOPK_THREADS) {
+      const float4 a = r4[i], b = r4[i + TOPK_THREADS], c = r4[i + 2 * TOPK_THREADS], d = r4[i + 3 * TOPK_THREADS];
+      f(a.x, 4 * i); f(a.y, 4 * i + 1); f(a.z, 4 * i + 2); f(a.w, 4 * i + 3);
+      const int j = i + TOPK_THREADS;
+      f(b.x, 4 * j); f(b.y, 4 * j + 1); f(b.z, 4 * j + 2); f(b.w, 4 * j + 3);
+      const int l = j + TOPK_THREADS;
+      f(c.x, 4 * l); f(c.y, 4 * l + 1); f(c.z, 4 * l + 2); f(c.w, 4 * l + 3);
+      const int m = l + TOPK_THREADS;
+      f(d.x, 4 * m); f(d.y, 4 * m + 1); f(d.z, 4 * m + 2); f(d.w, 4 * m + 3);
+    }
+    for (; i < n4; i += TOPK_THREADS) {
+      const float4 a = r4[i];
+      f(a.x, 4 * i); f(a.y, 4 * i + 1); f(a.z, 4 * i + 2); f(a.w, 4 * i + 3);
+    }
+    for (int j = (n4 << 2) + tid; j < n; j += TOPK_THREADS) f(row[j], j);
+  } else {
+    for (int i = tid; i < n; i += TOPK_THREADS) f(row[i], i);
+  }
+}
+
+// From the 256 x COPIES lane-private counters: the bin b with  count(bins > b) < want <= count(bins >= b), and
+// count(bins > b).  `tot` (256 ints) is scratch.  All threads call; results land in LDS scalars.
+__device__ void find_bin(const int* hist, int* tot, int want, int* out_bin, int* out_above) {
+  const int tid = threadIdx.x;
+  if (tid < 256) {
+    int s = 0;
+    for (int c = 0; c < COPIES; ++c) s += hist[tid * COPIES + ((c + tid) & (COPIES - 1))];   // rotated: no bank conflict
+    tot[tid] = s;
+  }
+  __syncthreads();
+  if (tid < 64) {
+    const int lane = tid;
+    int s = tot[4 * lane] + tot[4 * lane + 1] + tot[4 * lane + 2] + tot[4 * lane + 3];
+    int incl = s;                                          // suffix sums over lanes (higher lane = larger keys)
+    for (int d = 1; d < 64; d <<= 1) {
+      const int t = __shfl_down(incl, d, 64);
+      if (lane + d < 64) incl += t;
+    }
+    const int above_lane = incl - s;
+    if (above_lane < want && want <= incl) {               // exactly one lane (1 <= want <= matching elements)
+      int above = above_lane;
+      for (int i = 3; i >= 0; --i) {
+        const int c = tot[4 * lane + i];
+        if (above + c >= want) {
+          *out_bin = 4 * lane + i;
+          *out_above = above;
+          break;
+        }
+        above += c;
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ scores, int n, int k,
+                                                                 float* __restrict__ out_scores,
+                                                                 int64_t* __restrict__ out_idx) {
+  __shared__ int hist[256 * COPIES];
+  __shared__ int tot[256];
+  __shared__ unsigned long long sel[TOPK_MAX];
+  __shared__ int s_bin, s_above, s_count, s_ties;
+  const float* row = scores + (int64_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+
+  uint32_t prefix = 0;           // key bits fixed so far (in place)
+  uint32_t prefix_mask = 0;
+  int want = k;                  // rank still to locate among elements matching the prefix
+  const int copy = tid & (COPIES - 1);
+  for (int shift = 24; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256 * COPIES; i += TOPK_THREADS) hist[i] = 0;
+    __syncthreads();
+    scan_row(row, n, [&](float v, int) {
+      const uint32_t key = order_key(v);
+      if ((key & prefix_mask) == prefix) atomicAdd(&hist[((key >> shift) & 255u) * COPIES + copy], 1);
+    });
+    __syncthreads();
+    find_bin(hist, tot, want, &s_bin, &s_above);
+    __syncthreads();
+    prefix |= (uint32_t)s_bin << shift;
+    prefix_mask |= 255u << shift;
+    want -= s_above;
+    __syncthreads();
+  }
+  // prefix == key of the k-th largest element; `want` (>= 1) of the elements equal to it are still to be taken
+  const uint32_t kth = prefix;
+  if (tid == 0) { s_count = 0; s_ties = 0; }
+  __syncthreads();
+  scan_row(row, n, [&](float v, int i) {
+    const uint32_t key = order_key(v);
+    if (key > kth) {
+      const int p = atomicAdd(&s_count, 1);
+      sel[p] = ((unsigned long long)(~key) << 32) | (uint32_t)i;
+    }
+    // ties can be most of the row (saturated scores): one LDS atomic per wavefront, not per lane
+    const unsigned long long m = __ballot(key == kth);
+    if (key == kth && (m & ((1ull << (tid & 63)) - 1ull)) == 0) atomicAdd(&s_ties, __popcll(m));
+  });
+  __syncthreads();
+  const int above = s_count;                    // == k - want
+  if (s_ties == want) {                         // every tie has a place: order does not matter here, the sort fixes it
+    scan_row(row, n, [&](float v, int i) {
+      const uint32_t key = order_key(v);
+      if (key == kth) {
+        const int p = atomicAdd(&s_count, 1);
+        sel[p] = ((unsigned long long)(~key) << 32) | (uint32_t)i;
+      }
+    });
+  } else {
+    // more ties than places: the lowest indices win.  Walk the row in index order, 1024 elements at a time, with a
+    // ballot + prefix count over the workgroup.
+    __shared__ int wave_cnt[TOPK_THREADS / 64];
+    int taken = 0;                              // uniform across the workgroup
+    for (int base = 0; base < n && taken < want; base += TOPK_THREADS) {
+      const int i = base + tid;
+      const bool tie = i < n && order_key(row[i]) == kth;
+      const unsigned long long b = __ballot(tie);
+      const int lane = tid & 63, wv = tid >> 6;
+      if (lane == 0) wave_cnt[wv] = __popcll(b);
+      __syncthreads();
+      int before = 0, total = 0;
+      for (int w = 0; w < TOPK_THREADS / 64; ++w) {
+        const int c = wave_cnt[w];
+        if (w < wv) before += c;
+        total += c;
+      }
+      const int r = taken + before + __popcll(b & ((1ull << lane) - 1ull));
+      if (tie && r < want) sel[above + r] = ((unsigned long long)(~kth) << 32) | (uint32_t)i;
+      taken += total;
+      __syncthreads();
+    }
+  }
+  __syncthreads();
+  // bitonic sort of the k composite keys (ascending == score descending, index ascending)
+  int np2 = 1;
+  while (np2 < k) np2 <<= 1;
+  for (int i = k + tid; i < np2; i += TOPK_THREADS) sel[i] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < np2 / 2; t += TOPK_THREADS) {
+        const int lo = ((t / stride) * stride * 2) + (t % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long a = sel[lo], b2 = sel[hi];
+        if ((a > b2) == up) { sel[lo] = b2; sel[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  float* os = out_scores + (int64_t)blockIdx.x * k;
+  int64_t* oi = out_idx + (int64_t)blockIdx.x * k;
+  for (int j = tid; j < k; j += TOPK_THREADS) {
+    const uint32_t idx = (uint32_t)(sel[j] & 0xffffffffull);
+    os[j] = row[idx];
+    oi[j] = (int64_t)idx;
+  }
+}
+
+}  // namespace
+
+CPM_EXPORT int cpm_topk_rows(const float* scores, int rows, int n, int k, float* out_scores, int64_t* out_idx,
+                             void* stream) {
+  CPM_REQUIRE(rows >= 0 && n > 0, "bad shape");
+  CPM_REQUIRE(k >= 1 && k <= n && k <= TOPK_MAX, "k must be in [1, min(n, 2048)]");
+  CPM_REQUIRE((int64_t)rows * n < (1ll << 31), "too many elements");
+  if (rows == 0) return CPM_OK;
+  CPM_REQUIRE(scores && out_scores && out_idx, "null pointer");
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, (hipStream_t)stream, scores, n, k,
+                     out_scores, out_idx);
+  return cpm::check_launch("topk_rows");
+}

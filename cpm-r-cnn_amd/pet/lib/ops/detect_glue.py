@@ -131,3 +131,25 @@ def rpn_decode(reg, topk_idx, anchors, weights, clip, image_sizes):
                                     H.stream())
     H.check(rc, "rpn_decode")
     return out
+
+
+TOPK_MAX = 2048
+
+
+def topk_rows(scores, k):
+    """scores [rows, n] fp32 -> (values [rows, k] descending, indices [rows, k] int64), ties by ascending index.
+    One launch for all rows (cpm_topk_rows); replaces objectness.topk(k, dim=1, sorted=True) of the RPN
+    (pet/rcnn/modeling/rpn/inference.py:79-84).  k <= 2048."""
+    H.require_gpu(scores)
+    if scores.dim() != 2 or scores.dtype != torch.float32:
+        raise RuntimeError("topk_rows: scores must be fp32 [rows, n]")
+    rows, n = scores.shape
+    if not 1 <= k <= min(n, TOPK_MAX):
+        raise RuntimeError("topk_rows: k must be in [1, min(n, %d)], got %d (n = %d)" % (TOPK_MAX, k, n))
+    s = scores if scores.is_contiguous() else scores.contiguous()
+    vals = torch.empty((rows, k), dtype=torch.float32, device=s.device)
+    idx = torch.empty((rows, k), dtype=torch.int64, device=s.device)
+    with torch.cuda.device(s.device):
+        rc = H.lib().cpm_topk_rows(H.ptr(s), rows, n, k, H.ptr(vals), H.ptr(idx), H.stream())
+    H.check(rc, "topk_rows")
+    return vals, idx

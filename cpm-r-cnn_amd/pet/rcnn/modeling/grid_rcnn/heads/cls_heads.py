@@ -19,7 +19,8 @@ class roi_cls_head(nn.Module):
                              sampling_ratio=G.ROI_XFORM_SAMPLING_RATIO)
         if G.MLP_HEAD.USE_WS:
             raise ValueError("weight-standardised heads are outside the hot path")
-        self.fc6 = make_fc(self.dim_in * res[0] * res[1], G.MLP_HEAD.MLP_DIM, G.MLP_HEAD.USE_BN, G.MLP_HEAD.USE_GN)
+        self.fc6 = make_fc(self.dim_in * res[0] * res[1], G.MLP_HEAD.MLP_DIM, G.MLP_HEAD.USE_BN, G.MLP_HEAD.USE_GN,
+                           window=(self.dim_in, res[0], res[1]))
         self.fc7 = make_fc(G.MLP_HEAD.MLP_DIM, G.MLP_HEAD.MLP_DIM, G.MLP_HEAD.USE_BN, G.MLP_HEAD.USE_GN)
         self.dim_out = G.MLP_HEAD.MLP_DIM
 

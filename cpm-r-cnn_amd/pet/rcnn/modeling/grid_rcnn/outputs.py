@@ -32,7 +32,8 @@ class Grid_output(nn.Module):
         self.has_iou = bool(G.IOU_HELPER and stage == G.CASCADE_MAPPING_OPTION.STAGE_NUM - 1)
         if self.has_iou:
             res = G.ROI_XFORM_RESOLUTION_CLS
-            self.iou_fc1 = make_fc(self.conv_out_channels * res[0] * res[1], 1024)
+            self.iou_fc1 = make_fc(self.conv_out_channels * res[0] * res[1], 1024,
+                                   window=(self.conv_out_channels, res[0], res[1]))
             self.iou_fc2 = make_fc(1024, 1024)
             self.iou_pred = ops.Linear(1024, 2)
             init.normal_(self.iou_pred.weight, std=0.01)

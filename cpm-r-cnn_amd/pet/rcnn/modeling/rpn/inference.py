@@ -71,7 +71,10 @@ class RPNPostProcessor(torch.nn.Module):
             scores = permute_and_flatten(o, N, A, 1, H, W).view(N, -1).sigmoid()
             reg = permute_and_flatten(b, N, A, 4, H, W)
             k = min(self.pre_nms_top_n, A * H * W)
-            scores, idx = scores.topk(k, dim=1, sorted=True)
+            if k <= ops.detect_glue.TOPK_MAX:
+                scores, idx = ops.topk_rows(scores, k)       # all images of the level in one launch
+            else:
+                scores, idx = scores.topk(k, dim=1, sorted=True)
             boxes = ops.rpn_decode(reg, idx, anchors[0][lvl].bbox, self.box_coder.weights,
                                    self.box_coder.bbox_xform_clip, sizes)
             seg_boxes.append(boxes.view(N * k, 4))

@@ -25,7 +25,7 @@ class RPNHead(nn.Module):
     def forward(self, x):
         logits, bbox_reg = [], []
         for feature in x:
-            t = self.conv(feature, relu=True)
+            t = ops.mark_shared_grad(self.conv(feature, relu=True))     # consumers: the two 1x1 predictors
             logits.append(self.cls_logits(t))
             bbox_reg.append(self.bbox_pred(t))
         return logits, bbox_reg

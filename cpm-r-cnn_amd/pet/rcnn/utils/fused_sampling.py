@@ -18,15 +18,16 @@ def batch_pos_neg_sample(labels, img, n_img, batch_size_per_image, positive_frac
     bucket = img * 3 + cls                                             # [R] in [0, 3*n_img)
     key = bucket.to(torch.float32) + torch.rand(R, device=dev) * 0.998
     order = torch.argsort(key)
-    counts = torch.zeros(3 * n_img, dtype=torch.int64, device=dev).index_add_(
-        0, bucket, torch.ones(R, dtype=torch.int64, device=dev))
-    starts = counts.cumsum(0) - counts
+    b_sorted = bucket[order]
+    # bucket boundaries in the sorted order (a binary search per bucket; an index_add_ of R ones into 3*n_img bins is
+    # R atomics on a handful of addresses)
+    bounds = torch.searchsorted(b_sorted, torch.arange(3 * n_img + 1, device=dev))
+    starts, counts = bounds[:-1], bounds[1:] - bounds[:-1]
     c = counts.view(n_img, 3)
     max_pos = int(batch_size_per_image * positive_fraction)
     n_pos = c[:, 0].clamp(max=max_pos)
     n_neg = torch.minimum(c[:, 1], batch_size_per_image - n_pos)
     quota = torch.stack([n_pos, n_neg, torch.zeros_like(n_pos)], dim=1).view(-1)
-    b_sorted = bucket[order]
     rank = torch.arange(R, device=dev) - starts[b_sorted]
     take = torch.empty(R, dtype=torch.bool, device=dev)
     take[order] = rank < quota[b_sorted]

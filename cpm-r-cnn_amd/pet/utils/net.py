@@ -29,11 +29,11 @@ def make_conv(in_channels, out_channels, kernel=3, stride=1, dilation=1, padding
     return nn.Sequential(*mods) if len(mods) > 1 else conv
 
 
-def make_fc(dim_in, hidden_dim, use_bn=False, use_gn=False):
-    """net.py:62-74 (plain variant)."""
+def make_fc(dim_in, hidden_dim, use_bn=False, use_gn=False, window=None):
+    """net.py:62-74 (plain variant).  `window=(C,H,W)`: the layer reads a flattened feature map (ops.Linear)."""
     if use_bn or use_gn:
         raise ValueError("make_fc: BN/GN variants are outside the hot path")
-    fc = ops.Linear(dim_in, hidden_dim)
+    fc = ops.Linear(dim_in, hidden_dim, window=window)
     nn.init.kaiming_uniform_(fc.weight, a=1)
     nn.init.constant_(fc.bias, 0)
     return fc

@@ -101,7 +101,8 @@ class FlatSGD(torch.optim.Optimizer):
                 if self._steps > 0:
                     p = self._flat_order[si]
                     buf = self._view(self.flat_mom, p, begins[si], ends[si] - begins[si])
-                    state[idx] = {"momentum_buffer": buf.detach().cpu().contiguous()}
+                    buf = buf.detach().cpu().contiguous()
+                    state[idx] = {"momentum_buffer": buf.reshape(getattr(p, "_cpm_abi_shape", buf.shape))}
                 ids.append(idx)
                 idx += 1
             meta = {k: v for k, v in g.items() if k != "params"}
@@ -128,10 +129,13 @@ class FlatSGD(torch.optim.Optimizer):
                 if not st or st.get("momentum_buffer") is None:
                     continue
                 p = self._flat_order[si]
-                if tuple(st["momentum_buffer"].shape) != tuple(p.shape):
+                mb = st["momentum_buffer"]
+                if tuple(mb.shape) == tuple(getattr(p, "_cpm_abi_shape", ())):
+                    mb = mb.reshape(p.shape)                # stored [K, C*H*W] (reference layout) -> [K,C,H,W]
+                if tuple(mb.shape) != tuple(p.shape):
                     raise ValueError("momentum buffer %d has shape %s, parameter %s has %s"
-                                     % (idx, tuple(st["momentum_buffer"].shape), self.names[si], tuple(p.shape)))
-                self._view(self.flat_mom, p, begins[si], ends[si] - begins[si]).copy_(st["momentum_buffer"])
+                                     % (idx, tuple(mb.shape), self.names[si], tuple(p.shape)))
+                self._view(self.flat_mom, p, begins[si], ends[si] - begins[si]).copy_(mb)
                 loaded += 1
         # momentum buffers that exist mean "not the first step" (torch.optim.SGD initialises buf = d on first use;
         # with a zero buffer momentum*0 + d is the same value, so a partially filled state is still exact)

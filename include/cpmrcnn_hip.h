@@ -229,6 +229,13 @@ int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, cons
 int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,
                                 void* stream);
 
+/* ---- row-wise top-k for the RPN proposal selection --------------------------------------
+ * Replaces `objectness.topk(pre_nms_top_n, dim=1, sorted=True)` of pet/rcnn/modeling/rpn/inference.py:79-84 (torch's
+ * multi-kernel radix top-k, one call per FPN level).  scores [rows][n] fp32; for every row the k largest values in
+ * descending order with their column indices (int64); equal values are ordered by ascending index (torch leaves
+ * that order unspecified).  1 <= k <= min(n, 2048).  NaNs rank above every number, as in torch. */
+int cpm_topk_rows(const float* scores, int rows, int n, int k, float* out_scores, int64_t* out_idx, void* stream);
+
 /* ---- image preparation on the device ---------------------------------
  * Replaces, per image, the host transform chain of pet/rcnn/datasets/transform.py:6-50:
  *   Resize (pet/utils/data/transforms/transforms.py:29-64 -> PIL.Image.resize(BILINEAR), i.e. Pillow's

@@ -32,9 +32,9 @@ def kind_of(name, tensor):
 
 
 def det_fill_(module):
-    with torch.no_grad():
-        for name, p in module.state_dict().items():
-            if not torch.is_floating_point(p):
-                continue
-            p.copy_(det_tensor(name, p.shape, kind_of(name, p)))
+    """Through load_state_dict (not in-place writes into state_dict() tensors): a module may keep a tensor in another
+    physical layout than its state-dict form (ops.Linear with a window)."""
+    fill = {name: det_tensor(name, p.shape, kind_of(name, p)) for name, p in module.state_dict().items()
+            if torch.is_floating_point(p)}
+    module.load_state_dict(fill, strict=False)
     return module

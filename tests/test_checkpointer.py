@@ -137,3 +137,46 @@ def test_checkpointer_round_trip_and_resume(tmp_path):
     model3 = _Tiny()
     load_weights(model3, str(tmp_path / "ddp.pth"))
     assert torch.equal(model3.fc.weight, model.fc.weight)
+
+
+def test_windowed_linear_keeps_reference_state_dict_layout():
+    """ops.Linear(window=(C,H,W)) stores its weight as the [K,C,H,W] KRSC filter it is used as, while state_dict /
+    load_state_dict / optimizer state keep the reference's [K, C*H*W] tensor."""
+    import pet.lib.ops as ops
+    from pet.utils.optimizer import Optimizer
+    torch.manual_seed(2)
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc6 = ops.Linear(5 * 3 * 3, 7, window=(5, 3, 3))
+            self.fc7 = ops.Linear(7, 4)
+    net = Net()
+    assert tuple(net.fc6.weight.shape) == (7, 5, 3, 3)
+    assert net.fc6.weight.is_contiguous(memory_format=torch.channels_last)
+    sd = net.state_dict()
+    assert tuple(sd["fc6.weight"].shape) == (7, 45) and list(sd) == ["fc6.weight", "fc6.bias", "fc7.weight", "fc7.bias"]
+    w = torch.randn(7, 45)
+    net.load_state_dict({**sd, "fc6.weight": w})
+    assert torch.equal(net.fc6.weight.detach().reshape(7, 45), w)
+    assert torch.equal(net.state_dict()["fc6.weight"], w)
+    # same function as a plain Linear on the flattened NCHW map
+    x = torch.randn(6, 5, 3, 3)
+    want = torch.nn.functional.linear(x.flatten(1), w, net.fc6.bias)
+    got = torch.nn.functional.conv2d(x, net.fc6.weight, net.fc6.bias).flatten(1)
+    assert torch.allclose(got, want, atol=1e-5)
+    # optimizer state keeps the 2-D layout
+    S = _solver()
+    ref = nn.Sequential()
+    ref.fc6, ref.fc7 = nn.Linear(45, 7), nn.Linear(7, 4)
+    ropt = _reference_style_sgd(ref, S)
+    for p in ref.parameters():
+        p.grad = torch.randn_like(p)
+    ropt.step()
+    saved = ropt.state_dict()
+    opt = Optimizer(net, S).build()
+    opt.load_state_dict(saved)
+    mine = opt.state_dict()
+    for i in saved["state"]:
+        assert torch.equal(mine["state"][i]["momentum_buffer"], saved["state"][i]["momentum_buffer"])
+    assert tuple(mine["state"][0]["momentum_buffer"].shape) == (7, 45)

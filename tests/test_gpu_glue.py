@@ -306,3 +306,50 @@ def test_fused_rpn_proposals_equal_per_level_path(oracle):
             np.testing.assert_allclose(a.bbox.cpu().numpy(), b.bbox.cpu().numpy(), rtol=1e-5, atol=1e-3)
     finally:
         config.reset_cfg()
+
+
+@pytest.mark.parametrize("rows,n,k", [(2, 201600, 2000), (2, 50400, 2000), (2, 819, 819), (3, 3150, 2000), (1, 5000, 1),
+                                      (2, 4096, 2048), (5, 37, 11)])
+@pytest.mark.parametrize("dist", ["sigmoid", "uniform", "quantised"])
+def test_topk_rows_matches_torch(rows, n, k, dist):
+    """Row-wise top-k (RPN pre-NMS selection) at the five FPN level sizes: values equal torch.topk's bit for bit,
+    the indices address those values, are unique, and equal scores come in ascending index order."""
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(rows * 1000 + n + k)
+    if dist == "sigmoid":                       # objectness at initialisation: a narrow band around 0.5
+        s = torch.sigmoid(torch.randn(rows, n, generator=g) * 0.02)
+    elif dist == "uniform":
+        s = torch.rand(rows, n, generator=g) * 2 - 1
+    else:                                       # many exact ties, also across the k-th value
+        s = torch.randint(0, 7, (rows, n), generator=g).float() / 8 - 0.25
+    s = s.cuda()
+    vals, idx = ops.topk_rows(s, k)
+    want = s.topk(k, dim=1, sorted=True)[0]
+    assert torch.equal(vals, want)
+    assert torch.equal(s.gather(1, idx), vals)
+    srt = idx.sort(dim=1)[0]
+    assert bool((srt[:, 1:] != srt[:, :-1]).all()) if k > 1 else True
+    same = vals[:, 1:] == vals[:, :-1]
+    assert bool((idx[:, 1:][same] > idx[:, :-1][same]).all())
+    if dist == "quantised":                     # ties at the threshold: the lowest indices are the ones taken
+        for r in range(rows):
+            thr = vals[r, -1]
+            cand = torch.nonzero(s[r] == thr).squeeze(1)
+            took = idx[r][vals[r] == thr]
+            assert torch.equal(took, cand[: took.numel()])
+
+
+def test_topk_rows_edge_cases():
+    import pet.lib.ops as ops
+    s = torch.zeros(2, 300, device="cuda")
+    v, i = ops.topk_rows(s, 100)
+    assert torch.equal(i, torch.arange(100, device="cuda").repeat(2, 1)) and bool((v == 0).all())
+    s = torch.tensor([[0.0, -0.0, float("-inf"), 3.0, float("inf"), -2.0]], device="cuda")
+    v, i = ops.topk_rows(s, 6)
+    assert i.tolist() == [[4, 3, 0, 1, 5, 2]]
+    with pytest.raises(RuntimeError):
+        ops.topk_rows(s, 7)
+    with pytest.raises(RuntimeError):
+        ops.topk_rows(torch.zeros(1, 5000, device="cuda"), 2049)
+    with pytest.raises(RuntimeError):
+        ops.topk_rows(torch.zeros(1, 50), 5)
