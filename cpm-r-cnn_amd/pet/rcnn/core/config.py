@@ -78,6 +78,20 @@ _DEFAULTS = {
         "FPN_POST_NMS_TOP_N_TRAIN": 2000, "FPN_POST_NMS_TOP_N_TEST": 2000, "FPN_POST_NMS_PER_BATCH": True,
         "SMOOTH_L1_BETA": 1.0 / 9, "RPN_HEAD": "SingleConvRPNHead",
     },
+    "FAST_RCNN": {                                                                           # :744-845 (MLP head subset)
+        "ROI_BOX_HEAD": "roi_2mlp_head", "ROI_BOX_OUTPUT": "Box_output", "ROI_XFORM_METHOD": "ROIAlign",
+        "ROI_XFORM_SAMPLING_RATIO": 0, "ROI_XFORM_RESOLUTION": (14, 14), "FG_IOU_THRESHOLD": 0.5,
+        "BG_IOU_THRESHOLD": 0.5, "BBOX_REG_WEIGHTS": (10., 10., 5., 5.), "BATCH_SIZE_PER_IMAGE": 512,
+        "POSITIVE_FRACTION": 0.25, "SCORE_THRESH": 0.05, "NMS": 0.5, "DETECTIONS_PER_IMG": 100, "SMOOTH_L1_BETA": 1,
+        "MLP_HEAD": {"MLP_DIM": 1024, "USE_BN": False, "USE_GN": False, "USE_WS": False},
+    },
+    "CASCADE_RCNN": {                                                                        # :1021-1061
+        "ROI_BOX_HEAD": "roi_2mlp_head", "ROI_BOX_OUTPUT": "Box_output", "NUM_STAGE": 3,
+        "FG_IOU_THRESHOLD": [0.5, 0.6, 0.7], "BG_IOU_THRESHOLD": [0.5, 0.6, 0.7],
+        "BBOX_REG_WEIGHTS": ((10., 10., 5., 5.), (20., 20., 10., 10.), (30., 30., 15., 15.)),
+        "STAGE_WEIGHTS": (1.0, 0.5, 0.25), "TEST_STAGE": 3, "TEST_ENSEMBLE": True, "RESCORE_ON": False,
+        "IOU_HELPER": False, "IOU_HELPER_MERGE": False, "IOU_LOSS_WEIGHT": 1.0, "RESCORE_LOSS_WEIGHT": 1.0,
+    },
     "GRID_RCNN": {                                                                           # :850-1008
         "CASCADE_MAPPING_ON": False, "RESCORE_ON": False, "ROI_GRID_HEAD": "roi_grid_head",
         "ROI_GRID_OUTPUT": "Grid_output", "ROI_CLS_HEAD": "roi_cls_head", "ROI_CLS_OUTPUT": "Cls_output",

@@ -1,5 +1,6 @@
 """Generalized_RCNN (counterpart of pet/rcnn/modeling/model_builder.py:19-195), CPM R-CNN wiring:
-Conv_Body -> Conv_Body_FPN -> RPN -> Grid_Cascade_RCNN.  Attribute names are the state-dict prefixes of the
+Conv_Body -> Conv_Body_FPN -> RPN -> Grid_Cascade_RCNN (MODEL.GRID_ON) or Cascade_RCNN (MODEL.FASTER_RCNN +
+MODEL.CASCADE_ON, the offset-regression cascade with ISM / RSM).  Attribute names are the state-dict prefixes of the
 released checkpoints.  Images enter as NCHW fp32 (the loader's layout); everything downstream is NHWC."""
 import numpy as np
 import torch
@@ -10,6 +11,7 @@ import pet.rcnn.modeling.backbone  # noqa: F401  (registers the bodies)
 import pet.rcnn.modeling.fpn  # noqa: F401
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
+from pet.rcnn.modeling.cascade_rcnn.cascade_rcnn import CascadeRCNN
 from pet.rcnn.modeling.grid_cascade_rcnn.grid_cascade_rcnn import GridCascadeRCNN
 from pet.rcnn.modeling.rpn.rpn import build_rpn
 from pet.utils.data.structures.image_list import to_image_list
@@ -37,16 +39,24 @@ class Generalized_RCNN(nn.Module):
             self.spatial_scale = self.spatial_scale[-1:]
         self.RPN = build_rpn(self.dim_in)
         if not M.RPN_ONLY:
-            if M.FASTER_RCNN or not (M.GRID_ON and cfg.GRID_RCNN.CASCADE_MAPPING_ON):
-                raise ValueError("only MODEL.GRID_ON + GRID_RCNN.CASCADE_MAPPING_ON (CPM R-CNN) is built; the "
-                                 "offset-regression Fast/Cascade R-CNN heads are a later row (SURVEY 8f-4)")
-            self.Grid_Cascade_RCNN = GridCascadeRCNN(self.dim_in, self.spatial_scale)
+            if M.FASTER_RCNN:
+                if not M.CASCADE_ON:
+                    raise ValueError("single-stage Fast R-CNN heads are not built (MODEL.CASCADE_ON or MODEL.GRID_ON)")
+                self.Cascade_RCNN = CascadeRCNN(self.dim_in, self.spatial_scale)
+            elif M.GRID_ON and cfg.GRID_RCNN.CASCADE_MAPPING_ON:
+                self.Grid_Cascade_RCNN = GridCascadeRCNN(self.dim_in, self.spatial_scale)
+            else:
+                raise ValueError("built RoI heads: MODEL.GRID_ON + GRID_RCNN.CASCADE_MAPPING_ON (CPM R-CNN) and "
+                                 "MODEL.FASTER_RCNN + MODEL.CASCADE_ON (Cascade R-CNN)")
         if cfg.TRAIN.FREEZE_CONV_BODY:
             for p in self.Conv_Body.parameters():
                 p.requires_grad = False
             if M.FPN_ON:
                 for p in self.Conv_Body_FPN.parameters():
                     p.requires_grad = False
+
+    def _roi_heads(self):
+        return self.Cascade_RCNN if cfg.MODEL.FASTER_RCNN else self.Grid_Cascade_RCNN
 
     def _features(self, x):
         feats = self.Conv_Body(x)
@@ -60,7 +70,7 @@ class Generalized_RCNN(nn.Module):
         proposals, proposal_losses = self.RPN(images, feats, targets)
         roi_losses = {}
         if not cfg.MODEL.RPN_ONLY:
-            _, result, roi_losses = self.Grid_Cascade_RCNN(feats, proposals, targets)
+            _, result, roi_losses = self._roi_heads()(feats, proposals, targets)
         else:
             result = proposals
         if self.training:
@@ -75,7 +85,7 @@ class Generalized_RCNN(nn.Module):
         feats = self._features(self.Norm(images.tensors))
         proposals, _ = self.RPN(images, feats, targets)
         if not cfg.MODEL.RPN_ONLY:
-            _, result, _ = self.Grid_Cascade_RCNN(feats, proposals, targets)
+            _, result, _ = self._roi_heads()(feats, proposals, targets)
         else:
             result = proposals
         return feats, result

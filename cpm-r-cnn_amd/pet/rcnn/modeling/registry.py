@@ -7,3 +7,5 @@ ROI_CLS_HEADS = Registry()
 ROI_CLS_OUTPUTS = Registry()
 ROI_GRID_HEADS = Registry()
 ROI_GRID_OUTPUTS = Registry()
+ROI_CASCADE_HEADS = Registry()
+ROI_CASCADE_OUTPUTS = Registry()

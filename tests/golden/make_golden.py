@@ -321,6 +321,83 @@ def gen_x101_meta():
     print("x101:", len(meta["state_dict"]), "keys,", len(meta["trainable"]), "trainable")
 
 
+def gen_cascade():
+    """Offset-regression Cascade R-CNN with ISM + RSM (cfgs/rcnn/mscoco/cascade/ISM+RSM): state-dict ABI,
+    the RoI head in evaluation mode (decode / refine / ensemble / IoU-merged scores) and in training mode on a
+    proposal set small enough that the 512-per-image sampler keeps everything (so the run is deterministic), all on
+    the reference's own modules with name-keyed deterministic weights."""
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    from pet.utils.data.structures.bounding_box import BoxList
+    cfg = load_cfg("cfgs/rcnn/mscoco/cascade/ISM+RSM/e2e_cascade_rcnn@2_R-50-FPN_1x.yaml")
+    cfg.DEVICE = "cpu"
+    torch.manual_seed(0)
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True), merge=True)
+    meta = {"state_dict": [[k, list(v.shape)] for k, v in model.state_dict().items()],
+            "trainable": [k for k, p in model.named_parameters() if p.requires_grad]}
+    det_fill_(model)
+    out = {}
+    rng = np.random.default_rng(5)
+    img = (rng.uniform(0, 255, (1, 3, 64, 96)) - np.array([102.9801, 115.9465, 122.7717]).reshape(1, 3, 1, 1))
+    img = img.astype(np.float32)
+    out["img"] = img
+    gt = np.array([[4, 6, 58, 44], [30, 10, 92, 60], [50, 30, 70, 50]], np.float32)
+    gt_labels = np.array([3, 17, 80], np.int64)
+    jit = np.array([[2, 3, 60, 40], [10, 5, 90, 60], [0, 0, 95, 63], [30, 20, 50, 45], [5, 30, 25, 62], [40, 2, 70, 20],
+                    [28, 12, 90, 58], [5, 8, 55, 41], [52, 29, 71, 52], [48, 33, 68, 49], [60, 40, 90, 60],
+                    [1, 1, 20, 20]], np.float32)
+    out["gt"], out["gt_labels"], out["rois"] = gt, gt_labels, jit
+
+    def props():
+        b = BoxList(torch.from_numpy(np.concatenate([jit, gt]).copy()), (96, 64))
+        b.add_field("objectness", torch.linspace(0.9, 0.1, len(b)))
+        return [b]
+
+    def targets():
+        t = BoxList(torch.from_numpy(gt.copy()), (96, 64))
+        t.add_field("labels", torch.from_numpy(gt_labels.copy()))
+        return [t]
+    head = model.Cascade_RCNN
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        with torch.no_grad():
+            p = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(img)))
+            model.eval()
+            x, result, _ = head(p, props())
+            out["eval_x"] = x.numpy()
+            out["eval_bbox"] = result[0].bbox.numpy()
+            out["eval_scores"] = result[0].get_field("scores").numpy()
+            for s in (1, 2):
+                f = getattr(head, "Box_Head_%d" % s)(p, props())
+                c, b, i = getattr(head, "Output_%d" % s)(f)
+                out["s%d_cls" % s], out["s%d_bbox" % s] = c.numpy(), b.numpy()
+                if i is not None:
+                    out["s%d_iou" % s] = i.numpy()
+        model.train()
+        for q in model.parameters():
+            q.grad = None
+        p = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(img)))
+        x, proposals, losses = head(p, props(), targets())
+        for k, v in losses.items():
+            out["loss::" + k] = np.asarray(float(v), np.float64)
+        out["train_final_bbox"] = proposals[0].bbox.detach().numpy()
+        out["train_final_labels"] = proposals[0].get_field("labels").numpy()
+        sum(losses.values()).backward()
+        grads = {}
+        for k, q in model.named_parameters():
+            if q.grad is not None and k.startswith("Cascade_RCNN"):
+                g = q.grad.double()
+                grads[k] = [float(g.sum()), float(g.abs().sum()), float((g ** 2).sum())]
+        meta["grad_stats"] = grads
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    np.savez_compressed(os.path.join(HERE, "model_cascade.npz"), **out)
+    with open(os.path.join(HERE, "model_cascade_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("cascade:", len(meta["state_dict"]), "keys;", {k: float(v) for k, v in out.items() if k.startswith("loss::")})
+
+
 def _load_ref_file(rel, name):
     import importlib.util
     spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
@@ -403,6 +480,8 @@ def main():
         return gen_x101_meta()
     if sys.argv[1:] == ["data"]:
         return gen_data_pipeline()
+    if sys.argv[1:] == ["cascade"]:
+        return gen_cascade()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
     cfg.DEVICE = "cpu"
     ops = {}

@@ -1,5 +1,6 @@
 """CPU-only: the device-agnostic host logic of the pet.* mirror against vectors captured from the reference
 (tests/golden/ops.npz) and against the oracle.  No HIP kernel is launched here."""
+import json
 import os
 
 import numpy as np
@@ -240,3 +241,32 @@ def test_l2_loss_nosync_matches_reference_quirk(golden_ops):
         assert abs(a - b) <= 1e-5 * abs(b) + 1e-9
     z = torch.zeros(5, 2)
     assert float(l2_loss_nosync(torch.randn(5, 2, generator=gen), z)) == 0.0
+
+
+CASCADE_OPTS = ["MODEL.FPN_ON", True, "MODEL.CASCADE_ON", True, "MODEL.NUM_CLASSES", 81, "MODEL.CONV1_RGB2BGR", False,
+                "MODEL.CLS_AGNOSTIC_BBOX_REG", True, "RPN.ANCHOR_STRIDE", (4, 8, 16, 32, 64),
+                "RPN.PRE_NMS_TOP_N_TRAIN", 2000, "RPN.PRE_NMS_TOP_N_TEST", 1000, "RPN.POST_NMS_TOP_N_TEST", 1000,
+                "RPN.FPN_POST_NMS_TOP_N_TEST", 1000, "FAST_RCNN.ROI_XFORM_RESOLUTION", (7, 7),
+                "FAST_RCNN.ROI_XFORM_SAMPLING_RATIO", 2, "CASCADE_RCNN.NUM_STAGE", 2, "CASCADE_RCNN.TEST_STAGE", 2,
+                "CASCADE_RCNN.TEST_ENSEMBLE", True, "CASCADE_RCNN.IOU_HELPER", True,
+                "CASCADE_RCNN.IOU_HELPER_MERGE", True, "CASCADE_RCNN.RESCORE_ON", True,
+                "CASCADE_RCNN.RESCORE_LOSS_WEIGHT", 0.2, "CASCADE_RCNN.IOU_LOSS_WEIGHT", 1.0]
+
+
+def test_cascade_rcnn_state_dict_abi():
+    """Offset-regression Cascade R-CNN with ISM + RSM (cfgs/rcnn/mscoco/cascade/ISM+RSM): same keys, shapes and
+    trainable set as the reference model (tests/golden/model_cascade_meta.json)."""
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    with open(os.path.join(os.path.dirname(__file__), "golden", "model_cascade_meta.json")) as f:
+        meta = json.load(f)
+    config.reset_cfg()
+    config.merge_cfg_from_list(CASCADE_OPTS)
+    try:
+        model = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+        got = [[k, list(v.shape)] for k, v in model.state_dict().items()]
+        assert got == meta["state_dict"]
+        assert [k for k, p in model.named_parameters() if p.requires_grad] == meta["trainable"]
+    finally:
+        config.reset_cfg()
