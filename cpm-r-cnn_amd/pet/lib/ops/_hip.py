@@ -38,7 +38,8 @@ def lib():
                     ctypes.CDLL(tl, mode=ctypes.RTLD_GLOBAL)
                 L = ctypes.CDLL(LIB_PATH)
                 L.cpm_last_error.restype = ctypes.c_char_p
-                for name in ("cpm_nms_workspace_bytes", "cpm_conv2d_workspace_bytes"):
+                for name in ("cpm_nms_workspace_bytes", "cpm_conv2d_workspace_bytes",
+                             "cpm_roi_align_fpn_gather_workspace_bytes"):
                     getattr(L, name).restype = c_size_t
                 mode = os.environ.get("CPM_CONV_MATH", "").lower()
                 if mode:

@@ -59,15 +59,21 @@ class _RoIAlignFPN(Function):
         r, = ctx.saved_tensors
         (ph, pw), scales, ratio, lvl_min, lvl_max, (s0, l0, eps), shapes = ctx.meta
         g = _nhwc(grad_out)
-        # the kernel accumulates with atomics: a level whose feature map is opted into shared gradient accumulation
-        # and already has an accumulator gets this call's contribution added there (and reports None to autograd)
+        K = r.shape[0]
+        C = int(shapes[0][1])
+        # gather formulation (no float atomics, no zero fill, bit-reproducible) when the shape allows it; the atomic
+        # scatter kernel otherwise.  A level whose feature map is opted into shared gradient accumulation and already
+        # has an accumulator gets this call's contribution added there (and reports None to autograd).
+        gather = ph <= 16 and pw <= 16 and C % 4 == 0 and K <= 8192
         grads, fresh = [], []
         for s, h in zip(shapes, ctx.holders):
             if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(s):
                 grads.append(h["acc"])
                 fresh.append(False)
             else:
-                t = torch.empty(s, dtype=torch.float32, device=g.device, memory_format=torch.channels_last).zero_()
+                t = torch.empty(s, dtype=torch.float32, device=g.device, memory_format=torch.channels_last)
+                if not gather:
+                    t.zero_()
                 if h is not None:
                     h["acc"] = t
                 grads.append(t)
@@ -75,11 +81,18 @@ class _RoIAlignFPN(Function):
         n = len(grads)
         hs, ws, sc = _tables(grads, scales)
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
-        K = r.shape[0]
         with torch.cuda.device(g.device):
-            rc = H.lib().cpm_roi_align_fpn_backward(H.ptr(g), ptrs, hs, ws, sc, n, H.ptr(r), K, int(shapes[0][0]),
-                                                    int(shapes[0][1]), ph, pw, ratio, H.f(lvl_min), H.f(lvl_max),
-                                                    H.f(s0), H.f(l0), H.f(eps), H.stream())
+            if gather:
+                need = H.lib().cpm_roi_align_fpn_gather_workspace_bytes(hs, ws, n, int(shapes[0][0]), K)
+                wsb = H.workspace(need, g.device)
+                mask = sum((0 if f else 1) << i for i, f in enumerate(fresh))
+                rc = H.lib().cpm_roi_align_fpn_backward_gather(
+                    H.ptr(g), ptrs, hs, ws, sc, n, H.ptr(r), K, int(shapes[0][0]), C, ph, pw, ratio, H.f(lvl_min),
+                    H.f(lvl_max), H.f(s0), H.f(l0), H.f(eps), mask, H.ptr(wsb), H.c_size_t(wsb.numel()), H.stream())
+            else:
+                rc = H.lib().cpm_roi_align_fpn_backward(H.ptr(g), ptrs, hs, ws, sc, n, H.ptr(r), K,
+                                                        int(shapes[0][0]), C, ph, pw, ratio, H.f(lvl_min),
+                                                        H.f(lvl_max), H.f(s0), H.f(l0), H.f(eps), H.stream())
         H.check(rc, "roi_align_fpn_backward")
         return (None, None, None, None, None, None, None) + tuple(t if f else None for t, f in zip(grads, fresh))
 

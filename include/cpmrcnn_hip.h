@@ -60,6 +60,17 @@ int cpm_roi_align_fpn_backward(const float* grad_output, float* const* grad_feat
                                const float* scales, int num_levels, const float* rois, int K, int B, int C,
                                int pooled_h, int pooled_w, int sampling_ratio, float k_min, float k_max,
                                float canonical_scale, float canonical_level, float eps, void* stream);
+/* The same gradient WITHOUT float atomics: every 8x8 tile of every level is owned by one workgroup that gathers from
+ * the RoIs binned onto it (a pre-pass lists them) and writes each pixel once.  Levels whose bit is set in
+ * accumulate_mask are added to (read-modify-write), the others are cleared and written here (no caller-side zero fill).
+ * Bit-reproducible (per-tile RoI lists are sorted).  pooled_h/w <= 16, C % 4 == 0, K <= 8192, maps 16-byte aligned.
+ * workspace: cpm_roi_align_fpn_gather_workspace_bytes(hs, ws, num_levels, B, K) bytes of device scratch. */
+size_t cpm_roi_align_fpn_gather_workspace_bytes(const int* hs, const int* ws, int num_levels, int B, int K);
+int cpm_roi_align_fpn_backward_gather(const float* grad_output, float* const* grad_feats, const int* hs,
+                                      const int* ws, const float* scales, int num_levels, const float* rois, int K,
+                                      int B, int C, int pooled_h, int pooled_w, int sampling_ratio, float k_min,
+                                      float k_max, float canonical_scale, float canonical_level, float eps,
+                                      int accumulate_mask, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- NMS -------------------------------------------------------------------
  * Replaces torchvision.ops.nms as bound at pet/lib/ops/nms.py:2,10 (labels ==

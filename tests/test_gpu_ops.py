@@ -201,3 +201,95 @@ def test_box_iou_and_pool_points(oracle, C):
     gi = C.pool_points_interp_backward(dev(go), dev(pts), 0.25, 2, 5, 20, 30)
     np.testing.assert_allclose(gi.cpu().numpy(), oracle.pool_points_interp_backward(go, pts, 0.25, 2, 5, 20, 30),
                                rtol=1e-5, atol=1e-5)
+
+
+def _fpn_backward(kind, go, rois, shapes, scales, ph, ratio, init=None):
+    """Run one of the two multi-level backward kernels straight through the C ABI."""
+    import ctypes
+    from pet.lib.ops import _hip as H
+    n = len(shapes)
+    grads = []
+    for i, s in enumerate(shapes):
+        if init is not None and init[i] is not None:
+            grads.append(init[i].clone())
+        elif kind == "atomic":
+            grads.append(torch.zeros(s, device="cuda").contiguous(memory_format=torch.channels_last))
+        else:
+            grads.append(torch.full(s, float("nan"), device="cuda").contiguous(memory_format=torch.channels_last))
+    hs = (ctypes.c_int * n)(*[s[2] for s in shapes])
+    ws = (ctypes.c_int * n)(*[s[3] for s in shapes])
+    sc = (ctypes.c_float * n)(*scales)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
+    K, B, Cc = rois.shape[0], shapes[0][0], shapes[0][1]
+    common = (H.ptr(go), ptrs, hs, ws, sc, n, H.ptr(rois), K, B, Cc, ph, ph, ratio, H.f(2.0), H.f(5.0), H.f(224.0),
+              H.f(4.0), H.f(1e-6))
+    if kind == "atomic":
+        rc = H.lib().cpm_roi_align_fpn_backward(*common, H.stream())
+    else:
+        need = H.lib().cpm_roi_align_fpn_gather_workspace_bytes(hs, ws, n, B, K)
+        wsb = torch.empty(max(int(need), 1), dtype=torch.uint8, device="cuda")
+        mask = 0 if init is None else sum((1 if t is not None else 0) << i for i, t in enumerate(init))
+        rc = H.lib().cpm_roi_align_fpn_backward_gather(*common, mask, H.ptr(wsb), H.c_size_t(wsb.numel()), H.stream())
+    H.check(rc, "fpn backward " + kind)
+    torch.cuda.synchronize()
+    return grads
+
+
+@pytest.mark.parametrize("ph,ratio", [(7, 2), (14, 2), (7, 0), (3, 1)])
+def test_roi_align_fpn_gather_backward(oracle, ph, ratio):
+    """The atomic-free gather formulation of the multi-level backward: equals the oracle (hence the scatter kernel),
+    overwrites un-initialised maps completely, adds into the levels flagged for accumulation, is bit-reproducible, and
+    handles sub-pixel, border-straddling, out-of-image and empty inputs."""
+    rng = np.random.default_rng(ph * 10 + ratio)
+    B, Cc = 2, 64
+    sizes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    shapes = [(B, Cc, h, w) for h, w in sizes]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    rois = _random_rois(rng, 300, B, 320, 192)
+    rois[:8, 1:] = [[0, 0, 55, 55], [0, 0, 111, 111], [0, 0, 223, 223], [0, 0, 447, 447], [100.2, 50.1, 100.9, 50.7],
+                    [-40, -30, 20, 10], [300, 170, 400, 260], [-500, -500, -400, -400]]
+    lv = oracle.level_map(rois[:, 1:])
+    go = rng.standard_normal((rois.shape[0], Cc, ph, ph)).astype(np.float32)
+    g_dev = dev(go).contiguous(memory_format=torch.channels_last)
+    r_dev = dev(rois)
+    got = _fpn_backward("gather", g_dev, r_dev, shapes, scales, ph, ratio)
+    for l in range(4):
+        idx = np.nonzero(lv == l)[0]
+        want = oracle.roi_align_backward(go[idx], rois[idx], scales[l], ph, ph, B, Cc, sizes[l][0], sizes[l][1], ratio)
+        assert torch.isfinite(got[l]).all()                          # every element of the NaN-filled map was written
+        np.testing.assert_allclose(got[l].cpu().numpy(), want, rtol=1e-4, atol=1e-4)
+    atom = _fpn_backward("atomic", g_dev, r_dev, shapes, scales, ph, ratio)
+    for a, b in zip(got, atom):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-4)
+    again = _fpn_backward("gather", g_dev, r_dev, shapes, scales, ph, ratio)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)                                      # no atomics: same bits every run
+    base = [torch.randn(s, device="cuda").contiguous(memory_format=torch.channels_last) if i % 2 else None
+            for i, s in enumerate(shapes)]
+    mixed = _fpn_backward("gather", g_dev, r_dev, shapes, scales, ph, ratio, init=base)
+    for i in range(4):
+        torch.testing.assert_close(mixed[i], got[i] + base[i] if base[i] is not None else got[i], rtol=1e-5, atol=1e-5)
+    empty = _fpn_backward("gather", g_dev[:0], r_dev[:0], shapes, scales, ph, ratio)
+    assert all(bool((t == 0).all()) for t in empty)
+
+
+def test_roi_align_fpn_gather_backward_full_size():
+    """BASELINE shapes (K=1024 cls RoIs 7x7 and 192 grid RoIs 14x14 on the 2 x 256-channel pyramid): gather == scatter,
+    and the gradient mass is conserved for in-bounds RoIs."""
+    rng = np.random.default_rng(3)
+    B, Cc = 2, 256
+    sizes = [(200, 336), (100, 168), (50, 84), (25, 42)]
+    shapes = [(B, Cc, h, w) for h, w in sizes]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    for K, ph in ((1024, 7), (192, 14)):
+        rois = _random_rois(rng, K, B, 1300, 780)
+        rois[:, 1:3] = np.abs(rois[:, 1:3]) + 8
+        rois[:, 3] = np.minimum(rois[:, 3], 1300)
+        rois[:, 4] = np.minimum(rois[:, 4], 780)
+        go = torch.randn(K, Cc, ph, ph, device="cuda").contiguous(memory_format=torch.channels_last)
+        a = _fpn_backward("gather", go, dev(rois), shapes, scales, ph, 2)
+        b = _fpn_backward("atomic", go, dev(rois), shapes, scales, ph, 2)
+        for x, y in zip(a, b):
+            torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-4)
+        total = sum(float(t.double().sum()) for t in a)
+        assert abs(total - float(go.double().sum())) < 1e-2 + 1e-4 * float(go.double().abs().sum()) ** 0.5
