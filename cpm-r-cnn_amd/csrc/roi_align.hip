@@ -263,9 +263,8 @@ __global__ __launch_bounds__(256) void roi_align_bwd_nhwc(const float* __restric
 // gradient is  sum_roi sum_{ph,pw} WY[r][ph]*WX[c][pw]/count * g[roi,ph,pw,:]  accumulated in registers with
 // 1 KB wave-contiguous loads of g and written ONCE (no atomics; the per-tile RoI list is sorted, so the result is
 // bit-reproducible).  Only tiles that some RoI reaches are visited (persistent workgroups over a compacted list);
-// a fresh map is cleared by a memset first.  Measured (K=1024, 7x7, 2 x 256-ch pyramid): 360 us + 50 us of fills vs
-// 480 + 50 for the scatter kernel; what is left is the wave-uniform bookkeeping per (pixel, RoI) pair, which a
-// lane-per-pair collection pass would cut further.
+// a fresh map is cleared by a memset first.  Measured (K=1024, 7x7, 2 x 256-ch pyramid): 245 us + ~50 us of fills vs
+// 480 + 50 for the scatter kernel.
 constexpr int GT = 8;                 // tile edge (64 pixels: 4 per wavefront, 16 wavefronts)
 constexpr int GCHUNK = 32;            // RoIs staged per pass
 constexpr int GBINS = 16;             // max pooled size per dimension
@@ -348,9 +347,9 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
                                                             const int* __restrict__ tile_list,
                                                             const int* __restrict__ active_count,
                                                             const int* __restrict__ active, int accumulate_mask) {
-  __shared__ float s_wy[GCHUNK][GT * GBINS];
-  __shared__ float s_wx[GCHUNK][GT * GBINS];
-  __shared__ int s_fy[GCHUNK][GT], s_ny[GCHUNK][GT], s_fx[GCHUNK][GT], s_nx[GCHUNK][GT];
+  __shared__ float s_wy[GCHUNK][GT * GBINS + 1];            // +1: lane-per-RoI reads hit distinct banks
+  __shared__ float s_wx[GCHUNK][GT * GBINS + 1];
+  __shared__ int s_fy[GCHUNK][GT + 1], s_ny[GCHUNK][GT + 1], s_fx[GCHUNK][GT + 1], s_nx[GCHUNK][GT + 1];
   __shared__ int s_roi[GCHUNK];
   __shared__ float s_inv[GCHUNK];
   __shared__ int s_sorted[1024];
@@ -448,23 +447,66 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
           }
           ne = 0;
         };
-        for (int j = 0; j < nch; ++j) {
-          const int ny = s_ny[j][r], nx = s_nx[j][cc];
-          if (ny == 0 || nx == 0) continue;
-          const int fy = s_fy[j][r], fx = s_fx[j][cc];
-          const int base = s_roi[j] * nbins;
-          const float inv = s_inv[j];
-          for (int a = 0; a < ny; ++a) {
-            const float wy = s_wy[j][r * GBINS + fy + a] * inv;
-            if (wy == 0.f) continue;
-            for (int q = 0; q < nx; ++q) {
-              const float w = wy * s_wx[j][cc * GBINS + fx + q];
-              if (w == 0.f) continue;
-              if (lane == 0) {
-                s_ew[wave][ne] = w;
-                s_eo[wave][ne] = base + (fy + a) * PW + fx + q;
+        // collection, one lane per RoI of the chunk: count this pixel's non-zero bins, exclusive prefix over the
+        // lanes (RoI order = list order, so the summation order stays fixed), then each lane writes its entries
+        int ny = 0, nx = 0, fy = 0, fx = 0, base = 0, cnt = 0;
+        float inv = 0.f;
+        if (lane < nch) {
+          ny = s_ny[lane][r]; nx = s_nx[lane][cc];
+          if (ny != 0 && nx != 0) {
+            fy = s_fy[lane][r]; fx = s_fx[lane][cc];
+            base = s_roi[lane] * nbins;
+            inv = s_inv[lane];
+            for (int a = 0; a < ny; ++a) {
+              const float wy = s_wy[lane][r * GBINS + fy + a] * inv;
+              if (wy == 0.f) continue;
+              for (int q = 0; q < nx; ++q) cnt += (wy * s_wx[lane][cc * GBINS + fx + q] != 0.f) ? 1 : 0;
+            }
+          }
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+          const int t = __shfl_up(incl, d, 64);
+          if (lane >= d) incl += t;
+        }
+        const int total = __shfl(incl, 63, 64);
+        if (total <= GLIST) {
+          int slot = incl - cnt;
+          if (cnt != 0) {
+            for (int a = 0; a < ny; ++a) {
+              const float wy = s_wy[lane][r * GBINS + fy + a] * inv;
+              if (wy == 0.f) continue;
+              for (int q = 0; q < nx; ++q) {
+                const float w = wy * s_wx[lane][cc * GBINS + fx + q];
+                if (w == 0.f) continue;
+                s_ew[wave][slot] = w;
+                s_eo[wave][slot] = base + (fy + a) * PW + fx + q;
+                ++slot;
               }
-              if (++ne == GLIST) flush();
+            }
+          }
+          ne = total;
+        } else {
+          // more bins than the list holds (tiny RoIs spread over few pixels): wave-uniform walk with flushes
+          for (int j = 0; j < nch; ++j) {
+            const int jy = s_ny[j][r], jx = s_nx[j][cc];
+            if (jy == 0 || jx == 0) continue;
+            const int gy = s_fy[j][r], gx = s_fx[j][cc];
+            const int jbase = s_roi[j] * nbins;
+            const float jinv = s_inv[j];
+            for (int a = 0; a < jy; ++a) {
+              const float wy = s_wy[j][r * GBINS + gy + a] * jinv;
+              if (wy == 0.f) continue;
+              for (int q = 0; q < jx; ++q) {
+                const float w = wy * s_wx[j][cc * GBINS + gx + q];
+                if (w == 0.f) continue;
+                if (lane == 0) {
+                  s_ew[wave][ne] = w;
+                  s_eo[wave][ne] = jbase + (gy + a) * PW + gx + q;
+                }
+                if (++ne == GLIST) flush();
+              }
             }
           }
         }
