@@ -314,6 +314,9 @@ def main():
                          "1e-3); f32 = exact fp32 MFMA.  The other mode is timed too and reported beside.")
     ap.add_argument("--no-other-math", action="store_true", help="skip the timing of the other conv arithmetic "
                                                                   "(profiling runs)")
+    ap.add_argument("--host-input", action="store_true", help="extra leg (N=1): every step starts from decoded uint8 "
+                    "images in HOST memory (480x800) -> one pinned copy + cpm_image_prep -> train step; reported as "
+                    "config.host_input (the PCIe-inclusive rate); `value` stays the HBM-resident number")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
                     "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
@@ -393,6 +396,39 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_other = float(t.item())
         _hip.set_conv_math(a.conv_math)
+    host_input = None
+    if a.host_input and world == 1:
+        from pet.utils.data.collate_batch import DeferredBatch
+        from pet.utils.data.transforms.transforms import DeferredImage
+        import numpy as np
+        rng = np.random.default_rng(7)
+        raw = [rng.integers(0, 256, (480, 800, 3), dtype=np.uint8) for _ in range(a.batch)]
+        oh, ow = a.height, min(a.width, int(a.height * 800 / 480))
+
+        def make_batch():
+            ims = []
+            for px in raw:
+                im = DeferredImage(px)
+                im.out_hw, im.flip, im.as_tensor = (oh, ow), False, True
+                im.norm = ((102.9801, 115.9465, 122.7717), (1.0, 1.0, 1.0), True)
+                ims.append(im)
+            return DeferredBatch(ims, 32)
+        tg = [t.resize((ow, oh)) for t in targets]
+        for _ in range(3):
+            trainer.step(make_batch().to(device), tg)
+        sync()
+        t1 = time.perf_counter()
+        k_h = max(1, min(a.steps, 10))
+        for _ in range(k_h):
+            trainer.step(make_batch().to(device), tg)
+        sync()
+        el_h = time.perf_counter() - t1
+        for _ in range(3):
+            trainer.step(images, targets)
+        sync()
+        host_input = {"img_per_s": round(a.batch * k_h / el_h, 3), "ms_per_step": round(el_h / k_h * 1e3, 2),
+                      "steps": k_h, "what": "per step: %d uint8 480x800 host images -> one pinned H2D copy -> "
+                      "cpm_image_prep (resize to %dx%d, BGR, normalise, pad) -> training step" % (a.batch, oh, ow)}
     hbm = None
     if not a.no_roofline and rank == 0:
         hbm = hbm_kernel_rooflines(device, a.batch, a.height, a.width, counts.get("cls", 512 * a.batch))
@@ -420,6 +456,7 @@ def main():
                            "mode": other, "img_per_s": round(a.batch * world * k_other / el_other, 3),
                            "ms_per_step": round(1000.0 * el_other / k_other, 2), "steps": k_other},
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
+                       **({"host_input": host_input} if host_input else {}),
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,
