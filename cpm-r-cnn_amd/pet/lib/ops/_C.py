@@ -118,6 +118,41 @@ def nms(dets, scores, iou_threshold):
     return keep[: int(counts.item())]
 
 
+SOFT_NMS_MAX = 2048
+
+
+def soft_nms_segments(dets, scores, offsets, sigma, iou_threshold, min_score, method):
+    """Batched device soft-NMS (cpm_soft_nms_batched) over segments (host list `offsets`, len P+1 <= 65, at most 2048
+    boxes per segment).  Returns (boxes [N,4], scores [N], idx int64 [N], counts int32 [P] on the device): segment p's
+    survivors occupy rows [off[p], off[p] + counts[p]) in the reference's output order."""
+    H.require_gpu(dets, scores)
+    P = len(offsets) - 1
+    N = int(offsets[-1])
+    b, s = dets.contiguous(), scores.contiguous()
+    ob = torch.empty((max(N, 1), 4), dtype=torch.float32, device=dets.device)
+    osc = torch.empty((max(N, 1),), dtype=torch.float32, device=dets.device)
+    oi = torch.empty((max(N, 1),), dtype=torch.int64, device=dets.device)
+    counts = torch.empty((max(P, 1),), dtype=torch.int32, device=dets.device)
+    off = (ctypes.c_int32 * (P + 1))(*[int(o) for o in offsets])
+    with torch.cuda.device(dets.device):
+        rc = H.lib().cpm_soft_nms_batched(H.ptr(b), H.ptr(s), off, P, H.f(iou_threshold), int(method), H.f(sigma),
+                                          H.f(min_score), H.ptr(ob), H.ptr(osc), H.ptr(oi), H.ptr(counts), H.stream())
+    H.check(rc, "soft_nms_batched")
+    return ob[:N], osc[:N], oi[:N], counts[:P]
+
+
+def soft_nms(dets, scores, sigma, iou_threshold, min_score, method):
+    """soft_nms.h:19-40 (argument order of the reference binding): (dets [m,4], scores [m], indices [m])."""
+    n = dets.size(0)
+    if n == 0:
+        return (torch.empty((0, 4), dtype=dets.dtype, device=dets.device),
+                torch.empty((0,), dtype=dets.dtype, device=dets.device),
+                torch.empty((0,), dtype=torch.int64, device=dets.device))
+    b, s, i, c = soft_nms_segments(dets.float(), scores.float(), [0, n], sigma, iou_threshold, min_score, method)
+    m = int(c.item())
+    return b[:m], s[:m], i[:m]
+
+
 def box_iou(boxes, query_boxes):
     """box_iou.h:13-30: dense [N,K] IoU, areas without +1."""
     H.require_gpu(boxes, query_boxes)
@@ -156,6 +191,23 @@ def pool_points_interp_backward(grad, rois, spatial_scale, batch_size, channels,
     return gin
 
 
+def box_voting(top_boxes, top_scores, all_boxes, all_scores, scoring_method, beta, overlap_thresh):
+    """box_voting.h (argument order of the reference binding): (voted boxes [N,4], re-estimated scores [N])."""
+    H.require_gpu(top_boxes, top_scores, all_boxes, all_scores)
+    n, k = top_boxes.size(0), all_boxes.size(0)
+    ob = torch.empty((n, 4), dtype=torch.float32, device=top_boxes.device)
+    osc = torch.empty((n,), dtype=torch.float32, device=top_boxes.device)
+    if n == 0:
+        return ob, osc
+    with torch.cuda.device(top_boxes.device):
+        rc = H.lib().cpm_box_voting(H.ptr(top_boxes.float().contiguous()), H.ptr(top_scores.float().contiguous()), n,
+                                    H.ptr(all_boxes.float().contiguous()), H.ptr(all_scores.float().contiguous()), k,
+                                    int(scoring_method), H.f(beta), H.f(overlap_thresh), H.ptr(ob), H.ptr(osc),
+                                    H.stream())
+    H.check(rc, "box_voting")
+    return ob, osc
+
+
 def _not_on_hot_path(name):
     def fn(*a, **k):
         raise RuntimeError("_C.%s is outside the CPM R-CNN hot path and is not provided by cpm-r-cnn_amd" % name)
@@ -164,7 +216,7 @@ def _not_on_hot_path(name):
 
 
 # names bound by vision.cpp:21-47 that no BASELINE config reaches (out of scope)
-for _n in ("soft_nms", "ml_soft_nms", "nms_rotated", "poly_nms", "box_voting", "box_ml_voting", "box_iou_rotated",
+for _n in ("ml_soft_nms", "nms_rotated", "poly_nms", "box_ml_voting", "box_iou_rotated",
            "roi_align_rotated_forward", "roi_align_rotated_backward", "roi_pool_forward", "roi_pool_backward",
            "sigmoid_focalloss_forward", "sigmoid_focalloss_backward"):
     globals()[_n] = _not_on_hot_path(_n)

@@ -11,3 +11,14 @@ def ml_nms(boxes, scores, labels, iou_threshold, topk=0):
 
 
 nms_segments = _C.nms_segments
+
+SOFT_NMS_METHODS = {"hard": 0, "linear": 1, "gaussian": 2}          # nms.py:5
+
+
+def soft_nms(dets, scores, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="linear"):
+    """Soft-NMS (https://arxiv.org/abs/1704.04503) on the device; reference: nms.py:16-28 (a CPU kernel there)."""
+    assert method in SOFT_NMS_METHODS, "Unknown soft_nms method: {}".format(method)
+    return _C.soft_nms(dets, scores, sigma, overlap_thresh, score_thresh, SOFT_NMS_METHODS[method])
+
+
+soft_nms_segments = _C.soft_nms_segments

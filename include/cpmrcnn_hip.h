@@ -240,6 +240,25 @@ int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, cons
 int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,
                                 void* stream);
 
+/* ---- soft-NMS on the device, batched over segments (classes) ----------------------------
+ * Replaces pet/lib/ops/nms.py:16-28 -> csrc/NMS/soft_nms.cpp:5-160 (a CPU kernel called per class after a device->host
+ * copy, boxlist_ops.py:86-90).  Segment p = rows [h_offsets[p], h_offsets[p+1]) (HOST offsets, <= 64 segments,
+ * <= 2048 boxes each).  method: 0 hard, 1 linear, 2 gaussian (SOFT_NMS_METHODS).  Results of segment p are written
+ * at its own offset, in the reference's output order: out_counts[p] boxes with their DECAYED scores and their index
+ * inside the segment.  Linear / hard: bit-identical to the reference; gaussian: device expf. */
+int cpm_soft_nms_batched(const float* boxes, const float* scores, const int32_t* h_offsets, int P, float iou_threshold,
+                         int method, float sigma, float min_score, float* out_boxes, float* out_scores,
+                         int64_t* out_idx, int32_t* out_counts, void* stream);
+
+/* ---- bounding-box voting ---------------------------------------------------------------------
+ * Replaces _C.box_voting (pet/lib/ops/boxes.py:6-22 -> csrc/Box_ops/box_voting.cu:24-210): every top box becomes the
+ * score-weighted mean of the candidate boxes with IoU >= threshold; scoring_method 0 ID, 1 TEMP_AVG, 2 AVG,
+ * 3 IOU_AVG, 4 GENERALIZED_AVG, 5 QUASI_SUM re-estimates its score.  boxes [N,4] / scores [N]: top detections;
+ * query_* [K,4] / [K]: all detections of the class.  One launch, no [N,K,7] intermediate. */
+int cpm_box_voting(const float* boxes, const float* scores, int N, const float* query_boxes, const float* query_scores,
+                   int K, int scoring_method, float beta, float threshold, float* out_boxes, float* out_scores,
+                   void* stream);
+
 /* ---- row-wise top-k for the RPN proposal selection --------------------------------------
  * Replaces `objectness.topk(pre_nms_top_n, dim=1, sorted=True)` of pet/rcnn/modeling/rpn/inference.py:79-84 (torch's
  * multi-kernel radix top-k, one call per FPN level).  scores [rows][n] fp32; for every row the k largest values in

@@ -1,4 +1,4 @@
-"""Compile the reference's own CPU RoIAlign into oracle/_ref/ (git-ignored).
+"""Compile the reference's own CPU RoIAlign and soft-NMS into oracle/_ref/ (git-ignored).
 
 Recipe only: sources are read from /root/reference where they lie, nothing is
 copied.  Runs in the build container; the GPU box ships the prebuilt .so.
@@ -20,8 +20,10 @@ def build(verbose=False):
     from torch.utils.cpp_extension import load
     # a CPU-only C++ build: keep hipcc out of it
     return load(name="cpm_ref", sources=[os.path.join(REF, "ROIAlign", "ROIAlign_cpu.cpp"),
+                                         os.path.join(REF, "NMS", "soft_nms.cpp"),
                                          os.path.join(HERE, "ref_binding.cpp")],
-                extra_include_paths=[os.path.join(REF, "ROIAlign")], extra_cflags=["-O2", "-ffp-contract=off"],
+                extra_include_paths=[os.path.join(REF, "ROIAlign"), os.path.join(REF, "NMS")],
+                extra_cflags=["-O2", "-ffp-contract=off"],
                 build_directory=out, verbose=verbose, with_cuda=False)
 
 

@@ -17,6 +17,9 @@
  *                        ml_nms (ml_nms.h:38) and nms lives in torchvision
  *                        (absent, unpinned version).  Restated from ml_nms.cu
  *                        and checked against a brute-force greedy in tests.
+ *   orc_soft_nms         pinned against oracle/_ref (the reference's own
+ *                        NMS/soft_nms.cpp compiled here) through
+ *                        tests/golden/soft_nms.npz
  *   orc_deform_conv      PARITY UNPINNED (CUDA-only op in the reference; see its
  *                        section header for what pins it instead).
  *   the box/level/grid helpers are pinned by goldens produced by importing the
@@ -239,6 +242,54 @@ ORC_API int64_t orc_ml_nms(const float* boxes, const float* scores,
 ORC_API int64_t orc_nms(const float* boxes, const float* scores, int64_t n,
                         float thr, int64_t* keep) {
   return orc_ml_nms(boxes, scores, NULL, n, thr, 0, keep);
+}
+
+/* Soft-NMS -- pet/lib/ops/csrc/NMS/soft_nms.cpp:5-110.  boxes [n,4], scores [n] */
+/* are reordered IN PLACE as the reference does; idx[n] receives the original     */
+/* indices; returns the number of survivors (the first `ret` rows).               */
+/* method 1 linear, 2 gaussian, otherwise hard (SOFT_NMS_METHODS, nms.py:5).      */
+ORC_API int64_t orc_soft_nms(float* boxes, float* scores, int64_t* idx, int64_t n, float thr, int method,
+                             float sigma, float min_score) {
+  float* area = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+  for (int64_t i = 0; i < n; ++i) {
+    area[i] = (boxes[4 * i + 2] - boxes[4 * i]) * (boxes[4 * i + 3] - boxes[4 * i + 1]);   /* :22 */
+    idx[i] = i;
+  }
+  int64_t nd = n;
+  for (int64_t i = 0; i < nd; ++i) {
+    int64_t mp = i;                                             /* :30-38 first position of the maximum */
+    float ms = scores[i];
+    for (int64_t q = i + 1; q < nd; ++q)
+      if (ms < scores[q]) { ms = scores[q]; mp = q; }
+    float b[4], sc = scores[mp], ar = area[mp];                 /* :41-66 swap to the front */
+    int64_t id = idx[mp];
+    memcpy(b, boxes + 4 * mp, sizeof b);
+    memcpy(boxes + 4 * mp, boxes + 4 * i, sizeof b);
+    scores[mp] = scores[i]; area[mp] = area[i]; idx[mp] = idx[i];
+    memcpy(boxes + 4 * i, b, sizeof b);
+    scores[i] = sc; area[i] = ar; idx[i] = id;
+    for (int64_t q = i + 1; q < nd; ++q) {                      /* :70-108 decay, drop by swapping with the last */
+      const float* c = boxes + 4 * q;
+      float inter = fmaxf(0.f, fminf(b[2], c[2]) - fmaxf(b[0], c[0])) *
+                    fmaxf(0.f, fminf(b[3], c[3]) - fmaxf(b[1], c[1]));
+      float ovr = inter / (ar + area[q] - inter);
+      if (method == 1) {
+        if (ovr > thr) scores[q] = (1.f - ovr) * scores[q];
+      } else if (method == 2) {
+        scores[q] = expf(-(ovr * ovr) / sigma) * scores[q];
+      } else {
+        if (ovr > thr) scores[q] = 0.f;
+      }
+      if (scores[q] < min_score) {
+        --nd;
+        memcpy(boxes + 4 * q, boxes + 4 * nd, sizeof b);
+        scores[q] = scores[nd]; area[q] = area[nd]; idx[q] = idx[nd];
+        --q;
+      }
+    }
+  }
+  free(area);
+  return nd;
 }
 
 /* box_iou -- pet/lib/ops/csrc/Box_ops/box_iou.cu:27-77 (no +1), out [N,K]     */

@@ -79,6 +79,17 @@ def nms(boxes, scores, thr):
     return keep[:nk].copy()
 
 
+def soft_nms(boxes, scores, sigma=0.5, thr=0.3, min_score=0.001, method=1):
+    """-> (boxes [m,4], decayed scores [m], original indices [m]) in the reference's output order."""
+    b, sc = _f32(boxes).reshape(-1, 4).copy(), _f32(scores).copy()
+    n = b.shape[0]
+    idx = np.zeros(max(n, 1), np.int64)
+    lib().orc_soft_nms.restype = ctypes.c_int64
+    m = lib().orc_soft_nms(_p(b), _p(sc), _p(idx), ctypes.c_int64(n), ctypes.c_float(thr), int(method),
+                           ctypes.c_float(sigma), ctypes.c_float(min_score))
+    return b[:m].copy(), sc[:m].copy(), idx[:m].copy()
+
+
 def box_iou(boxes, query):
     boxes, query = _f32(boxes).reshape(-1, 4), _f32(query).reshape(-1, 4)
     out = np.zeros((boxes.shape[0], query.shape[0]), np.float32)
@@ -282,3 +293,37 @@ def image_prep(img, out_hw, flip, mean, std, to_bgr255, pad_hw):
     out = np.zeros((3, pad_hw[0], pad_hw[1]), np.float32)
     out[:, : t.shape[1], : t.shape[2]] = t
     return out
+
+
+def box_voting(top_boxes, top_scores, all_boxes, all_scores, thr, method=0, beta=1.0):
+    """numpy restatement of pet/lib/ops/csrc/Box_ops/box_voting.cu:24-210 (fp32 per pair, float64 sums).
+    PARITY UNPINNED against the reference binary: the op is CUDA-only there and its tests hold no vectors; pinned by
+    the known answers in tests/test_gpu_ops.py (a lone box votes for itself; equal weights give the mean box)."""
+    tb, ab = _f32(top_boxes).reshape(-1, 4), _f32(all_boxes).reshape(-1, 4)
+    ts, as_ = _f32(top_scores), _f32(all_scores)
+    iou = box_iou(tb, ab)
+    out_b, out_s = np.zeros_like(tb), ts.copy()
+    for i in range(tb.shape[0]):
+        m = iou[i] >= np.float32(thr)
+        w = as_[m]
+        sw = np.ones_like(w)
+        sc = w.copy()
+        if method == 1:
+            nz = w != 0
+            sc[nz] = np.float32(1) / (np.float32(1) + np.power(np.float32(1) / w[nz] - np.float32(1),
+                                                                 np.float32(1.0 / beta), dtype=np.float32))
+        elif method == 3:
+            sw = iou[i][m]
+            sc = iou[i][m] * w
+        elif method == 4:
+            sc = np.power(w, np.float32(beta), dtype=np.float32)
+        bw = w.astype(np.float64).sum()
+        out_b[i] = (ab[m].astype(np.float64) * w[:, None].astype(np.float64)).sum(0) / bw
+        num, ssum = sw.astype(np.float64).sum(), sc.astype(np.float64).sum()
+        if method in (1, 2, 3):
+            out_s[i] = ssum / num
+        elif method == 4:
+            out_s[i] = (ssum / num) ** (1.0 / beta)
+        elif method == 5:
+            out_s[i] = ssum / num ** beta
+    return out_b, out_s

@@ -398,6 +398,35 @@ def gen_cascade():
     print("cascade:", len(meta["state_dict"]), "keys;", {k: float(v) for k, v in out.items() if k.startswith("loss::")})
 
 
+def gen_soft_nms(ref_ext):
+    """soft_nms_cpu of the reference (csrc/NMS/soft_nms.cpp compiled into oracle/_ref) on seeded box sets: all three
+    methods, ties in the scores, heavy overlap (many removals), n = 0 / 1."""
+    out = {}
+    rng = np.random.default_rng(42)
+    cases = []
+    for n, span, method, sigma, thr, ms in [(200, 300, 1, 0.5, 0.3, 0.001), (200, 300, 2, 0.5, 0.3, 0.001),
+                                            (200, 300, 0, 0.5, 0.5, 0.001), (500, 150, 1, 0.5, 0.3, 0.05),
+                                            (500, 150, 2, 0.3, 0.3, 0.05), (64, 60, 1, 0.5, 0.1, 0.2),
+                                            (1, 50, 1, 0.5, 0.3, 0.001), (0, 50, 1, 0.5, 0.3, 0.001),
+                                            (1500, 400, 1, 0.5, 0.3, 0.0001)]:
+        xy = rng.uniform(0, span, (n, 2))
+        wh = rng.uniform(4, 120, (n, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        scores = rng.uniform(0, 1, n).astype(np.float32)
+        if n > 10:
+            scores[5:9] = scores[4]                      # exact ties: the first position wins
+            boxes[10] = boxes[3]                         # duplicate box
+        cases.append((boxes, scores, method, sigma, thr, ms))
+    for i, (boxes, scores, method, sigma, thr, ms) in enumerate(cases):
+        d, s_, k = ref_ext.soft_nms_cpu(torch.from_numpy(boxes.copy()), torch.from_numpy(scores.copy()), thr, method,
+                                        sigma, ms)
+        out["c%d_boxes" % i], out["c%d_scores" % i] = boxes, scores
+        out["c%d_cfg" % i] = np.array([method, sigma, thr, ms], np.float64)
+        out["c%d_out_boxes" % i], out["c%d_out_scores" % i], out["c%d_out_idx" % i] = d.numpy(), s_.numpy(), k.numpy()
+    np.savez_compressed(os.path.join(HERE, "soft_nms.npz"), **out)
+    print("soft_nms:", len(cases), "cases; kept", [int(out["c%d_out_idx" % i].shape[0]) for i in range(len(cases))])
+
+
 def _load_ref_file(rel, name):
     import importlib.util
     spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
@@ -475,6 +504,8 @@ def gen_data_pipeline():
 def main():
     ref_ext = build_ref()
     assert ref_ext is not None, "needs /root/reference"
+    if sys.argv[1:] == ["softnms"]:
+        return gen_soft_nms(ref_ext)
     install_standins(ref_ext)
     if sys.argv[1:] == ["x101"]:
         return gen_x101_meta()

@@ -1,5 +1,7 @@
 """GPU parity tests (run with -m gpu on the MI355X box): HIP RoIAlign / NMS / box ops through the
 C ABI (pet.lib.ops._C -> libcpmrcnn_hip.so) against the CPU oracle and the reference goldens."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -293,3 +295,149 @@ def test_roi_align_fpn_gather_backward_full_size():
             torch.testing.assert_close(x, y, rtol=1e-4, atol=1e-4)
         total = sum(float(t.double().sum()) for t in a)
         assert abs(total - float(go.double().sum())) < 1e-2 + 1e-4 * float(go.double().abs().sum()) ** 0.5
+
+
+def test_soft_nms_vs_reference_golden(oracle):
+    """Device soft-NMS against the reference's soft_nms.cpp outputs (tests/golden/soft_nms.npz): same survivors in the
+    same order; linear / hard scores bit-equal, gaussian within expf rounding."""
+    import pet.lib.ops as ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
+    names = {0: "hard", 1: "linear", 2: "gaussian"}
+    for i in range(len([k for k in g.files if k.endswith("_cfg")])):
+        method, sigma, thr, ms = g["c%d_cfg" % i]
+        b, s, k = ops.soft_nms(dev(g["c%d_boxes" % i]).reshape(-1, 4), dev(g["c%d_scores" % i]), sigma, thr, ms,
+                               names[int(method)])
+        assert np.array_equal(k.cpu().numpy(), g["c%d_out_idx" % i]), i
+        assert np.array_equal(b.cpu().numpy(), g["c%d_out_boxes" % i].reshape(-1, 4)), i
+        if int(method) == 2:
+            np.testing.assert_allclose(s.cpu().numpy(), g["c%d_out_scores" % i], rtol=2e-6, atol=1e-7)
+        else:
+            assert np.array_equal(s.cpu().numpy(), g["c%d_out_scores" % i]), i
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_soft_nms_segments_vs_oracle(oracle, method):
+    """80 class segments of ragged sizes (0 .. 2048 boxes) in two launches, each against the C oracle."""
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(17 + method)
+    sizes = [0, 1, 2, 63, 64, 65, 300, 2048] + list(rng.integers(0, 400, 72))
+    boxes = np.concatenate([_rand_boxes(rng, n, 250) for n in sizes]).astype(np.float32)
+    scores = rng.uniform(0, 1, boxes.shape[0]).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    for lo in (0, 64):
+        seg = offs[lo:lo + 65] if lo + 64 < len(offs) else offs[lo:]
+        a, z = int(seg[0]), int(seg[-1])
+        b, s, k, c = ops.soft_nms_segments(dev(boxes[a:z]), dev(scores[a:z]), [int(o) - a for o in seg], 0.5, 0.3,
+                                           0.02, method)
+        c = c.cpu().numpy()
+        for j in range(len(seg) - 1):
+            o0, o1 = int(seg[j]) - a, int(seg[j + 1]) - a
+            wb, wsc, wk = oracle.soft_nms(boxes[a + o0:a + o1], scores[a + o0:a + o1], 0.5, 0.3, 0.02, method)
+            assert c[j] == len(wk), (lo, j)
+            assert np.array_equal(k[o0:o0 + c[j]].cpu().numpy(), wk)
+            assert np.array_equal(b[o0:o0 + c[j]].cpu().numpy(), wb.reshape(-1, 4))
+            if method == 2:
+                np.testing.assert_allclose(s[o0:o0 + c[j]].cpu().numpy(), wsc, rtol=2e-6, atol=1e-7)
+            else:
+                assert np.array_equal(s[o0:o0 + c[j]].cpu().numpy(), wsc)
+
+
+def test_soft_nms_boxlist_and_errors():
+    import pet.lib.ops as ops
+    from pet.lib.ops.boxlist_ops import boxlist_soft_nms
+    from pet.utils.data.structures.bounding_box import BoxList
+    rng = np.random.default_rng(5)
+    bl = BoxList(dev(_rand_boxes(rng, 50, 100)), (400, 300))
+    bl.add_field("scores", dev(rng.uniform(0, 1, 50).astype(np.float32)))
+    out = boxlist_soft_nms(bl, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="linear")
+    assert out.has_field("scores") and 0 < len(out) <= 50
+    sc = out.get_field("scores")
+    assert boxlist_soft_nms(bl, overlap_thresh=0) is bl
+    assert float(sc[0]) == float(bl.get_field("scores").max())          # the first pick keeps its score
+    e = ops.soft_nms(torch.zeros(0, 4, device="cuda"), torch.zeros(0, device="cuda"))
+    assert e[0].shape == (0, 4) and e[2].dtype == torch.int64
+    with pytest.raises(RuntimeError):
+        ops.soft_nms(torch.zeros(2049, 4, device="cuda"), torch.zeros(2049, device="cuda"))
+    with pytest.raises(AssertionError):
+        ops.soft_nms(torch.zeros(4, 4, device="cuda"), torch.zeros(4, device="cuda"), method="nope")
+
+
+@pytest.mark.parametrize("method", ["ID", "TEMP_AVG", "AVG", "IOU_AVG", "GENERALIZED_AVG", "QUASI_SUM"])
+def test_box_voting_vs_oracle(oracle, method):
+    import pet.lib.ops as ops
+    from pet.lib.ops.boxes import BOX_VOTING_METHODS
+    rng = np.random.default_rng(23)
+    allb = _rand_boxes(rng, 700, 200)
+    alls = rng.uniform(0.05, 1, 700).astype(np.float32)
+    top = np.sort(rng.choice(700, 90, replace=False))
+    beta = 1.5 if method in ("TEMP_AVG", "GENERALIZED_AVG", "QUASI_SUM") else 1.0
+    b, s = ops.box_voting(dev(allb[top]), dev(alls[top]), dev(allb), dev(alls), 0.6, method, beta)
+    wb, ws = oracle.box_voting(allb[top], alls[top], allb, alls, 0.6, BOX_VOTING_METHODS[method], beta)
+    np.testing.assert_allclose(b.cpu().numpy(), wb, rtol=2e-5, atol=1e-4)
+    np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=2e-5, atol=1e-6)
+
+
+def test_box_voting_known_answers():
+    import pet.lib.ops as ops
+    box = torch.tensor([[10., 20., 50., 80.]], device="cuda")
+    far = torch.tensor([[300., 300., 340., 350.]], device="cuda")
+    b, s = ops.box_voting(box, torch.tensor([0.7], device="cuda"), torch.cat([box, far]),
+                          torch.tensor([0.7, 0.9], device="cuda"), 0.5, "AVG")
+    assert torch.allclose(b, box) and abs(float(s) - 0.7) < 1e-6              # a lone box votes for itself
+    two = torch.tensor([[10., 20., 50., 80.], [12., 22., 52., 82.]], device="cuda")
+    b, s = ops.box_voting(two[:1], torch.tensor([0.9], device="cuda"), two, torch.tensor([0.5, 0.5], device="cuda"), 0.5,
+                          "ID")
+    assert torch.allclose(b, two.mean(0, keepdim=True)) and abs(float(s) - 0.9) < 1e-7   # equal weights: the mean box
+    e = ops.box_voting(two[:0], torch.zeros(0, device="cuda"), two, torch.ones(2, device="cuda"), 0.5)
+    assert e[0].shape == (0, 4)
+
+
+@pytest.mark.parametrize("mode", ["ml_nms", "soft", "soft_vote", "vote"])
+def test_filter_results_modes(oracle, mode):
+    """pet/rcnn/core/test.py filter_results: every branch against a per-class numpy evaluation with the oracle."""
+    from pet.rcnn.core import config
+    from pet.rcnn.core.test import filter_results
+    from pet.utils.data.structures.bounding_box import BoxList
+    rng = np.random.default_rng(31)
+    C, R = 81, 120
+    config.reset_cfg()
+    config.merge_cfg_from_list(["MODEL.NUM_CLASSES", C, "FAST_RCNN.SCORE_THRESH", 0.3, "FAST_RCNN.NMS", 0.5,
+                                "FAST_RCNN.DETECTIONS_PER_IMG", 60, "TEST.SOFT_NMS.ENABLED", "soft" in mode,
+                                "TEST.BBOX_VOTE.ENABLED", "vote" in mode, "TEST.BBOX_VOTE.SCORING_METHOD", "AVG"])
+    try:
+        base = _rand_boxes(rng, R, 300)
+        boxes = np.repeat(base, C, axis=0) + rng.uniform(-2, 2, (R * C, 4)).astype(np.float32)
+        scores = (rng.uniform(0, 1, R * C) ** 6).astype(np.float32)
+        labels = np.tile(np.arange(C), R)
+        bl = BoxList(dev(boxes), (640, 480))
+        bl.add_field("scores", dev(scores))
+        if mode != "ml_nms":
+            bl.add_field("labels", torch.from_numpy(labels).cuda())
+        out = filter_results(bl)
+        ob, os_, ol = out.bbox.cpu().numpy(), out.get_field("scores").cpu().numpy(), out.get_field("labels").cpu().numpy()
+        # numpy evaluation
+        wb, ws, wl = [], [], []
+        for j in range(1, C):
+            m = (labels == j) & (scores > 0.3)
+            cb, cs = boxes[m], scores[m]
+            if mode in ("ml_nms", "vote"):
+                k = oracle.nms(cb, cs, 0.5)
+                kb, ks = cb[k], cs[k]
+            else:
+                kb, ks, _ = oracle.soft_nms(cb, cs, 0.5, 0.5, 0.0001, 1)
+            if "vote" in mode and len(cb):
+                kb, ks = oracle.box_voting(kb, ks, cb, cs, 0.8, 2, 1.0)
+            wb.append(kb.reshape(-1, 4)); ws.append(ks); wl.append(np.full(len(ks), j))
+        wb, ws, wl = np.concatenate(wb), np.concatenate(ws), np.concatenate(wl)
+        if len(ws) > 60:
+            th = np.sort(ws)[len(ws) - 60]
+            sel = ws >= th
+            wb, ws, wl = wb[sel], ws[sel], wl[sel]
+        key_got = np.lexsort((os_, ol))
+        key_want = np.lexsort((ws, wl))
+        assert len(os_) == len(ws)
+        assert np.array_equal(ol[key_got], wl[key_want])
+        np.testing.assert_allclose(os_[key_got], ws[key_want], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(ob[key_got], wb[key_want], rtol=1e-5, atol=1e-3)
+    finally:
+        config.reset_cfg()

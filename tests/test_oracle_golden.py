@@ -1,5 +1,7 @@
 """Pins the CPU oracle (oracle/cpm_oracle.c) to vectors produced by the reference itself
 (tests/golden/make_golden.py).  CPU-only."""
+import os
+
 import numpy as np
 import pytest
 
@@ -115,3 +117,17 @@ def test_nms_against_bruteforce(oracle):
             assert got.tolist() == keep
         assert oracle.ml_nms(boxes, scores, labels, 0.5, topk=3).tolist() == oracle.ml_nms(boxes, scores, labels, 0.5)[:3].tolist()
     assert oracle.nms(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).size == 0
+
+
+def test_soft_nms_oracle_is_reference(oracle):
+    """orc_soft_nms against the reference's own soft_nms.cpp (compiled into oracle/_ref by build_ref.py; vectors in
+    tests/golden/soft_nms.npz): surviving boxes, decayed scores and original indices, in output order, bit for bit."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
+    n_cases = len([k for k in g.files if k.endswith("_cfg")])
+    assert n_cases >= 9
+    for i in range(n_cases):
+        method, sigma, thr, ms = g["c%d_cfg" % i]
+        b, s, k = oracle.soft_nms(g["c%d_boxes" % i], g["c%d_scores" % i], sigma, thr, ms, int(method))
+        assert np.array_equal(k, g["c%d_out_idx" % i]), i
+        assert np.array_equal(b, g["c%d_out_boxes" % i].reshape(-1, 4)), i
+        assert np.array_equal(s, g["c%d_out_scores" % i]), i
