@@ -41,7 +41,7 @@ def roi_align_forward(input, rois, spatial_scale, pooled_height, pooled_width, s
     if K == 0:
         return out
     r = rois.contiguous()
-    with torch.cuda.device(input.device):
+    with H.guard(input.device):
         rc = H.lib().cpm_roi_align_forward(H.ptr(x), H.ptr(r), K, B, C, Hh, W, H.f(spatial_scale),
                                            int(pooled_height), int(pooled_width), int(sampling_ratio),
                                            int(bool(aligned)), int(interpolation_method), 1 if nhwc else 0,
@@ -66,7 +66,7 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     if K == 0 or grad.numel() == 0:
         return gin
     r = rois.contiguous()
-    with torch.cuda.device(grad.device):
+    with H.guard(grad.device):
         rc = H.lib().cpm_roi_align_backward(H.ptr(g), H.ptr(r), K, int(batch_size), int(channels), int(height),
                                             int(width), H.f(spatial_scale), int(pooled_height), int(pooled_width),
                                             int(sampling_ratio), int(bool(aligned)), int(interpolation_method),
@@ -89,7 +89,7 @@ def nms_segments(boxes, scores, labels, offsets, iou_threshold, topk=0):
     off = (ctypes.c_int32 * (P + 1))(*[int(o) for o in offsets])
     keep = torch.empty((max(N, 1),), dtype=torch.int64, device=boxes.device)
     counts = torch.empty((P,), dtype=torch.int32, device=boxes.device)
-    with torch.cuda.device(boxes.device):
+    with H.guard(boxes.device):
         nbytes = H.lib().cpm_nms_workspace_bytes(off, P)
         ws = H.workspace(nbytes, boxes.device)
         rc = H.lib().cpm_nms_batched(H.ptr(b), H.ptr(s), H.ptr(lab), off, P, H.f(iou_threshold), int(topk),
@@ -134,7 +134,7 @@ def soft_nms_segments(dets, scores, offsets, sigma, iou_threshold, min_score, me
     oi = torch.empty((max(N, 1),), dtype=torch.int64, device=dets.device)
     counts = torch.empty((max(P, 1),), dtype=torch.int32, device=dets.device)
     off = (ctypes.c_int32 * (P + 1))(*[int(o) for o in offsets])
-    with torch.cuda.device(dets.device):
+    with H.guard(dets.device):
         rc = H.lib().cpm_soft_nms_batched(H.ptr(b), H.ptr(s), off, P, H.f(iou_threshold), int(method), H.f(sigma),
                                           H.f(min_score), H.ptr(ob), H.ptr(osc), H.ptr(oi), H.ptr(counts), H.stream())
     H.check(rc, "soft_nms_batched")
@@ -158,7 +158,7 @@ def box_iou(boxes, query_boxes):
     H.require_gpu(boxes, query_boxes)
     N, K = boxes.size(0), query_boxes.size(0)
     out = torch.empty((N, K), dtype=torch.float32, device=boxes.device)
-    with torch.cuda.device(boxes.device):
+    with H.guard(boxes.device):
         rc = H.lib().cpm_box_iou(H.ptr(boxes.contiguous()), N, H.ptr(query_boxes.contiguous()), K, H.ptr(out),
                                  H.stream())
     H.check(rc, "box_iou")
@@ -171,7 +171,7 @@ def pool_points_interp_forward(input, rois, spatial_scale):
     B, C, Hh, W = input.shape
     K = rois.size(0)
     out = torch.empty((K, C), dtype=torch.float32, device=input.device)
-    with torch.cuda.device(input.device):
+    with H.guard(input.device):
         rc = H.lib().cpm_pool_points_interp_forward(H.ptr(input.contiguous()), H.ptr(rois.contiguous()), K, B, C, Hh,
                                                     W, H.f(spatial_scale), H.ptr(out), H.stream())
     H.check(rc, "pool_points_interp_forward")
@@ -183,7 +183,7 @@ def pool_points_interp_backward(grad, rois, spatial_scale, batch_size, channels,
     H.require_gpu(grad, rois)
     K = rois.size(0)
     gin = torch.zeros((batch_size, channels, height, width), dtype=torch.float32, device=grad.device)
-    with torch.cuda.device(grad.device):
+    with H.guard(grad.device):
         rc = H.lib().cpm_pool_points_interp_backward(H.ptr(grad.contiguous()), H.ptr(rois.contiguous()), K,
                                                      int(batch_size), int(channels), int(height), int(width),
                                                      H.f(spatial_scale), H.ptr(gin), H.stream())
@@ -199,7 +199,7 @@ def box_voting(top_boxes, top_scores, all_boxes, all_scores, scoring_method, bet
     osc = torch.empty((n,), dtype=torch.float32, device=top_boxes.device)
     if n == 0:
         return ob, osc
-    with torch.cuda.device(top_boxes.device):
+    with H.guard(top_boxes.device):
         rc = H.lib().cpm_box_voting(H.ptr(top_boxes.float().contiguous()), H.ptr(top_scores.float().contiguous()), n,
                                     H.ptr(all_boxes.float().contiguous()), H.ptr(all_scores.float().contiguous()), k,
                                     int(scoring_method), H.f(beta), H.f(overlap_thresh), H.ptr(ob), H.ptr(osc),

@@ -66,7 +66,7 @@ def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, di
     if y.numel() == 0:
         return y
     ws = _ws(d, x.device)
-    with torch.cuda.device(x.device):
+    with H.guard(x.device):
         rc = H.lib().cpm_conv2d_forward(H.ctypes.byref(d), H.ptr(x), H.ptr(w), H.ptr(scale), H.ptr(shift),
                                         H.ptr(residual), int(res_mode), int(bool(relu)), H.ptr(y), H.ptr(ws),
                                         H.c_size_t(ws.numel()), H.stream())
@@ -85,7 +85,7 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
             return acc
         d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
         ws = _ws(d, dy.device)
-        with torch.cuda.device(dy.device):
+        with H.guard(dy.device):
             rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(acc), 1, H.ptr(ws),
                                                   H.c_size_t(ws.numel()), H.stream())
         H.check(rc, "conv2d_backward_data(accumulate)")
@@ -104,7 +104,7 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
     if dy.numel() == 0:
         return dx.zero_()
     ws = _ws(d, dy.device)
-    with torch.cuda.device(dy.device):
+    with H.guard(dy.device):
         rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), 0, H.ptr(ws),
                                               H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_data")
@@ -122,7 +122,7 @@ def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups):
     if dy.numel() == 0:
         return dx.zero_()
     ws = _ws(d, dy.device)
-    with torch.cuda.device(dy.device):
+    with H.guard(dy.device):
         rc = H.lib().cpm_conv2d_backward_data_gated(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), H.ptr(in_scale),
                                                     H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_data_gated")
@@ -138,7 +138,7 @@ def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None):
     if x.numel() == 0 or dy.numel() == 0:
         return dw
     ws = _ws(d, x.device)
-    with torch.cuda.device(x.device):
+    with H.guard(x.device):
         rc = H.lib().cpm_conv2d_backward_weight(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(ws),
                                                 H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_weight")
@@ -156,7 +156,7 @@ def epilogue_backward(dy, y, scale, relu, want_dpre=True, want_dres=False, want_
     if want_dshift:
         dshift = dshift_out if dshift_out is not None else torch.zeros((k,), dtype=torch.float32, device=dy.device)
     if dy.numel():
-        with torch.cuda.device(dy.device):
+        with H.guard(dy.device):
             rc = H.lib().cpm_epilogue_backward(H.ptr(dy), H.ptr(y), H.ptr(scale), int(bool(relu)), H.c_int64(m), k,
                                                H.ptr(dpre), H.ptr(dres), H.ptr(dshift), H.stream())
         H.check(rc, "epilogue_backward")
@@ -312,7 +312,7 @@ def upsample2x_add_backward(dy, top_shape):
     n, c, p, q = dy.shape
     assert tuple(top_shape) == (n, c, (p + 1) // 2, (q + 1) // 2), "top-down sizes must be 2x apart"
     dtop = empty_nhwc(top_shape, dy)
-    with torch.cuda.device(dy.device):
+    with H.guard(dy.device):
         rc = H.lib().cpm_upsample2x_add_backward(H.ptr(nhwc(dy)), n, p, q, c, H.ptr(dtop), 0, H.stream())
     H.check(rc, "upsample2x_add_backward")
     return dtop
@@ -335,7 +335,7 @@ class _ConvTransposeFn(Function):
         y = empty_nhwc((n, cout, hh, ww), x)
         if y.numel():
             ws = _ws(d, x.device)
-            with torch.cuda.device(x.device):
+            with H.guard(x.device):
                 rc = H.lib().cpm_conv_transpose2d_forward(H.ctypes.byref(d), H.ptr(x), H.ptr(w), H.ptr(bias),
                                                           int(bool(relu)), H.ptr(y), H.ptr(ws),
                                                           H.c_size_t(ws.numel()), H.stream())
@@ -375,7 +375,7 @@ class _GroupNormFn(Function):
         mean = torch.empty((n, groups), dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
         if n:
-            with torch.cuda.device(x.device):
+            with H.guard(x.device):
                 rc = H.lib().cpm_groupnorm_forward(H.ptr(x), H.ptr(gamma), H.ptr(beta), n, h * w, c, int(groups),
                                                    H.f(eps), int(bool(relu)), H.ptr(y), H.ptr(mean), H.ptr(rstd),
                                                    H.stream())
@@ -398,7 +398,7 @@ class _GroupNormFn(Function):
         dgamma = gp._cpm_grad_sink if gp is not None else torch.zeros_like(gamma)     # the kernel accumulates
         dbeta = bp._cpm_grad_sink if bp is not None else torch.zeros_like(gamma)
         if n:
-            with torch.cuda.device(x.device):
+            with H.guard(x.device):
                 rc = H.lib().cpm_groupnorm_backward(H.ptr(dy), H.ptr(x), H.ptr(y), H.ptr(gamma), H.ptr(mean),
                                                     H.ptr(rstd), n, h * w, c, int(groups), int(bool(relu)),
                                                     H.ptr(dx), H.ptr(dgamma), H.ptr(dbeta), H.stream())
@@ -427,14 +427,14 @@ def stem_forward(x, w_pad, scale, shift, r=7, s=7, stride=2, pad=3):
     p, q = out_size(h, r, stride, pad), out_size(w, s, stride, pad)
     kpad = w_pad.shape[1]
     cols = torch.empty((n * p * q, kpad), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with H.guard(x.device):
         rc = H.lib().cpm_im2col(H.ptr(xin), 1 if is_nhwc else 0, n, c, h, w, r, s, stride, pad, p, q, kpad,
                                 H.ptr(cols), H.stream())
     H.check(rc, "im2col")
     y = conv2d_forward(cols.view(n, p, q, kpad).permute(0, 3, 1, 2), w_pad, scale, shift, None, 0, True, 1, 0, 1, 1)
     pp, pq = out_size(p, 3, 2, 1), out_size(q, 3, 2, 1)
     out = empty_nhwc((n, y.shape[1], pp, pq), x)
-    with torch.cuda.device(x.device):
+    with H.guard(x.device):
         rc = H.lib().cpm_maxpool3x3s2_forward(H.ptr(y), n, p, q, y.shape[1], pp, pq, H.ptr(out), H.stream())
     H.check(rc, "maxpool")
     return out

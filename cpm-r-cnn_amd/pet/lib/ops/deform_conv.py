@@ -42,7 +42,7 @@ def sample_columns(x, offset, geom):
     n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
     cols = torch.empty((n, p, q, r * s * c), dtype=torch.float32, device=x.device)
     if cols.numel():
-        with torch.cuda.device(x.device):
+        with H.guard(x.device):
             rc = H.lib().cpm_deform_im2col(H.ptr(x), H.ptr(offset), n, h, w, c, r, s, stride, pad, dil, groups, dg,
                                            p, q, H.ptr(cols), H.stream())
         H.check(rc, "deform_im2col")
@@ -114,7 +114,7 @@ class _ColsConvFn(Function):
         if need_x or need_off:
             dcols = F.conv2d_backward_data(dpre, w1, (n, r * s * c, p, q), 1, 0, 1, groups)
             args = (n, h, wd, c, r, s, stride, pad, dil, groups, dg, p, q)
-            with torch.cuda.device(dy.device):
+            with H.guard(dy.device):
                 if need_x:
                     dx = F.empty_nhwc((n, c, h, wd), dy).zero_()
                     if dcols.numel():

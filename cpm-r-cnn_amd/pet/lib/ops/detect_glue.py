@@ -38,7 +38,7 @@ def match_rois(rois, roi_img, gts, gt_off, high, low, allow_low_quality=False):
     ws = torch.empty((G,), dtype=torch.int32, device=rois.device) if allow_low_quality else None
     roi_img = _i32(roi_img) if roi_img is not None else None
     gt_off = _i32(gt_off)
-    with torch.cuda.device(rois.device):
+    with H.guard(rois.device):
         rc = H.lib().cpm_match_rois(H.ptr(rois), H.ptr(roi_img), H.ptr(gts), H.ptr(gt_off), R, G, H.f(high),
                                     H.f(low), int(bool(allow_low_quality)), H.ptr(ws), H.ptr(matched),
                                     H.ptr(max_iou), H.stream())
@@ -67,7 +67,7 @@ class _GridBCEFn(Function):
         loss = torch.zeros((), dtype=torch.float32, device=logits.device)
         grad = torch.empty_like(logits)                      # preserve_format: same strides as the logits
         assert grad.stride() == logits.stride()
-        with torch.cuda.device(logits.device):
+        with H.guard(logits.device):
             rc = H.lib().cpm_grid_bce_loss(H.ptr(logits), strides, H.ptr(rois), H.ptr(gt_boxes), R, pts,
                                            int(map_size), sub, H.f(ratio), int(radius), H.f(weight), H.ptr(loss),
                                            H.ptr(grad), H.stream())
@@ -105,7 +105,7 @@ def grid_decode(logits, rois, map_size, sub_regions, mapping_ratio, roi_img=None
         keep = torch.empty((R,), dtype=torch.uint8, device=rois.device)
         roi_img = _i32(roi_img) if roi_img is not None else None
         gt_off = _i32(gt_off)
-    with torch.cuda.device(rois.device):
+    with H.guard(rois.device):
         rc = H.lib().cpm_grid_decode(H.ptr(logits), strides, H.ptr(rois), R, pts, int(map_size), sub,
                                      H.f(mapping_ratio), H.ptr(roi_img), H.ptr(gts), H.ptr(gt_off), H.ptr(out),
                                      H.ptr(keep), H.stream())
@@ -126,7 +126,7 @@ def rpn_decode(reg, topk_idx, anchors, weights, clip, image_sizes):
     w4 = (ctypes.c_float * 4)(*[float(v) for v in weights])
     iw = (ctypes.c_float * N)(*[float(s[0]) for s in image_sizes])
     ih = (ctypes.c_float * N)(*[float(s[1]) for s in image_sizes])
-    with torch.cuda.device(reg.device):
+    with H.guard(reg.device):
         rc = H.lib().cpm_rpn_decode(H.ptr(reg), H.ptr(idx), H.ptr(anchors), N, A, k, w4, H.f(clip), iw, ih, H.ptr(out),
                                     H.stream())
     H.check(rc, "rpn_decode")
@@ -149,7 +149,7 @@ def topk_rows(scores, k):
     s = scores if scores.is_contiguous() else scores.contiguous()
     vals = torch.empty((rows, k), dtype=torch.float32, device=s.device)
     idx = torch.empty((rows, k), dtype=torch.int64, device=s.device)
-    with torch.cuda.device(s.device):
+    with H.guard(s.device):
         rc = H.lib().cpm_topk_rows(H.ptr(s), rows, n, k, H.ptr(vals), H.ptr(idx), H.stream())
     H.check(rc, "topk_rows")
     return vals, idx

@@ -100,7 +100,7 @@ def image_prep(src, out_size, flip, lut, swap_rb, dst):
         b, k, vks = _device_tables(hgt, oh, src.device)
         vb, vk = H.ptr(b), H.ptr(k)
         keep += [b, k]
-    with torch.cuda.device(src.device):
+    with H.guard(src.device):
         rc = H.lib().cpm_image_prep(H.ptr(src), hgt, wid, hb, hk, hks, vb, vk, vks, oh, ow, int(bool(flip)),
                                     H.ptr(lut), int(bool(swap_rb)), tmp, H.ptr(dst), dh, dw, layout, H.stream())
     H.check(rc, "image_prep")

@@ -41,7 +41,7 @@ class _RoIAlignFPN(Function):
         hs, ws, sc = _tables(feats, scales)
         ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
         s0, l0, eps = canonical
-        with torch.cuda.device(rois.device):
+        with H.guard(rois.device):
             rc = H.lib().cpm_roi_align_fpn_forward(ptrs, hs, ws, sc, n, H.ptr(r), K, int(B), int(C), ph, pw,
                                                    int(sampling_ratio), H.f(lvl_min), H.f(lvl_max), H.f(s0),
                                                    H.f(l0), H.f(eps), H.ptr(out), H.ptr(levels), H.stream())
@@ -81,7 +81,7 @@ class _RoIAlignFPN(Function):
         n = len(grads)
         hs, ws, sc = _tables(grads, scales)
         ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in grads])
-        with torch.cuda.device(g.device):
+        with H.guard(g.device):
             if gather:
                 need = H.lib().cpm_roi_align_fpn_gather_workspace_bytes(hs, ws, n, int(shapes[0][0]), K)
                 wsb = H.workspace(need, g.device)
