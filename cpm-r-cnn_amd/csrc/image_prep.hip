@@ -8,7 +8,7 @@
 // bit-identical to the host pipeline (tests/test_gpu_image_prep.py checks against PIL itself).
 //
 // Tap tables (bounds + Q22 coefficients) are computed on the host in double precision exactly as Pillow's
-// precompute_coeffs / normalize_coeffs_8bpc do (pet/utils/data/transforms/device.py); the per-value arithmetic of
+// precompute_coeffs / normalize_coeffs_8bpc do (pet/lib/ops/image_prep.py: resample_tables); the per-value arithmetic of
 // ToTensor/Normalize ((v / 255) * 255 - mean) / std is a 3 x 256 fp32 table built with the same fp32 operations.
 #include "common.h"
 
@@ -100,6 +100,38 @@ __global__ void __launch_bounds__(256) resize_v_kernel(const uint8_t* __restrict
   }
 }
 
+// Test-time resize (pet/rcnn/core/test.py:340-358 get_blob): the reference converts the BGR uint8 image to float32,
+// optionally mirrors it, and calls cv2.resize(..., fx, fy, INTER_LINEAR) -- plain (not antialiased) bilinear with
+// half-pixel centres on float data: sx = (dx + 0.5) / fx - 0.5, left tap floor(sx) clamped to [0, W-1] with the
+// fraction zeroed at the borders, rows blended after columns.  One thread per output pixel, all three channels.
+__global__ void __launch_bounds__(256) resize_linear_kernel(const uint8_t* __restrict__ src, int H, int W, int oh,
+                                                            int ow, float inv_fx, float inv_fy, int flip,
+                                                            int swap_rb, float* __restrict__ dst) {
+  const int64_t total = (int64_t)oh * ow;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int dy = (int)(i / ow), dx = (int)(i - (int64_t)dy * ow);
+    float fx = ((float)dx + 0.5f) * inv_fx - 0.5f;
+    float fy = ((float)dy + 0.5f) * inv_fy - 0.5f;
+    int sx = (int)floorf(fx), sy = (int)floorf(fy);
+    fx -= (float)sx; fy -= (float)sy;
+    if (sx < 0) { sx = 0; fx = 0.f; }
+    if (sx >= W - 1) { sx = W - 1; fx = 0.f; }
+    if (sy < 0) { sy = 0; fy = 0.f; }
+    if (sy >= H - 1) { sy = H - 1; fy = 0.f; }
+    const int sx1 = sx < W - 1 ? sx + 1 : sx, sy1 = sy < H - 1 ? sy + 1 : sy;
+    const int x0 = flip ? W - 1 - sx : sx, x1 = flip ? W - 1 - sx1 : sx1;          // im[:, ::-1, :] before the resize
+    const uint8_t* r0 = src + (int64_t)sy * W * 3;
+    const uint8_t* r1 = src + (int64_t)sy1 * W * 3;
+    const float a0 = 1.f - fx, a1 = fx, b0 = 1.f - fy, b1 = fy;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float top = (float)r0[x0 * 3 + c] * a0 + (float)r0[x1 * 3 + c] * a1;
+      const float bot = (float)r1[x0 * 3 + c] * a0 + (float)r1[x1 * 3 + c] * a1;
+      dst[(int64_t)(swap_rb ? 2 - c : c) * total + i] = top * b0 + bot * b1;
+    }
+  }
+}
+
 inline unsigned grid_of(int64_t total) {
   int64_t b = (total + 255) / 256;
   return (unsigned)(b < 1 ? 1 : (b > 65536 ? 65536 : b));
@@ -139,4 +171,14 @@ CPM_EXPORT int cpm_image_prep(const uint8_t* src, int H, int W, const int32_t* h
     hipLaunchKernelGGL(resize_v_kernel<false>, dim3(g), dim3(256), 0, s, mid, ow, oh, vbounds, vcoef, vksize, flip, lut,
                        swap_rb, dst, dstH, dstW);
   return cpm::check_launch("image_prep vertical");
+}
+
+CPM_EXPORT int cpm_image_resize_linear(const uint8_t* src, int H, int W, int oh, int ow, float inv_fx, float inv_fy,
+                                       int flip, int swap_rb, float* dst, void* stream) {
+  CPM_REQUIRE(src && dst, "null pointer");
+  CPM_REQUIRE(H > 0 && W > 0 && oh > 0 && ow > 0 && inv_fx > 0.f && inv_fy > 0.f, "bad size or scale");
+  CPM_REQUIRE((int64_t)H * W < (1ll << 28) && (int64_t)oh * ow < (1ll << 28), "image too large");
+  hipLaunchKernelGGL(resize_linear_kernel, dim3(grid_of((int64_t)oh * ow)), dim3(256), 0, (hipStream_t)stream, src, H,
+                     W, oh, ow, inv_fx, inv_fy, flip, swap_rb, dst);
+  return cpm::check_launch("image_resize_linear");
 }

@@ -105,3 +105,27 @@ def image_prep(src, out_size, flip, lut, swap_rb, dst):
                                     H.ptr(lut), int(bool(swap_rb)), tmp, H.ptr(dst), dh, dw, layout, H.stream())
     H.check(rc, "image_prep")
     return dst
+
+
+def cv_round(x):
+    """cvRound: nearest integer, ties to even (OpenCV's dsize = cvRound(src * f))."""
+    return int(np.rint(x))
+
+
+def resize_linear(src, scale, flip=False, swap_rb=True):
+    """Test-time image blob (pet/rcnn/core/test.py:340-358): src uint8 [H,W,3] on the device -> fp32 [3, oh, ow] where
+    (ow, oh) = cvRound(W * scale), cvRound(H * scale); cv2.resize(..., fx=scale, fy=scale, INTER_LINEAR) on float data,
+    optional mirror of the source, RGB -> BGR plane order."""
+    if not src.is_cuda:
+        raise RuntimeError("resize_linear runs on MI355X only (no CPU fallback)")
+    if src.dtype != torch.uint8 or src.dim() != 3 or src.shape[2] != 3 or not src.is_contiguous():
+        raise RuntimeError("resize_linear: src must be a contiguous uint8 [H,W,3] tensor")
+    hgt, wid = int(src.shape[0]), int(src.shape[1])
+    oh, ow = cv_round(hgt * float(scale)), cv_round(wid * float(scale))
+    dst = torch.empty((3, oh, ow), dtype=torch.float32, device=src.device)
+    inv = 1.0 / float(scale)
+    with H.guard(src.device):
+        rc = H.lib().cpm_image_resize_linear(H.ptr(src), hgt, wid, oh, ow, H.f(inv), H.f(inv), int(bool(flip)),
+                                             int(bool(swap_rb)), H.ptr(dst), H.stream())
+    H.check(rc, "image_resize_linear")
+    return dst

@@ -1,0 +1,69 @@
+"""Detections -> COCO result records and their evaluation (counterpart of pet/rcnn/datasets/evaluation.py:21-153, box
+part).  `post_processing` maps the boxes of a batch back to the original image sizes and emits COCO json records;
+`evaluation` writes `<CKPT>/test/bbox.json` and, when pycocotools is importable, runs its COCOeval on it (the
+reference evaluates with its own copy of that class, mycocoeval.py, over pycocotools' C mask/IoU code -- neither is a
+dependency of this tree, so without pycocotools the records are written and the scoring is skipped with a notice)."""
+import json
+import logging
+import os
+
+import numpy as np
+import torch
+
+from pet.rcnn.core.config import cfg
+
+_log = logging.getLogger("pet.evaluation")
+
+
+def prepare_box_results(results, image_ids, dataset):
+    box_results, ims_dets, ims_labels = [], [], []
+    if cfg.MODEL.RPN_ONLY:
+        return results, None, None
+    for result, image_id in zip(results, image_ids):
+        original_id = dataset.id_to_img_map[image_id]
+        if len(result) == 0:
+            ims_dets.append(None)
+            ims_labels.append(None)
+            continue
+        info = dataset.get_img_info(image_id)
+        result = result.resize((info["width"], info["height"]))
+        scores = result.get_field("scores")
+        labels = result.get_field("labels").tolist()
+        ims_dets.append(np.hstack((result.bbox.numpy(), scores.numpy()[:, np.newaxis])).astype(np.float32, copy=False))
+        ims_labels.append(labels)
+        boxes = result.convert("xywh").bbox.tolist()
+        scores = scores.tolist()
+        box_results.extend({"image_id": original_id, "category_id": dataset.contiguous_category_id_to_json_id[labels[k]],
+                            "bbox": box, "score": scores[k]} for k, box in enumerate(boxes))
+    return box_results, ims_dets, ims_labels
+
+
+def post_processing(results, image_ids, dataset):
+    results = [o.to(torch.device("cpu")) for o in results]
+    box_results, ims_dets, ims_labels = prepare_box_results(results, image_ids, dataset)
+    none = [None for _ in image_ids]
+    return [box_results, [], [], [], [], []], [ims_dets, ims_labels, none, none, none, none]
+
+
+def evaluation(dataset, all_boxes, *unused):
+    out_dir = os.path.join(cfg.CKPT, "test")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "bbox.json")
+    with open(path, "w") as f:
+        json.dump(all_boxes, f)
+    _log.info("Wrote %d detections to %s", len(all_boxes), path)
+    try:
+        from pycocotools.coco import COCO
+        from pycocotools.cocoeval import COCOeval
+    except ImportError:
+        _log.warning("pycocotools is not installed: detections written, COCO scoring skipped")
+        return None, {"bbox": all_boxes}
+    ann_file = getattr(dataset, "ann_file", None)
+    gt = COCO(ann_file)
+    dt = gt.loadRes(path) if all_boxes else COCO()
+    ev = COCOeval(gt, dt, "bbox")
+    ev.evaluate()
+    ev.accumulate()
+    ev.summarize()
+    names = ["AP", "AP50", "AP75", "APs", "APm", "APl"]
+    return {"bbox": dict(zip(names, (float(v) for v in ev.stats[:6])))}, {"bbox": all_boxes}

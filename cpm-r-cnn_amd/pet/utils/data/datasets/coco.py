@@ -66,6 +66,7 @@ class COCODataset(torch.utils.data.Dataset):
         if tuple(ann_types) != ("bbox",):
             raise NotImplementedError("only box annotations are on the CPM R-CNN path, got %s" % (ann_types,))
         self.root = root
+        self.ann_file = ann_file
         self.coco = COCOIndex(ann_file)
         self.ids = sorted(self.coco.imgs.keys())
         if remove_images_without_annotations:

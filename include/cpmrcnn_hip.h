@@ -285,6 +285,14 @@ int cpm_image_prep(const uint8_t* src, int H, int W, const int32_t* hbounds, con
                    const float* lut, int swap_rb, uint8_t* tmp, float* dst, int dstH, int dstW, int layout,
                    void* stream);
 
+/* Test-time resize of pet/rcnn/core/test.py:340-358 (get_blob): uint8 [H][W][3] -> fp32 [3][oh][ow] by plain bilinear
+ * interpolation with half-pixel centres on float values (cv2.resize(im.astype(float32), None, None, fx, fy,
+ * INTER_LINEAR)); inv_fx / inv_fy = 1/fx, 1/fy; flip mirrors the SOURCE columns first (im[:, ::-1, :]); swap_rb writes
+ * channel c to plane 2-c (the reference reads BGR with cv2, the loader here decodes RGB).  No normalisation: the
+ * model's Norm layer does that at test time (model_builder.py:25-30). */
+int cpm_image_resize_linear(const uint8_t* src, int H, int W, int oh, int ow, float inv_fx, float inv_fy, int flip,
+                            int swap_rb, float* dst, void* stream);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------
  * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and
  * remembers the launch's ALGORITHMIC flops (2*N*P*Q*K*R*S*C/groups); cpm_prof_enable(0) stops and

@@ -327,3 +327,35 @@ def box_voting(top_boxes, top_scores, all_boxes, all_scores, thr, method=0, beta
         elif method == 5:
             out_s[i] = ssum / num ** beta
     return out_b, out_s
+
+
+def cv_resize_linear(img, scale, flip=False):
+    """numpy float32 restatement of cv2.resize(im.astype(float32), None, None, fx=scale, fy=scale, INTER_LINEAR) as
+    used by pet/rcnn/core/test.py:340-358 (optionally on the mirrored image).  OpenCV is a third-party dependency
+    absent from /root/reference and from this image: PARITY UNPINNED; the published algorithm (imgproc/resize.cpp:
+    dsize = cvRound(size * f); sx = (dx + 0.5) / fx - 0.5; left tap floor(sx), fraction zeroed when the tap is
+    clamped at a border; columns blended first, then rows, in float32)."""
+    im = np.asarray(img)
+    if flip:
+        im = im[:, ::-1, :]
+    im = im.astype(np.float32)
+    H, W = im.shape[:2]
+    oh, ow = int(np.rint(H * scale)), int(np.rint(W * scale))
+    inv = np.float32(1.0 / scale)
+
+    def taps(n_out, n_in):
+        f = (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) * inv - np.float32(0.5)
+        s = np.floor(f).astype(np.int64)
+        a = (f - s.astype(np.float32)).astype(np.float32)
+        lo = s < 0
+        s[lo], a[lo] = 0, 0
+        hi = s >= n_in - 1
+        s[hi], a[hi] = n_in - 1, 0
+        return s, np.minimum(s + 1, n_in - 1), a
+    x0, x1, ax = taps(ow, W)
+    y0, y1, ay = taps(oh, H)
+    a0, a1 = (np.float32(1) - ax)[None, :, None], ax[None, :, None]
+    top = im[y0][:, x0] * a0 + im[y0][:, x1] * a1
+    bot = im[y1][:, x0] * a0 + im[y1][:, x1] * a1
+    out = top * (np.float32(1) - ay)[:, None, None] + bot * ay[:, None, None]
+    return out.astype(np.float32)
