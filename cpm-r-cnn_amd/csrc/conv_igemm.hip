@@ -751,6 +751,46 @@ __global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__
   }
 }
 
+// The same transform for MANY weights in one launch (all conv weights of the flat parameter buffer, once per optimizer
+// step instead of once per data-gradient call): a device table gives every weight's offsets, shape and the index of
+// its first 32x32 tile; a workgroup finds its weight by binary search over those tile starts.
+__global__ __launch_bounds__(256) void weights_to_dgrad_batched(const cpm_wt_desc* __restrict__ descs, int n,
+                                                                int64_t total_tiles, const float* __restrict__ src,
+                                                                float* __restrict__ dst) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int64_t b = blockIdx.x; b < total_tiles; b += gridDim.x) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {                                          // last descriptor with tile_start <= b
+      const int mid = (lo + hi + 1) >> 1;
+      if (descs[mid].tile_start <= b) lo = mid; else hi = mid - 1;
+    }
+    const cpm_wt_desc d = descs[lo];
+    const float* w = src + d.src_off;
+    float* wt = dst + d.dst_off;
+    const int Kg = d.Kg, Cg = d.Cg, RS = d.RS;
+    const int tiles_c = (Cg + 31) / 32, tiles_k = (Kg + 31) / 32;
+    int64_t r = b - d.tile_start;
+    const int tcx = (int)(r % tiles_c); r /= tiles_c;
+    const int tkx = (int)(r % tiles_k); r /= tiles_k;
+    const int t = (int)(r % RS);
+    const int g = (int)(r / RS);
+    const int k0 = tkx * 32, c0 = tcx * 32;
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+      const int k = k0 + ty + j, c = c0 + tx;
+      tile[ty + j][tx] = (k < Kg && c < Cg) ? w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 32; j += 8) {
+      const int c = c0 + ty + j, k = k0 + tx;
+      if (c < Cg && k < Kg) wt[(((int64_t)(g * Cg + c)) * RS + t) * Kg + k] = tile[tx][ty + j];
+    }
+    __syncthreads();
+  }
+}
+
 // ---- weight gradient ---------------------------------------------------------------------------------
 // dw[oc][tap][c] += sum_m dy[m][oc] * x[gather(m, tap)][c]
 // tile: BM output channels x BN input channels for ONE tap; reduction over pixels in chunks of 32.
@@ -1418,18 +1458,20 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
 
 static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
-                     const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr) {
+                     const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr,
+                     bool prepared = false) {
   const size_t need = dgrad_weight_bytes(d);
-  if (!workspace || workspace_bytes < need) {
+  if (!prepared && (!workspace || workspace_bytes < need)) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
     return CPM_EWORKSPACE;
   }
-  float* wt = (float*)workspace;
+  // prepared: `w` already is the [g][c][tap][k] image (cpm_weights_to_dgrad_batched)
+  const float* wt = prepared ? w : (const float*)workspace;
   const int Cg = d->C / d->groups, Kg = d->K / d->groups;
-  {
+  if (!prepared) {
     const int64_t b = (int64_t)cpm::cdiv(Cg, 32) * cpm::cdiv(Kg, 32) * d->R * d->S * d->groups;
     hipLaunchKernelGGL(weight_to_dgrad, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, s, w, d->groups, Kg,
-                       d->R * d->S, Cg, wt);
+                       d->R * d->S, Cg, (float*)workspace);
   }
   IgemmArgs a = {};
   a.in = dy; a.wm = wt; a.out = dx; a.shift = shift; a.relu = relu;
@@ -1517,6 +1559,28 @@ CPM_EXPORT int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const floa
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
   return run_dgrad(d, dy, w, dx, 0, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
                    "cpm_conv2d_backward_data_gated", in_scale, in_act);
+}
+
+CPM_EXPORT int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
+                                                 int accumulate, const float* in_scale, const float* in_act,
+                                                 void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(dy && wt && dx, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
+  CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
+  return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, nullptr, 0, (hipStream_t)stream,
+                   "cpm_conv2d_backward_data_prepared", in_scale, in_act, true);
+}
+
+CPM_EXPORT int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs, int n, int64_t total_tiles, const float* src_base,
+                                            float* dst_base, void* stream) {
+  CPM_REQUIRE(n >= 0 && total_tiles >= 0, "bad counts");
+  if (n == 0 || total_tiles == 0) return CPM_OK;
+  CPM_REQUIRE(d_descs && src_base && dst_base, "null pointer");
+  const int64_t b = total_tiles > 65536 ? 65536 : total_tiles;
+  hipLaunchKernelGGL(weights_to_dgrad_batched, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, d_descs, n,
+                     total_tiles, src_base, dst_base);
+  return cpm::check_launch("weights_to_dgrad_batched");
 }
 
 CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float* x, const float* w,

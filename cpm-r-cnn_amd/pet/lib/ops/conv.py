@@ -6,6 +6,8 @@ NHWC in memory (torch channels_last, logical shape stays [N,C,H,W]); weights are
 (torch [K,C/g,R,S] channels_last).  Everything is fp32; autograd is wired with explicit backward
 kernels (data gradient, weight gradient, fused-epilogue gradient).
 """
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -74,28 +76,57 @@ def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, di
     return y
 
 
-def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_into=None):
-    """dx = conv^T(dy, w); with `accumulate_into` (an NHWC tensor of x's shape) the result is ADDED to it instead."""
+_WT_CACHE = os.environ.get("CPM_DGRAD_WT_CACHE", "1") != "0"
+
+
+def _prepared_wt(wparam, groups, kg, rs, cg):
+    """The data-gradient image of a weight owned by the flat optimizer, made for ALL such weights in one launch after
+    every optimizer step (pet/utils/optimizer.py: FlatSGD._refresh_dgrad_weights) -- or None (transform per call):
+    first use (this call registers the weight with its convolution geometry), foreign weights, or a weight modified
+    since the last refresh (`_version` moved: load_state_dict, manual edits)."""
+    if wparam is None or not _WT_CACHE:
+        return None
+    key = (groups, kg, rs, cg)
+    reg = getattr(wparam, "_cpm_wt_desc", None)
+    if reg is None:
+        if getattr(wparam, "_cpm_grad_sink", None) is not None:
+            wparam._cpm_wt_desc = key
+        return None
+    wt = getattr(wparam, "_cpm_wt", None)
+    if wt is None or reg != key or wparam._cpm_wt_version != wparam._version:
+        return None
+    return wt
+
+
+def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_into=None, wparam=None):
+    """dx = conv^T(dy, w); with `accumulate_into` (an NHWC tensor of x's shape) the result is ADDED to it instead.
+    `wparam`: the parameter `w` is (a view of), for the once-per-step weight image (_prepared_wt)."""
     n, c, h, wd = x_shape
     k, _, r, s = w.shape
+    full_window = (r, s) == (h, wd) and pad == 0 and stride == 1 and dil == 1 and groups == 1 and (r > 1 or s > 1)
+    wt = None if full_window else _prepared_wt(wparam, groups, k // groups, r * s, c // groups)
     if accumulate_into is not None:
         acc = accumulate_into
         assert tuple(acc.shape) == tuple(x_shape) and acc.is_contiguous(memory_format=CL)
         if dy.numel() == 0 or acc.numel() == 0:
             return acc
         d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
-        ws = _ws(d, dy.device)
         with H.guard(dy.device):
-            rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(acc), 1, H.ptr(ws),
-                                                  H.c_size_t(ws.numel()), H.stream())
+            if wt is not None:
+                rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(acc), 1,
+                                                               None, None, H.stream())
+            else:
+                ws = _ws(d, dy.device)
+                rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(acc), 1,
+                                                      H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
         H.check(rc, "conv2d_backward_data(accumulate)")
         return acc
-    if (r, s) == (h, wd) and pad == 0 and stride == 1 and dil == 1 and groups == 1 and (r > 1 or s > 1):
+    if full_window:
         # full-window conv (an FC over a flattened NHWC map): every input pixel sees exactly one tap, so the data
         # gradient is the plain GEMM dy[N,K] x W[K, R*S*C] -- run it as a 1x1 problem over R*S*C "channels"
         # (the KRSC weight bytes are already that matrix) instead of 49 taps of which 48 are masked per row
         w2 = w.permute(0, 2, 3, 1).reshape(k, r * s * c, 1, 1)
-        dx2 = conv2d_backward_data(dy.reshape(n, k, 1, 1), w2, (n, r * s * c, 1, 1), 1, 0, 1, 1)
+        dx2 = conv2d_backward_data(dy.reshape(n, k, 1, 1), w2, (n, r * s * c, 1, 1), 1, 0, 1, 1, wparam=wparam)
         return dx2.view(n, r, s, c).permute(0, 3, 1, 2)
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     dx = empty_nhwc((n, c, h, wd), dy)
@@ -103,28 +134,38 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
         return dx
     if dy.numel() == 0:
         return dx.zero_()
-    ws = _ws(d, dy.device)
     with H.guard(dy.device):
-        rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), 0, H.ptr(ws),
-                                              H.c_size_t(ws.numel()), H.stream())
+        if wt is not None:
+            rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0, None,
+                                                           None, H.stream())
+        else:
+            ws = _ws(d, dy.device)
+            rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), 0, H.ptr(ws),
+                                                  H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_data")
     return dx
 
 
-def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups):
+def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wparam=None):
     """Data gradient with the producer's ReLU gate (x > 0) and frozen scale folded into the epilogue."""
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
+    wt = _prepared_wt(wparam, groups, k // groups, r * s, c // groups)
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     dx = empty_nhwc((n, c, h, wd), dy)
     if dx.numel() == 0:
         return dx
     if dy.numel() == 0:
         return dx.zero_()
-    ws = _ws(d, dy.device)
     with H.guard(dy.device):
-        rc = H.lib().cpm_conv2d_backward_data_gated(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), H.ptr(in_scale),
-                                                    H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+        if wt is not None:
+            rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0,
+                                                           H.ptr(in_scale), H.ptr(x), H.stream())
+        else:
+            ws = _ws(d, dy.device)
+            rc = H.lib().cpm_conv2d_backward_data_gated(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx),
+                                                        H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()),
+                                                        H.stream())
     H.check(rc, "conv2d_backward_data_gated")
     return dx
 
@@ -206,6 +247,8 @@ class _ConvFn(Function):
         ctx.wparam = w_in if (ctx.needs_input_grad[1] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         if ctx.wparam is not None:
             w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+        # the parameter itself (not a repacked copy) when `w` aliases it: key of the once-per-step dgrad image
+        ctx.wsrc = w_in if (w is w_in and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         ctx.bparam = _sink_of(shift, shift is not None and ctx.needs_input_grad[3])
         y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
         # Epilogue-backward folded into the consumer: when the caller promises that y feeds exactly one consumer
@@ -263,15 +306,16 @@ class _ConvFn(Function):
         if need_x:
             h = ctx.x_holder
             if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(x_shape):
-                conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, accumulate_into=h["acc"])
+                conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, accumulate_into=h["acc"],
+                                     wparam=ctx.wsrc)
             else:
                 tag = ctx.in_tag
                 if tag is not None and not tag["applied"] and h is None and dil == 1 and \
                         not ((w.shape[2], w.shape[3]) == (x_shape[2], x_shape[3]) and (w.shape[2] > 1 or w.shape[3] > 1)):
-                    dx = conv2d_backward_data_gated(dpre, w, x, tag["scale"], stride, pad, dil, groups)
+                    dx = conv2d_backward_data_gated(dpre, w, x, tag["scale"], stride, pad, dil, groups, wparam=ctx.wsrc)
                     tag["applied"] = True
                 else:
-                    dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups)
+                    dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, wparam=ctx.wsrc)
                 if h is not None:
                     h["acc"] = dx
         dw = None

@@ -160,6 +160,44 @@ class FlatSGD(torch.optim.Optimizer):
                                       int(self._steps == 0), H.stream())
         H.check(rc, "sgd_step")
         self._steps += 1
+        self._refresh_dgrad_weights()
+
+    def _refresh_dgrad_weights(self):
+        """Every conv weight that has been used by a data-gradient call (pet.lib.ops.conv._prepared_wt registers it
+        with its geometry) gets its data-gradient image rebuilt here, right behind the SGD kernel, for ALL weights in
+        ONE launch -- instead of one small transform launch in front of each of the ~100 data-gradient calls of the
+        next backward pass."""
+        params = [p for p in self._flat_order if getattr(p, "_cpm_wt_desc", None) is not None]
+        if not params:
+            return
+        if getattr(self, "_wt_params", None) is None or len(self._wt_params) != len(params):
+            if getattr(self, "flat_wt", None) is None:
+                self.flat_wt = torch.empty_like(self.flat_param)
+            begins = self.seg_begin.tolist()
+            rows, tiles = [], 0
+            for p in params:
+                groups, kg, rs, cg = p._cpm_wt_desc
+                off = begins[self._seg_index[id(p)]]
+                rows.append((off, off, groups, kg, rs, cg, tiles))
+                tiles += ((cg + 31) // 32) * ((kg + 31) // 32) * rs * groups
+            import numpy as np
+            tab = np.zeros(len(rows), dtype=[("src", "<i8"), ("dst", "<i8"), ("g", "<i4"), ("kg", "<i4"), ("rs", "<i4"),
+                                             ("cg", "<i4"), ("t0", "<i8")])
+            for i, r in enumerate(rows):
+                tab[i] = r
+            self._wt_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.flat_param.device)
+            self._wt_tiles = tiles
+            self._wt_params = params
+            for p in params:
+                off = begins[self._seg_index[id(p)]]
+                p._cpm_wt = self.flat_wt[off:off + p.numel()]
+        with H.guard(self.flat_param.device):
+            rc = H.lib().cpm_weights_to_dgrad_batched(H.ptr(self._wt_table), len(self._wt_params),
+                                                      H.c_int64(self._wt_tiles), H.ptr(self.flat_param),
+                                                      H.ptr(self.flat_wt), H.stream())
+        H.check(rc, "weights_to_dgrad_batched")
+        for p in self._wt_params:
+            p._cpm_wt_version = p._version
 
 
 class Optimizer(object):

@@ -152,6 +152,20 @@ int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const float* dy, cons
                                    const float* in_scale, const float* in_act, void* workspace,
                                    size_t workspace_bytes, void* stream);
 
+/* Data gradient with the weight ALREADY in the data-gradient image ([group][c][tap][k], what the calls above build
+ * in their workspace on every call): `wt` comes from cpm_weights_to_dgrad_batched, which transforms all conv weights
+ * of a flat parameter buffer in ONE launch per optimizer step (101 small launches per step otherwise).  in_scale /
+ * in_act as in cpm_conv2d_backward_data_gated (both NULL: plain).  No workspace. */
+typedef struct {
+  int64_t src_off, dst_off;   /* element offsets of the KRSC weight in src_base and of its image in dst_base */
+  int32_t groups, Kg, RS, Cg; /* K/groups, R*S, C/groups of the convolution the weight belongs to */
+  int64_t tile_start;         /* number of 32x32 tiles (ceil(Cg/32)*ceil(Kg/32)*RS*groups) of all earlier entries */
+} cpm_wt_desc;
+int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs /* DEVICE table, sorted by tile_start */, int n,
+                                 int64_t total_tiles, const float* src_base, float* dst_base, void* stream);
+int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
+                                      int accumulate, const float* in_scale, const float* in_act, void* stream);
+
 /* nn.ConvTranspose2d forward (grid_rcnn/outputs.py:24-37,66-71) = the data gradient of the conv
  * described by `d` with a fused bias(+ReLU) epilogue: x [N,P,Q,K] -> y [N,H,W,C], w as for `d`
  * (torch's ConvTranspose2d weight [Cin=K][Cout/groups=C/g][R][S] permuted to KRSC).  Its own

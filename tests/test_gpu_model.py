@@ -235,3 +235,53 @@ def test_flat_optimizer_grad_sink_equals_autograd(model, golden_model):
             # order; typical difference 1e-6, rare outliers up to a few 1e-4 -- the bar is north_star's 1e-3
             assert err < 1e-3, (k, err)
     assert model.RPN.head.conv.weight._cpm_uses == 0      # 5 uses (one per FPN level) counted up and back down
+
+
+def test_dgrad_weight_images_follow_the_optimizer():
+    """FlatSGD rebuilds the data-gradient image of every conv weight in one launch per step (instead of one transform
+    per data-gradient call): after two steps every registered weight's image equals the permutation of the CURRENT
+    weight, a weight edited outside the optimizer is no longer served from the cache, and the step still runs."""
+    from pet.lib.ops.conv import _prepared_wt
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    from pet.utils.optimizer import Optimizer
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS)
+    try:
+        torch.manual_seed(0)
+        m = convert_bn2affine_model(Generalized_RCNN(is_train=True)).cuda().to(memory_format=CL)
+        m.train()
+        opt = Optimizer(m, config.cfg.SOLVER).build()
+        for g_ in opt.param_groups:
+            g_["lr"] = 1e-4 * g_["lr_scale"]
+        images, targets = synthetic_batch(2, 256, 320, 6, seed=3)
+        images, targets = images.cuda().contiguous(memory_format=CL), [t.to("cuda") for t in targets]
+        for _ in range(2):
+            opt.zero_grad()
+            sum(m(images, targets)["losses"].values()).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        reg = [(k, p) for k, p in m.named_parameters() if getattr(p, "_cpm_wt_desc", None) is not None]
+        assert len(reg) >= 60                                    # every trainable conv / FC-as-conv weight with a dgrad
+        for k, p in reg:
+            groups, kg, rs, cg = p._cpm_wt_desc
+            w = p.detach()
+            if rs == 1 and w.shape[2] * w.shape[3] > 1:          # full-window conv registered as a [K, R*S*C] matrix
+                want = w.permute(2, 3, 1, 0).reshape(-1)
+            else:
+                K, Cg, R, S = w.shape
+                want = w.reshape(groups, kg, Cg, R * S).permute(0, 2, 3, 1).reshape(-1)
+            assert torch.equal(p._cpm_wt, want), k
+            assert _prepared_wt(p, groups, kg, rs, cg) is p._cpm_wt
+        k0, p0 = reg[0]
+        with torch.no_grad():
+            p0.mul_(1.0)                                         # an edit outside the optimizer moves _version
+        assert _prepared_wt(p0, *p0._cpm_wt_desc) is None
+        opt.zero_grad()
+        loss = sum(m(images, targets)["losses"].values())
+        loss.backward()
+        opt.step()
+        assert torch.isfinite(loss) and _prepared_wt(p0, *p0._cpm_wt_desc) is p0._cpm_wt
+    finally:
+        config.reset_cfg()
