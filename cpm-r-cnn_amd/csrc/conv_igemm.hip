@@ -1285,6 +1285,13 @@ Plan plan_igemm(const IgemmArgs& a) {
   // (3-4 workgroups per CU) lose less against the big one (tools/sweep_igemm.sh, MATH=bf16x3)
   const Cand cands_f32[3] = {{128, 128, 2, 1.00}, {128, 64, 2, 0.86}, {64, 64, 4, 0.78}};
   const Cand cands_split_short[3] = {{128, 128, 2, 1.00}, {128, 64, 3, 0.90}, {64, 64, 4, 0.95}};
+  // 2-4 k-steps (1x1 layers over 64 or 128 channels at full resolution): the tile is all prologue and epilogue, and
+  // four 64x64 workgroups per CU interleave those phases better than two big ones (measured in the training step, with
+  // the real residual / gate epilogues: 64->256 on 200x336 124 -> 97 us, 128->512 on 100x168 72 -> 67 us)
+  if (g_conv_split && a.ksteps <= 4 && a.OCg >= 64 && tiles(64, 64) >= 2ll * num_cus()) {
+    p.bm = 64; p.bn = 64; p.split = 1;
+    return p;
+  }
   const Cand* cands = (g_conv_split && a.ksteps <= 40) ? cands_split_short : cands_f32;   // short reductions (1x1)
   const double fixed = (g_conv_split && a.ksteps <= 40) ? 10.0 : 5.0;
   double best = 1e300;
