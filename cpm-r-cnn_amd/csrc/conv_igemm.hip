@@ -440,8 +440,36 @@ __global__ __launch_bounds__(64 * WM * WN)
     }
     return;
   }
+  // per-column epilogue constants once per lane (inside the store loop every one of these loads would sit behind
+  // the previous store: the compiler cannot hoist a load over a store that may alias it)
+  float e_sc[TN], e_sh[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ocl = n0 + wn * WTN + j * 32 + ecol;
+    const bool ok = ocl < a.OCg && !a.atomic_out;
+    e_sc[j] = (a.scale && ok) ? a.scale[g * a.OCg + ocl] : 1.f;
+    e_sh[j] = (a.shift && ok) ? a.shift[g * a.OCg + ocl] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    // gate operands of the 32-row slab first (independent loads in flight), see igemm3x3_kernel's epilogue
+    float gate[16][TN];
+    if (a.mask && !a.atomic_out) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+        int orow = m;
+        if (!dense_rows && m < a.M) {
+          const int jj = m % a.OWp, t = m / a.OWp;
+          orow = ((t / a.OHp) * a.OH + (t % a.OHp) * a.osh + a.oah) * a.OW + jj * a.osw + a.oaw;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int ocl = n0 + wn * WTN + j * 32 + ecol;
+          gate[e][j] = (m < a.M && ocl < a.OCg) ? a.mask[(size_t)orow * a.OCtot + g * a.OCg + ocl] : 1.f;
+        }
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
@@ -465,8 +493,8 @@ __global__ __launch_bounds__(64 * WM * WN)
         if (a.atomic_out) {
           atomicAdd(dst, v);
         } else {
-          if (a.scale) v *= a.scale[oc];
-          if (a.shift) v += a.shift[oc];
+          if (a.scale) v *= e_sc[j];
+          if (a.shift) v += e_sh[j];
           if (a.res) {
             if (a.res_mode == 0) {
               v += a.res[(size_t)orow * a.OCtot + oc];
@@ -476,7 +504,7 @@ __global__ __launch_bounds__(64 * WM * WN)
             }
           }
           if (a.relu) v = fmaxf(v, 0.f);
-          if (a.mask) v = a.mask[(size_t)orow * a.OCtot + oc] > 0.f ? v : 0.f;
+          if (a.mask) v = gate[e][j] > 0.f ? v : 0.f;
           *dst = v;
         }
       }
@@ -658,8 +686,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- epilogue: C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  // The gate / residual operands of a 32-row slab are fetched FIRST (16 x TN independent loads in flight), then the
+  // slab is finished and stored: interleaved with the stores, every load waited out its full latency (the compiler
+  // cannot move a load across a store that may alias it) -- the gated data gradient ran 1.5x slower than the forward.
+  float e_sc[TN], e_sh[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int oc = n0 + wn * WTN + j * 32 + ecol;
+    e_sc[j] = (a.scale && oc < a.OCg) ? a.scale[oc] : 1.f;
+    e_sh[j] = (a.shift && oc < a.OCg) ? a.shift[oc] : 0.f;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
+    float gate[16][TN], resv[16][TN];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+      const int oy = oy0 + (ml >> 4), ox = ox0 + (ml & 15);
+      const bool row_ok = oy < a.OH && ox < a.OW;
+      const size_t orow = ((size_t)n * a.OH + oy) * a.OW + ox;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int oc = n0 + wn * WTN + j * 32 + ecol;
+        const bool ok = row_ok && oc < a.OCg;
+        gate[e][j] = (a.mask && ok) ? a.mask[orow * a.OCtot + oc] : 1.f;
+        float r = 0.f;
+        if (a.res && ok) {
+          if (a.res_mode == 0) {
+            r = a.res[orow * a.OCtot + oc];
+          } else {
+            const int rh = (a.OH + 1) / 2, rw = (a.OW + 1) / 2;
+            r = a.res[((size_t)(n * rh + oy / 2) * rw + ox / 2) * a.OCtot + oc];
+          }
+        }
+        resv[e][j] = r;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const int ml = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
@@ -671,18 +733,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int oc = n0 + wn * WTN + j * 32 + ecol;
         if (oc >= a.OCg) continue;
         float v = acc[i][j][e];
-        if (a.scale) v *= a.scale[oc];
-        if (a.shift) v += a.shift[oc];
-        if (a.res) {
-          if (a.res_mode == 0) {
-            v += a.res[orow * a.OCtot + oc];
-          } else {
-            const int rh = (a.OH + 1) / 2, rw = (a.OW + 1) / 2;
-            v += a.res[((size_t)(n * rh + oy / 2) * rw + ox / 2) * a.OCtot + oc];
-          }
-        }
+        if (a.scale) v *= e_sc[j];
+        if (a.shift) v += e_sh[j];
+        v += resv[e][j];
         if (a.relu) v = fmaxf(v, 0.f);
-        if (a.mask) v = a.mask[orow * a.OCtot + oc] > 0.f ? v : 0.f;
+        if (a.mask) v = gate[e][j] > 0.f ? v : 0.f;
         a.out[orow * a.OCtot + oc] = v;
       }
     }
