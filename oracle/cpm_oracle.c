@@ -10,13 +10,15 @@
  * contraction disabled (build with -ffp-contract=off) so that the operation
  * order -- and therefore the rounding -- is the reference's.
  *
- * Pinning (see oracle/README.md):
+ * Pinning:
  *   orc_roi_align_*      pinned against oracle/_ref (the reference's own
- *                        ROIAlign_cpu.cpp compiled here) + tests/golden/roi_align.npz
- *   orc_nms / orc_ml_nms PARITY UNPINNED: the reference has no CPU kernel for
- *                        ml_nms (ml_nms.h:38) and nms lives in torchvision
- *                        (absent, unpinned version).  Restated from ml_nms.cu
- *                        and checked against a brute-force greedy in tests.
+ *                        ROIAlign_cpu.cpp compiled here) + tests/golden/ops.npz
+ *   orc_nms / orc_ml_nms restated from ml_nms.cu (the reference has no CPU kernel
+ *                        for ml_nms, ml_nms.h:38, and nms lives in torchvision);
+ *                        pinned to the keep lists of the reference's CPU greedy
+ *                        NMS = soft_nms.cpp with the 'hard' method (oracle/_ref,
+ *                        tie-free cases of tests/golden/soft_nms.npz) and checked
+ *                        against a brute-force greedy in tests.
  *   orc_soft_nms         pinned against oracle/_ref (the reference's own
  *                        NMS/soft_nms.cpp compiled here) through
  *                        tests/golden/soft_nms.npz

@@ -408,12 +408,15 @@ def gen_soft_nms(ref_ext):
                                             (200, 300, 0, 0.5, 0.5, 0.001), (500, 150, 1, 0.5, 0.3, 0.05),
                                             (500, 150, 2, 0.3, 0.3, 0.05), (64, 60, 1, 0.5, 0.1, 0.2),
                                             (1, 50, 1, 0.5, 0.3, 0.001), (0, 50, 1, 0.5, 0.3, 0.001),
-                                            (1500, 400, 1, 0.5, 0.3, 0.0001)]:
+                                            (1500, 400, 1, 0.5, 0.3, 0.0001),
+                                            # hard method = the reference's own CPU greedy NMS: pins orc_nms / the HIP NMS
+                                            (1000, 300, 0, 0.5, 0.7, 0.001), (2000, 500, 0, 0.5, 0.3, 0.001),
+                                            (700, 120, 0, 0.5, 0.5, 0.001)]:
         xy = rng.uniform(0, span, (n, 2))
         wh = rng.uniform(4, 120, (n, 2))
         boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
         scores = rng.uniform(0, 1, n).astype(np.float32)
-        if n > 10:
+        if n > 10 and not (method == 0 and n >= 700):
             scores[5:9] = scores[4]                      # exact ties: the first position wins
             boxes[10] = boxes[3]                         # duplicate box
         cases.append((boxes, scores, method, sigma, thr, ms))

@@ -441,3 +441,23 @@ def test_filter_results_modes(oracle, mode):
         np.testing.assert_allclose(ob[key_got], wb[key_want], rtol=1e-5, atol=1e-3)
     finally:
         config.reset_cfg()
+
+
+def test_nms_vs_reference_hard_soft_nms_golden():
+    """The device NMS against the reference's own CPU greedy NMS (soft_nms.cpp, 'hard' method; tie-free cases of
+    tests/golden/soft_nms.npz): identical keep lists, also through the multi-label entry with a single label."""
+    import pet.lib.ops as ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
+    n_hard = 0
+    for i in range(len([k for k in g.files if k.endswith("_cfg")])):
+        method, _, thr, min_score = g["c%d_cfg" % i]
+        boxes, scores = g["c%d_boxes" % i], g["c%d_scores" % i]
+        if int(method) != 0 or len(scores) < 700:
+            continue
+        n_hard += 1
+        live = np.nonzero(scores >= np.float32(min_score))[0]
+        b, s = dev(boxes[live]), dev(scores[live])
+        assert np.array_equal(live[ops.nms(b, s, float(thr)).cpu().numpy()], g["c%d_out_idx" % i])
+        lab = torch.zeros(len(live), dtype=torch.int64, device="cuda")
+        assert np.array_equal(live[ops.ml_nms(b, s, lab, float(thr)).cpu().numpy()], g["c%d_out_idx" % i])
+    assert n_hard >= 3

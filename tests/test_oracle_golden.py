@@ -131,3 +131,20 @@ def test_soft_nms_oracle_is_reference(oracle):
         assert np.array_equal(k, g["c%d_out_idx" % i]), i
         assert np.array_equal(b, g["c%d_out_boxes" % i].reshape(-1, 4)), i
         assert np.array_equal(s, g["c%d_out_scores" % i]), i
+
+
+def test_nms_oracle_is_reference_hard_soft_nms(oracle):
+    """Greedy NMS pinned against the reference's own CPU kernel: soft_nms.cpp with the 'hard' method zeroes every box
+    whose IoU with the current best exceeds the threshold and drops it -- plain greedy NMS with first-position ties --
+    so its surviving indices (selection order = descending score) are what orc_nms / orc_ml_nms must return."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
+    hard = [i for i in range(len([k for k in g.files if k.endswith("_cfg")]))
+            if int(g["c%d_cfg" % i][0]) == 0 and len(g["c%d_scores" % i]) >= 700]       # the tie-free hard cases
+    assert len(hard) >= 3
+    for i in hard:
+        _, _, thr, min_score = g["c%d_cfg" % i]
+        boxes, scores = g["c%d_boxes" % i], g["c%d_scores" % i]
+        live = np.nonzero(scores >= np.float32(min_score))[0]      # soft_nms.cpp also drops scores under min_score
+        assert np.array_equal(live[oracle.nms(boxes[live], scores[live], thr)], g["c%d_out_idx" % i]), i
+        lab = np.zeros(len(live), np.int64)
+        assert np.array_equal(live[oracle.ml_nms(boxes[live], scores[live], lab, thr)], g["c%d_out_idx" % i]), i
