@@ -1,5 +1,7 @@
 // Soft-NMS on the device, batched over segments (classes): the reference runs it on the CPU, class by class, after
-// copying boxes and scores to the host (pet/lib/ops/boxlist_ops.py:70-91 -> csrc/NMS/soft_nms.cpp:5-110).
+// copying boxes and scores to the host (pet/lib/ops/boxlist_ops.py:70-91 -> csrc/NMS/soft_nms.cpp:5-110); with
+// `labels` it is the multi-label variant (boxlist_ops.py:94-117 -> csrc/NMS/ml_soft_nms.cpp:5-122): only boxes with
+// the label of the selected box decay, and the selection stops after `topk` picks.
 //
 // The algorithm is inherently sequential -- pick the best remaining box, decay the others by their overlap with it,
 // drop the ones that fall under min_score by swapping them with the last element -- and its OUTPUT ORDER and its
@@ -33,11 +35,18 @@ __device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
   return incl - v;
 }
 
+// areas are recomputed from the corners where the reference keeps an array (same fp32 expression, same value): the
+// freed LDS holds the labels
+#define SN_AREA(q) ((x2[q] - x1[q]) * (y2[q] - y1[q]))
+
 __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
-                                                      SoftSeg T, float thr, int method, float sigma, float min_score,
+                                                      const int64_t* __restrict__ labels, SoftSeg T, float thr,
+                                                      int method, float sigma, float min_score, int topk,
                                                       float* __restrict__ out_boxes, float* __restrict__ out_scores,
-                                                      int64_t* __restrict__ out_idx, int32_t* __restrict__ out_count) {
-  __shared__ float x1[SN_MAX], y1[SN_MAX], x2[SN_MAX], y2[SN_MAX], sc[SN_MAX], ar[SN_MAX];
+                                                      int64_t* __restrict__ out_labels, int64_t* __restrict__ out_idx,
+                                                      int32_t* __restrict__ out_count) {
+  __shared__ float x1[SN_MAX], y1[SN_MAX], x2[SN_MAX], y2[SN_MAX], sc[SN_MAX];
+  __shared__ int lb[SN_MAX];
   __shared__ int id[SN_MAX];
   __shared__ int holes[SN_MAX];
   const int p = blockIdx.x, lane = threadIdx.x;
@@ -47,11 +56,12 @@ __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ 
     const float4 b = *(const float4*)(boxes + 4 * (size_t)(base + i));
     x1[i] = b.x; y1[i] = b.y; x2[i] = b.z; y2[i] = b.w;
     sc[i] = scores[base + i];
-    ar[i] = (b.z - b.x) * (b.w - b.y);
+    lb[i] = labels ? (int)labels[base + i] : 0;
     id[i] = i;
   }
   __builtin_amdgcn_wave_barrier();
   for (int i = 0; i < nd; ++i) {
+    if (labels && topk == i) { nd = topk; break; }          // ml_soft_nms.cpp:31-35 (0 keeps nothing, < 0 never stops)
     // 1. first position of the maximum score in [i, nd)
     float best = -INFINITY;
     int bpos = 0x7fffffff;
@@ -66,13 +76,14 @@ __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ 
       if (op != 0x7fffffff && (bpos == 0x7fffffff || ob > best || (ob == best && op < bpos))) { best = ob; bpos = op; }
     }
     // 2. swap it to position i (every lane holds the same bpos)
-    const float ix1 = x1[bpos], iy1 = y1[bpos], ix2 = x2[bpos], iy2 = y2[bpos], isc = sc[bpos], iar = ar[bpos];
-    const int iid = id[bpos];
+    const float ix1 = x1[bpos], iy1 = y1[bpos], ix2 = x2[bpos], iy2 = y2[bpos], isc = sc[bpos];
+    const float iar = (ix2 - ix1) * (iy2 - iy1);
+    const int iid = id[bpos], ilb = lb[bpos];
     __builtin_amdgcn_wave_barrier();
     if (lane == 0) {
-      x1[bpos] = x1[i]; y1[bpos] = y1[i]; x2[bpos] = x2[i]; y2[bpos] = y2[i]; sc[bpos] = sc[i]; ar[bpos] = ar[i];
+      x1[bpos] = x1[i]; y1[bpos] = y1[i]; x2[bpos] = x2[i]; y2[bpos] = y2[i]; sc[bpos] = sc[i]; lb[bpos] = lb[i];
       id[bpos] = id[i];
-      x1[i] = ix1; y1[i] = iy1; x2[i] = ix2; y2[i] = iy2; sc[i] = isc; ar[i] = iar; id[i] = iid;
+      x1[i] = ix1; y1[i] = iy1; x2[i] = ix2; y2[i] = iy2; sc[i] = isc; lb[i] = ilb; id[i] = iid;
     }
     __builtin_amdgcn_wave_barrier();
     // 3. decay (i, nd); each lane owns a contiguous run so that the prefix counts below follow positions
@@ -81,18 +92,20 @@ __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ 
     const int lo = i + 1 + lane * per, hi = min(lo + per, nd);
     int dead_cnt = 0;
     for (int q = lo; q < hi; ++q) {
-      const float inter = fmaxf(0.f, fminf(ix2, x2[q]) - fmaxf(ix1, x1[q])) *
-                          fmaxf(0.f, fminf(iy2, y2[q]) - fmaxf(iy1, y1[q]));
-      const float ovr = inter / (iar + ar[q] - inter);
       float s = sc[q];
-      if (method == 1) {
-        if (ovr > thr) s = (1.f - ovr) * s;
-      } else if (method == 2) {
-        s = expf(-(ovr * ovr) / sigma) * s;
-      } else {
-        if (ovr > thr) s = 0.f;
+      if (lb[q] == ilb) {
+        const float inter = fmaxf(0.f, fminf(ix2, x2[q]) - fmaxf(ix1, x1[q])) *
+                            fmaxf(0.f, fminf(iy2, y2[q]) - fmaxf(iy1, y1[q]));
+        const float ovr = inter / (iar + SN_AREA(q) - inter);
+        if (method == 1) {
+          if (ovr > thr) s = (1.f - ovr) * s;
+        } else if (method == 2) {
+          s = expf(-(ovr * ovr) / sigma) * s;
+        } else {
+          if (ovr > thr) s = 0.f;
+        }
+        sc[q] = s;
       }
-      sc[q] = s;
       dead_cnt += (s < min_score) ? 1 : 0;
     }
     int total_dead;
@@ -118,7 +131,7 @@ __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ 
           if (q >= new_nd) {
             const int rank = total_live - seen - 1;          // live elements above q
             const int h = holes[rank];
-            x1[h] = x1[q]; y1[h] = y1[q]; x2[h] = x2[q]; y2[h] = y2[q]; sc[h] = sc[q]; ar[h] = ar[q]; id[h] = id[q];
+            x1[h] = x1[q]; y1[h] = y1[q]; x2[h] = x2[q]; y2[h] = y2[q]; sc[h] = sc[q]; lb[h] = lb[q]; id[h] = id[q];
           }
           ++seen;
         }
@@ -130,6 +143,7 @@ __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ 
   for (int i = lane; i < nd; i += 64) {
     *(float4*)(out_boxes + 4 * (size_t)(base + i)) = make_float4(x1[i], y1[i], x2[i], y2[i]);
     out_scores[base + i] = sc[i];
+    if (out_labels) out_labels[base + i] = (int64_t)lb[i];
     out_idx[base + i] = (int64_t)id[i];
   }
   if (lane == 0) out_count[p] = nd;
@@ -137,9 +151,10 @@ __global__ void __launch_bounds__(64) soft_nms_kernel(const float* __restrict__ 
 
 }  // namespace
 
-CPM_EXPORT int cpm_soft_nms_batched(const float* boxes, const float* scores, const int32_t* h_offsets, int P,
-                                    float iou_threshold, int method, float sigma, float min_score, float* out_boxes,
-                                    float* out_scores, int64_t* out_idx, int32_t* out_counts, void* stream) {
+CPM_EXPORT int cpm_soft_nms_batched(const float* boxes, const float* scores, const int64_t* labels,
+                                    const int32_t* h_offsets, int P, float iou_threshold, int method, float sigma,
+                                    float min_score, int topk, float* out_boxes, float* out_scores,
+                                    int64_t* out_labels, int64_t* out_idx, int32_t* out_counts, void* stream) {
   CPM_REQUIRE(P >= 0 && P <= 64, "1..64 segments per call");
   if (P == 0) return CPM_OK;
   CPM_REQUIRE(h_offsets && out_counts, "null pointer");
@@ -158,7 +173,8 @@ CPM_EXPORT int cpm_soft_nms_batched(const float* boxes, const float* scores, con
     CPM_REQUIRE(boxes && scores && out_boxes && out_scores && out_idx, "null pointer");
     CPM_REQUIRE((((uintptr_t)boxes) & 15) == 0 && (((uintptr_t)out_boxes) & 15) == 0, "boxes must be 16-byte aligned");
   }
-  hipLaunchKernelGGL(soft_nms_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, boxes, scores, T, iou_threshold, method,
-                     sigma, min_score, out_boxes, out_scores, out_idx, out_counts);
+  hipLaunchKernelGGL(soft_nms_kernel, dim3(P), dim3(64), 0, (hipStream_t)stream, boxes, scores, labels, T,
+                     iou_threshold, method, sigma, min_score, topk, out_boxes, out_scores, out_labels, out_idx,
+                     out_counts);
   return cpm::check_launch("soft_nms_batched");
 }

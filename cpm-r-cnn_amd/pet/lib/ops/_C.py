@@ -121,11 +121,12 @@ def nms(dets, scores, iou_threshold):
 SOFT_NMS_MAX = 2048
 
 
-def soft_nms_segments(dets, scores, offsets, sigma, iou_threshold, min_score, method):
+def soft_nms_segments(dets, scores, offsets, sigma, iou_threshold, min_score, method, labels=None, topk=-1):
     """Batched device soft-NMS (cpm_soft_nms_batched) over segments (host list `offsets`, len P+1 <= 65, at most 2048
     boxes per segment).  Returns (boxes [N,4], scores [N], idx int64 [N], counts int32 [P] on the device): segment p's
-    survivors occupy rows [off[p], off[p] + counts[p]) in the reference's output order."""
-    H.require_gpu(dets, scores)
+    survivors occupy rows [off[p], off[p] + counts[p]) in the reference's output order.  With `labels` (int64 [N]) the
+    multi-label variant runs and the labels of the survivors are returned as a fifth value."""
+    H.require_gpu(dets, scores, labels)
     P = len(offsets) - 1
     N = int(offsets[-1])
     b, s = dets.contiguous(), scores.contiguous()
@@ -133,11 +134,16 @@ def soft_nms_segments(dets, scores, offsets, sigma, iou_threshold, min_score, me
     osc = torch.empty((max(N, 1),), dtype=torch.float32, device=dets.device)
     oi = torch.empty((max(N, 1),), dtype=torch.int64, device=dets.device)
     counts = torch.empty((max(P, 1),), dtype=torch.int32, device=dets.device)
+    lab = labels.contiguous().to(torch.int64) if labels is not None else None
+    ol = torch.empty((max(N, 1),), dtype=torch.int64, device=dets.device) if lab is not None else None
     off = (ctypes.c_int32 * (P + 1))(*[int(o) for o in offsets])
     with H.guard(dets.device):
-        rc = H.lib().cpm_soft_nms_batched(H.ptr(b), H.ptr(s), off, P, H.f(iou_threshold), int(method), H.f(sigma),
-                                          H.f(min_score), H.ptr(ob), H.ptr(osc), H.ptr(oi), H.ptr(counts), H.stream())
+        rc = H.lib().cpm_soft_nms_batched(H.ptr(b), H.ptr(s), H.ptr(lab), off, P, H.f(iou_threshold), int(method),
+                                          H.f(sigma), H.f(min_score), int(topk), H.ptr(ob), H.ptr(osc), H.ptr(ol),
+                                          H.ptr(oi), H.ptr(counts), H.stream())
     H.check(rc, "soft_nms_batched")
+    if lab is not None:
+        return ob[:N], osc[:N], oi[:N], counts[:P], ol[:N]
     return ob[:N], osc[:N], oi[:N], counts[:P]
 
 
@@ -191,6 +197,20 @@ def pool_points_interp_backward(grad, rois, spatial_scale, batch_size, channels,
     return gin
 
 
+def ml_soft_nms(dets, scores, labels, sigma, iou_threshold, min_score, method, topk):
+    """ml_soft_nms.h:19-44 (argument order of the reference binding): (dets, scores, labels, indices)."""
+    n = dets.size(0)
+    if n == 0:
+        return (torch.empty((0, 4), dtype=dets.dtype, device=dets.device),
+                torch.empty((0,), dtype=dets.dtype, device=dets.device),
+                torch.empty((0,), dtype=torch.int64, device=dets.device),
+                torch.empty((0,), dtype=torch.int64, device=dets.device))
+    b, s, i, c, l = soft_nms_segments(dets.float(), scores.float(), [0, n], sigma, iou_threshold, min_score, method,
+                                      labels=labels, topk=topk)
+    m = int(c.item())
+    return b[:m], s[:m], l[:m], i[:m]
+
+
 def box_voting(top_boxes, top_scores, all_boxes, all_scores, scoring_method, beta, overlap_thresh):
     """box_voting.h (argument order of the reference binding): (voted boxes [N,4], re-estimated scores [N])."""
     H.require_gpu(top_boxes, top_scores, all_boxes, all_scores)
@@ -216,7 +236,7 @@ def _not_on_hot_path(name):
 
 
 # names bound by vision.cpp:21-47 that no BASELINE config reaches (out of scope)
-for _n in ("ml_soft_nms", "nms_rotated", "poly_nms", "box_ml_voting", "box_iou_rotated",
+for _n in ("nms_rotated", "poly_nms", "box_ml_voting", "box_iou_rotated",
            "roi_align_rotated_forward", "roi_align_rotated_backward", "roi_pool_forward", "roi_pool_backward",
            "sigmoid_focalloss_forward", "sigmoid_focalloss_backward"):
     globals()[_n] = _not_on_hot_path(_n)

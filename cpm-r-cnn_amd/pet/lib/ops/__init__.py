@@ -1,5 +1,5 @@
 """Operator surface of the hot path (counterpart of pet/lib/ops/__init__.py:1-30, hot-path names only)."""
-from .nms import nms, ml_nms, nms_segments, soft_nms, soft_nms_segments
+from .nms import nms, ml_nms, nms_segments, soft_nms, ml_soft_nms, soft_nms_segments
 from .roi_align import roi_align, ROIAlign
 from .pooler_fpn import roi_align_fpn
 from .affine import AffineChannel2d

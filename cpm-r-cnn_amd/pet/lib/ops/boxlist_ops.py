@@ -56,3 +56,20 @@ def boxlist_box_voting(top_boxlist, all_boxlist, thresh, scoring_method="ID", be
     out = BoxList(boxes, all_boxlist.size, mode="xyxy")
     out.add_field("scores", scores)
     return out.convert(mode)
+
+
+def boxlist_ml_soft_nms(boxlist, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="linear", topk=0,
+                        score_field="scores"):
+    """boxlist_ops.py:94-117 (multi-label), on the device."""
+    if overlap_thresh <= 0:
+        return boxlist
+    from pet.lib.ops.nms import ml_soft_nms
+    from pet.utils.data.structures.bounding_box import BoxList
+    mode = boxlist.mode
+    boxlist = boxlist.convert("xyxy")
+    dets, scores, labels, _ = ml_soft_nms(boxlist.bbox, boxlist.get_field(score_field), boxlist.get_field("labels"), sigma,
+                                          overlap_thresh, score_thresh, method, topk)
+    out = BoxList(dets, boxlist.size, mode="xyxy")
+    out.add_field("scores", scores)
+    out.add_field("labels", labels)
+    return out.convert(mode)

@@ -21,4 +21,11 @@ def soft_nms(dets, scores, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, me
     return _C.soft_nms(dets, scores, sigma, overlap_thresh, score_thresh, SOFT_NMS_METHODS[method])
 
 
+def ml_soft_nms(dets, scores, labels, sigma=0.5, overlap_thresh=0.3, score_thresh=0.001, method="linear", topk=0):
+    """Multi-label soft-NMS on the device; reference: nms.py:31-45.  NB the reference kernel stops when `topk == i`, so
+    its default topk = 0 keeps nothing; pass a negative topk for "no limit"."""
+    assert method in SOFT_NMS_METHODS, "Unknown soft_nms method: {}".format(method)
+    return _C.ml_soft_nms(dets, scores, labels, sigma, overlap_thresh, score_thresh, SOFT_NMS_METHODS[method], topk)
+
+
 soft_nms_segments = _C.soft_nms_segments

@@ -256,13 +256,17 @@ int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, flo
 
 /* ---- soft-NMS on the device, batched over segments (classes) ----------------------------
  * Replaces pet/lib/ops/nms.py:16-28 -> csrc/NMS/soft_nms.cpp:5-160 (a CPU kernel called per class after a device->host
- * copy, boxlist_ops.py:86-90).  Segment p = rows [h_offsets[p], h_offsets[p+1]) (HOST offsets, <= 64 segments,
- * <= 2048 boxes each).  method: 0 hard, 1 linear, 2 gaussian (SOFT_NMS_METHODS).  Results of segment p are written
- * at its own offset, in the reference's output order: out_counts[p] boxes with their DECAYED scores and their index
- * inside the segment.  Linear / hard: bit-identical to the reference; gaussian: device expf. */
-int cpm_soft_nms_batched(const float* boxes, const float* scores, const int32_t* h_offsets, int P, float iou_threshold,
-                         int method, float sigma, float min_score, float* out_boxes, float* out_scores,
-                         int64_t* out_idx, int32_t* out_counts, void* stream);
+ * copy, boxlist_ops.py:86-90) and, with `labels`, nms.py:31-45 -> csrc/NMS/ml_soft_nms.cpp:5-186 (only boxes carrying
+ * the selected box's label decay; the selection stops after `topk` picks: 0 keeps nothing, < 0 never stops -- the
+ * reference's `topk == i` rule; topk is ignored without labels).  Segment p = rows [h_offsets[p], h_offsets[p+1])
+ * (HOST offsets, <= 64 segments, <= 2048 boxes each).  method: 0 hard, 1 linear, 2 gaussian (SOFT_NMS_METHODS).
+ * Results of segment p are written at its own offset, in the reference's output order: out_counts[p] boxes with their
+ * DECAYED scores, their labels (out_labels may be NULL) and their index inside the segment.  Linear / hard:
+ * bit-identical to the reference; gaussian: device expf. */
+int cpm_soft_nms_batched(const float* boxes, const float* scores, const int64_t* labels, const int32_t* h_offsets,
+                         int P, float iou_threshold, int method, float sigma, float min_score, int topk,
+                         float* out_boxes, float* out_scores, int64_t* out_labels, int64_t* out_idx,
+                         int32_t* out_counts, void* stream);
 
 /* ---- bounding-box voting ---------------------------------------------------------------------
  * Replaces _C.box_voting (pet/lib/ops/boxes.py:6-22 -> csrc/Box_ops/box_voting.cu:24-210): every top box becomes the

@@ -21,6 +21,7 @@ def build(verbose=False):
     # a CPU-only C++ build: keep hipcc out of it
     return load(name="cpm_ref", sources=[os.path.join(REF, "ROIAlign", "ROIAlign_cpu.cpp"),
                                          os.path.join(REF, "NMS", "soft_nms.cpp"),
+                                         os.path.join(REF, "NMS", "ml_soft_nms.cpp"),
                                          os.path.join(HERE, "ref_binding.cpp")],
                 extra_include_paths=[os.path.join(REF, "ROIAlign"), os.path.join(REF, "NMS")],
                 extra_cflags=["-O2", "-ffp-contract=off"],

@@ -19,9 +19,9 @@
  *                        NMS = soft_nms.cpp with the 'hard' method (oracle/_ref,
  *                        tie-free cases of tests/golden/soft_nms.npz) and checked
  *                        against a brute-force greedy in tests.
- *   orc_soft_nms         pinned against oracle/_ref (the reference's own
- *                        NMS/soft_nms.cpp compiled here) through
- *                        tests/golden/soft_nms.npz
+ *   orc_soft_nms,        pinned against oracle/_ref (the reference's own
+ *   orc_ml_soft_nms      NMS/soft_nms.cpp and NMS/ml_soft_nms.cpp compiled here)
+ *                        through tests/golden/soft_nms.npz
  *   orc_deform_conv      PARITY UNPINNED (CUDA-only op in the reference; see its
  *                        section header for what pins it instead).
  *   the box/level/grid helpers are pinned by goldens produced by importing the
@@ -246,12 +246,14 @@ ORC_API int64_t orc_nms(const float* boxes, const float* scores, int64_t n,
   return orc_ml_nms(boxes, scores, NULL, n, thr, 0, keep);
 }
 
-/* Soft-NMS -- pet/lib/ops/csrc/NMS/soft_nms.cpp:5-110.  boxes [n,4], scores [n] */
-/* are reordered IN PLACE as the reference does; idx[n] receives the original     */
-/* indices; returns the number of survivors (the first `ret` rows).               */
-/* method 1 linear, 2 gaussian, otherwise hard (SOFT_NMS_METHODS, nms.py:5).      */
-ORC_API int64_t orc_soft_nms(float* boxes, float* scores, int64_t* idx, int64_t n, float thr, int method,
-                             float sigma, float min_score) {
+/* Soft-NMS -- pet/lib/ops/csrc/NMS/soft_nms.cpp:5-110 and its multi-label twin        */
+/* NMS/ml_soft_nms.cpp:5-122 (only boxes of the selected box's label decay; stop after   */
+/* `topk` selections -- `if (topk == i)`, so topk 0 returns nothing and topk < 0 never   */
+/* stops).  boxes [n,4], scores [n], labels [n] (NULL: single label) are reordered IN    */
+/* PLACE as the reference does; idx[n] receives the original indices; returns the number */
+/* of survivors (the first `ret` rows).  method 1 linear, 2 gaussian, otherwise hard.     */
+ORC_API int64_t orc_ml_soft_nms(float* boxes, float* scores, int64_t* labels, int64_t* idx, int64_t n, float thr,
+                                int method, float sigma, float min_score, int64_t topk) {
   float* area = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
   for (int64_t i = 0; i < n; ++i) {
     area[i] = (boxes[4 * i + 2] - boxes[4 * i]) * (boxes[4 * i + 3] - boxes[4 * i + 1]);   /* :22 */
@@ -259,39 +261,49 @@ ORC_API int64_t orc_soft_nms(float* boxes, float* scores, int64_t* idx, int64_t 
   }
   int64_t nd = n;
   for (int64_t i = 0; i < nd; ++i) {
+    if (labels && topk == i) { nd = topk; break; }              /* ml_soft_nms.cpp:31-35 */
     int64_t mp = i;                                             /* :30-38 first position of the maximum */
     float ms = scores[i];
     for (int64_t q = i + 1; q < nd; ++q)
       if (ms < scores[q]) { ms = scores[q]; mp = q; }
     float b[4], sc = scores[mp], ar = area[mp];                 /* :41-66 swap to the front */
-    int64_t id = idx[mp];
+    int64_t id = idx[mp], lab = labels ? labels[mp] : 0;
     memcpy(b, boxes + 4 * mp, sizeof b);
     memcpy(boxes + 4 * mp, boxes + 4 * i, sizeof b);
     scores[mp] = scores[i]; area[mp] = area[i]; idx[mp] = idx[i];
+    if (labels) { labels[mp] = labels[i]; labels[i] = lab; }
     memcpy(boxes + 4 * i, b, sizeof b);
     scores[i] = sc; area[i] = ar; idx[i] = id;
     for (int64_t q = i + 1; q < nd; ++q) {                      /* :70-108 decay, drop by swapping with the last */
-      const float* c = boxes + 4 * q;
-      float inter = fmaxf(0.f, fminf(b[2], c[2]) - fmaxf(b[0], c[0])) *
-                    fmaxf(0.f, fminf(b[3], c[3]) - fmaxf(b[1], c[1]));
-      float ovr = inter / (ar + area[q] - inter);
-      if (method == 1) {
-        if (ovr > thr) scores[q] = (1.f - ovr) * scores[q];
-      } else if (method == 2) {
-        scores[q] = expf(-(ovr * ovr) / sigma) * scores[q];
-      } else {
-        if (ovr > thr) scores[q] = 0.f;
+      if (!labels || labels[q] == lab) {
+        const float* c = boxes + 4 * q;
+        float inter = fmaxf(0.f, fminf(b[2], c[2]) - fmaxf(b[0], c[0])) *
+                      fmaxf(0.f, fminf(b[3], c[3]) - fmaxf(b[1], c[1]));
+        float ovr = inter / (ar + area[q] - inter);
+        if (method == 1) {
+          if (ovr > thr) scores[q] = (1.f - ovr) * scores[q];
+        } else if (method == 2) {
+          scores[q] = expf(-(ovr * ovr) / sigma) * scores[q];
+        } else {
+          if (ovr > thr) scores[q] = 0.f;
+        }
       }
       if (scores[q] < min_score) {
         --nd;
         memcpy(boxes + 4 * q, boxes + 4 * nd, sizeof b);
         scores[q] = scores[nd]; area[q] = area[nd]; idx[q] = idx[nd];
+        if (labels) labels[q] = labels[nd];
         --q;
       }
     }
   }
   free(area);
   return nd;
+}
+
+ORC_API int64_t orc_soft_nms(float* boxes, float* scores, int64_t* idx, int64_t n, float thr, int method,
+                             float sigma, float min_score) {
+  return orc_ml_soft_nms(boxes, scores, NULL, idx, n, thr, method, sigma, min_score, -1);
 }
 
 /* box_iou -- pet/lib/ops/csrc/Box_ops/box_iou.cu:27-77 (no +1), out [N,K]     */

@@ -90,6 +90,18 @@ def soft_nms(boxes, scores, sigma=0.5, thr=0.3, min_score=0.001, method=1):
     return b[:m].copy(), sc[:m].copy(), idx[:m].copy()
 
 
+def ml_soft_nms(boxes, scores, labels, sigma=0.5, thr=0.3, min_score=0.001, method=1, topk=-1):
+    """-> (boxes [m,4], decayed scores [m], labels [m], original indices [m]) in the reference's output order."""
+    b, sc = _f32(boxes).reshape(-1, 4).copy(), _f32(scores).copy()
+    lab = np.ascontiguousarray(labels, dtype=np.int64).copy()
+    n = b.shape[0]
+    idx = np.zeros(max(n, 1), np.int64)
+    lib().orc_ml_soft_nms.restype = ctypes.c_int64
+    m = lib().orc_ml_soft_nms(_p(b), _p(sc), _p(lab), _p(idx), ctypes.c_int64(n), ctypes.c_float(thr), int(method),
+                              ctypes.c_float(sigma), ctypes.c_float(min_score), ctypes.c_int64(topk))
+    return b[:m].copy(), sc[:m].copy(), lab[:m].copy(), idx[:m].copy()
+
+
 def box_iou(boxes, query):
     boxes, query = _f32(boxes).reshape(-1, 4), _f32(query).reshape(-1, 4)
     out = np.zeros((boxes.shape[0], query.shape[0]), np.float32)

@@ -426,6 +426,27 @@ def gen_soft_nms(ref_ext):
         out["c%d_boxes" % i], out["c%d_scores" % i] = boxes, scores
         out["c%d_cfg" % i] = np.array([method, sigma, thr, ms], np.float64)
         out["c%d_out_boxes" % i], out["c%d_out_scores" % i], out["c%d_out_idx" % i] = d.numpy(), s_.numpy(), k.numpy()
+    # multi-label twin (NMS/ml_soft_nms.cpp): labels 1..5, with and without topk; the hard method is the reference's
+    # own CPU form of ml_nms
+    ml = []
+    for n, span, method, sigma, thr, ms, topk in [(400, 200, 0, 0.5, 0.5, 0.001, -1), (900, 300, 0, 0.5, 0.3, 0.001, -1),
+                                                  (400, 200, 1, 0.5, 0.3, 0.01, -1), (400, 200, 2, 0.5, 0.3, 0.01, -1),
+                                                  (400, 200, 1, 0.5, 0.3, 0.01, 50), (400, 200, 0, 0.5, 0.5, 0.001, 30),
+                                                  (50, 100, 1, 0.5, 0.3, 0.01, 0), (0, 100, 1, 0.5, 0.3, 0.01, -1)]:
+        xy = rng.uniform(0, span, (n, 2))
+        wh = rng.uniform(4, 120, (n, 2))
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        scores = rng.uniform(0, 1, n).astype(np.float32)
+        labels = rng.integers(1, 6, n).astype(np.int64)
+        ml.append((boxes, scores, labels, method, sigma, thr, ms, topk))
+    for i, (boxes, scores, labels, method, sigma, thr, ms, topk) in enumerate(ml):
+        d, s_, l_, k = ref_ext.ml_soft_nms_cpu(torch.from_numpy(boxes.copy()), torch.from_numpy(scores.copy()),
+                                               torch.from_numpy(labels.copy()), thr, method, sigma, ms, topk)
+        out["m%d_boxes" % i], out["m%d_scores" % i], out["m%d_labels" % i] = boxes, scores, labels
+        out["m%d_cfg" % i] = np.array([method, sigma, thr, ms, topk], np.float64)
+        out["m%d_out_boxes" % i], out["m%d_out_scores" % i] = d.numpy(), s_.numpy()
+        out["m%d_out_labels" % i], out["m%d_out_idx" % i] = l_.numpy(), k.numpy()
+    print("ml_soft_nms kept", [int(out["m%d_out_idx" % i].shape[0]) for i in range(len(ml))])
     np.savez_compressed(os.path.join(HERE, "soft_nms.npz"), **out)
     print("soft_nms:", len(cases), "cases; kept", [int(out["c%d_out_idx" % i].shape[0]) for i in range(len(cases))])
 

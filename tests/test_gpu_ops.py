@@ -303,7 +303,7 @@ def test_soft_nms_vs_reference_golden(oracle):
     import pet.lib.ops as ops
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
     names = {0: "hard", 1: "linear", 2: "gaussian"}
-    for i in range(len([k for k in g.files if k.endswith("_cfg")])):
+    for i in range(len([k for k in g.files if k.startswith("c") and k.endswith("_cfg")])):
         method, sigma, thr, ms = g["c%d_cfg" % i]
         b, s, k = ops.soft_nms(dev(g["c%d_boxes" % i]).reshape(-1, 4), dev(g["c%d_scores" % i]), sigma, thr, ms,
                                names[int(method)])
@@ -449,7 +449,7 @@ def test_nms_vs_reference_hard_soft_nms_golden():
     import pet.lib.ops as ops
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
     n_hard = 0
-    for i in range(len([k for k in g.files if k.endswith("_cfg")])):
+    for i in range(len([k for k in g.files if k.startswith("c") and k.endswith("_cfg")])):
         method, _, thr, min_score = g["c%d_cfg" % i]
         boxes, scores = g["c%d_boxes" % i], g["c%d_scores" % i]
         if int(method) != 0 or len(scores) < 700:
@@ -461,3 +461,31 @@ def test_nms_vs_reference_hard_soft_nms_golden():
         lab = torch.zeros(len(live), dtype=torch.int64, device="cuda")
         assert np.array_equal(live[ops.ml_nms(b, s, lab, float(thr)).cpu().numpy()], g["c%d_out_idx" % i])
     assert n_hard >= 3
+
+
+def test_ml_soft_nms_vs_reference_golden():
+    """Multi-label soft-NMS on the device against the reference's ml_soft_nms.cpp (tests/golden/soft_nms.npz): survivors,
+    labels and order identical, scores bit-equal (gaussian: expf rounding), the top-k rule included; and the hard
+    method == the device ml_nms keep lists (the reference's CPU form of that op)."""
+    import pet.lib.ops as ops
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
+    names = {0: "hard", 1: "linear", 2: "gaussian"}
+    n_cases = len([k for k in g.files if k.startswith("m") and k.endswith("_cfg")])
+    assert n_cases >= 8
+    for i in range(n_cases):
+        method, sigma, thr, ms, topk = g["m%d_cfg" % i]
+        boxes, scores, labels = g["m%d_boxes" % i], g["m%d_scores" % i], g["m%d_labels" % i]
+        b, s, l, k = ops.ml_soft_nms(dev(boxes).reshape(-1, 4), dev(scores), torch.from_numpy(labels).cuda(), sigma, thr,
+                                     ms, names[int(method)], int(topk))
+        assert np.array_equal(k.cpu().numpy(), g["m%d_out_idx" % i]), i
+        assert np.array_equal(l.cpu().numpy(), g["m%d_out_labels" % i]), i
+        assert np.array_equal(b.cpu().numpy(), g["m%d_out_boxes" % i].reshape(-1, 4)), i
+        if int(method) == 2:
+            np.testing.assert_allclose(s.cpu().numpy(), g["m%d_out_scores" % i], rtol=2e-6, atol=1e-7)
+        else:
+            assert np.array_equal(s.cpu().numpy(), g["m%d_out_scores" % i]), i
+        if int(method) == 0 and len(scores):
+            live = np.nonzero(scores >= np.float32(ms))[0]
+            keep = ops.ml_nms(dev(boxes[live]), dev(scores[live]), torch.from_numpy(labels[live]).cuda(), float(thr),
+                              max(int(topk), 0))
+            assert np.array_equal(live[keep.cpu().numpy()], g["m%d_out_idx" % i]), i

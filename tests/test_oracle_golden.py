@@ -123,7 +123,7 @@ def test_soft_nms_oracle_is_reference(oracle):
     """orc_soft_nms against the reference's own soft_nms.cpp (compiled into oracle/_ref by build_ref.py; vectors in
     tests/golden/soft_nms.npz): surviving boxes, decayed scores and original indices, in output order, bit for bit."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
-    n_cases = len([k for k in g.files if k.endswith("_cfg")])
+    n_cases = len([k for k in g.files if k.startswith("c") and k.endswith("_cfg")])
     assert n_cases >= 9
     for i in range(n_cases):
         method, sigma, thr, ms = g["c%d_cfg" % i]
@@ -138,7 +138,7 @@ def test_nms_oracle_is_reference_hard_soft_nms(oracle):
     whose IoU with the current best exceeds the threshold and drops it -- plain greedy NMS with first-position ties --
     so its surviving indices (selection order = descending score) are what orc_nms / orc_ml_nms must return."""
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
-    hard = [i for i in range(len([k for k in g.files if k.endswith("_cfg")]))
+    hard = [i for i in range(len([k for k in g.files if k.startswith("c") and k.endswith("_cfg")]))
             if int(g["c%d_cfg" % i][0]) == 0 and len(g["c%d_scores" % i]) >= 700]       # the tie-free hard cases
     assert len(hard) >= 3
     for i in hard:
@@ -148,3 +148,27 @@ def test_nms_oracle_is_reference_hard_soft_nms(oracle):
         assert np.array_equal(live[oracle.nms(boxes[live], scores[live], thr)], g["c%d_out_idx" % i]), i
         lab = np.zeros(len(live), np.int64)
         assert np.array_equal(live[oracle.ml_nms(boxes[live], scores[live], lab, thr)], g["c%d_out_idx" % i]), i
+
+
+def test_ml_soft_nms_oracle_is_reference(oracle):
+    """orc_ml_soft_nms against the reference's ml_soft_nms.cpp (oracle/_ref): survivors, scores, labels, indices in
+    output order, bit for bit -- including its top-k rule (`topk == i`: 0 keeps nothing, < 0 never stops).  Its hard
+    method is the reference's own CPU form of the multi-label NMS, which pins orc_ml_nms with real labels."""
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "soft_nms.npz"))
+    n_cases = len([k for k in g.files if k.startswith("m") and k.endswith("_cfg")])
+    assert n_cases >= 8
+    for i in range(n_cases):
+        method, sigma, thr, ms, topk = g["m%d_cfg" % i]
+        boxes, scores, labels = g["m%d_boxes" % i], g["m%d_scores" % i], g["m%d_labels" % i]
+        b, s, l, k = oracle.ml_soft_nms(boxes, scores, labels, sigma, thr, ms, int(method), int(topk))
+        assert np.array_equal(k, g["m%d_out_idx" % i]), i
+        assert np.array_equal(l, g["m%d_out_labels" % i]), i
+        assert np.array_equal(b, g["m%d_out_boxes" % i].reshape(-1, 4)), i
+        assert np.array_equal(s, g["m%d_out_scores" % i]), i
+        if int(method) == 0 and len(scores):
+            live = np.nonzero(scores >= np.float32(ms))[0]
+            keep = live[oracle.ml_nms(boxes[live], scores[live], labels[live], thr, 0)]
+            want = g["m%d_out_idx" % i]
+            if int(topk) > 0:
+                keep = keep[: int(topk)]
+            assert np.array_equal(keep, want), i
