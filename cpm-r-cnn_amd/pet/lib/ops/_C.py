@@ -211,21 +211,33 @@ def ml_soft_nms(dets, scores, labels, sigma, iou_threshold, min_score, method, t
     return b[:m], s[:m], l[:m], i[:m]
 
 
-def box_voting(top_boxes, top_scores, all_boxes, all_scores, scoring_method, beta, overlap_thresh):
+def box_voting(top_boxes, top_scores, all_boxes, all_scores, scoring_method, beta, overlap_thresh, top_labels=None,
+               all_labels=None):
     """box_voting.h (argument order of the reference binding): (voted boxes [N,4], re-estimated scores [N])."""
-    H.require_gpu(top_boxes, top_scores, all_boxes, all_scores)
+    H.require_gpu(top_boxes, top_scores, all_boxes, all_scores, top_labels, all_labels)
+    tl = top_labels.contiguous().to(torch.int64) if top_labels is not None else None
+    al = all_labels.contiguous().to(torch.int64) if all_labels is not None else None
     n, k = top_boxes.size(0), all_boxes.size(0)
     ob = torch.empty((n, 4), dtype=torch.float32, device=top_boxes.device)
     osc = torch.empty((n,), dtype=torch.float32, device=top_boxes.device)
     if n == 0:
         return ob, osc
     with H.guard(top_boxes.device):
-        rc = H.lib().cpm_box_voting(H.ptr(top_boxes.float().contiguous()), H.ptr(top_scores.float().contiguous()), n,
-                                    H.ptr(all_boxes.float().contiguous()), H.ptr(all_scores.float().contiguous()), k,
+        rc = H.lib().cpm_box_voting(H.ptr(top_boxes.float().contiguous()), H.ptr(top_scores.float().contiguous()),
+                                    H.ptr(tl), n, H.ptr(all_boxes.float().contiguous()),
+                                    H.ptr(all_scores.float().contiguous()), H.ptr(al), k,
                                     int(scoring_method), H.f(beta), H.f(overlap_thresh), H.ptr(ob), H.ptr(osc),
                                     H.stream())
     H.check(rc, "box_voting")
     return ob, osc
+
+
+def box_ml_voting(top_boxes, top_scores, top_labels, all_boxes, all_scores, all_labels, scoring_method, beta,
+                  overlap_thresh):
+    """box_ml_voting.h: (voted boxes, re-estimated scores, labels of the top boxes)."""
+    b, s = box_voting(top_boxes, top_scores, all_boxes, all_scores, scoring_method, beta, overlap_thresh, top_labels,
+                      all_labels)
+    return b, s, top_labels
 
 
 def _not_on_hot_path(name):
@@ -236,7 +248,7 @@ def _not_on_hot_path(name):
 
 
 # names bound by vision.cpp:21-47 that no BASELINE config reaches (out of scope)
-for _n in ("nms_rotated", "poly_nms", "box_ml_voting", "box_iou_rotated",
+for _n in ("nms_rotated", "poly_nms", "box_iou_rotated",
            "roi_align_rotated_forward", "roi_align_rotated_backward", "roi_pool_forward", "roi_pool_backward",
            "sigmoid_focalloss_forward", "sigmoid_focalloss_backward"):
     globals()[_n] = _not_on_hot_path(_n)

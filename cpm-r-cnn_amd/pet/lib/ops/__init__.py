@@ -7,7 +7,7 @@ from .losses import smooth_l1_loss, l2_loss, l2_loss_nosync
 from .modules import Conv2d, Linear, ConvTranspose2d, GroupNorm, ReLU
 from .conv import conv2d, linear, conv_transpose2d, group_norm, stem_forward, mark_shared_grad
 from .pool_points_interp import pool_points_interp, PoolPointsInterp
-from .boxes import box_iou, box_voting
+from .boxes import box_iou, box_voting, box_ml_voting
 from .deform_conv import deform_conv, cols_conv, DeformConv, DeformConvPack
 from .detect_glue import match_rois, grid_bce_loss, grid_decode, rpn_decode, topk_rows
 from .image_prep import image_prep, resample_tables, value_table, resize_linear

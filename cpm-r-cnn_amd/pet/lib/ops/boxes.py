@@ -13,3 +13,11 @@ def box_voting(top_boxes, top_scores, all_boxes, all_scores, overlap_thresh, met
     reference: boxes.py:6-22."""
     assert method in BOX_VOTING_METHODS, "Unknown box_voting method: {}".format(method)
     return _C.box_voting(top_boxes, top_scores, all_boxes, all_scores, BOX_VOTING_METHODS[method], beta, overlap_thresh)
+
+
+def box_ml_voting(top_boxes, top_scores, top_labels, all_boxes, all_scores, all_labels, overlap_thresh, method="ID",
+                  beta=1.0):
+    """Multi-label voting: only detections of the same label vote (reference: boxes.py:25-45)."""
+    assert method in BOX_VOTING_METHODS, "Unknown box_voting method: {}".format(method)
+    return _C.box_ml_voting(top_boxes, top_scores, top_labels, all_boxes, all_scores, all_labels,
+                            BOX_VOTING_METHODS[method], beta, overlap_thresh)

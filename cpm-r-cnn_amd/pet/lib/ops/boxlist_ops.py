@@ -73,3 +73,20 @@ def boxlist_ml_soft_nms(boxlist, sigma=0.5, overlap_thresh=0.3, score_thresh=0.0
     out.add_field("scores", scores)
     out.add_field("labels", labels)
     return out.convert(mode)
+
+
+def boxlist_box_ml_voting(top_boxlist, all_boxlist, thresh, scoring_method="ID", beta=1.0, score_field="scores"):
+    """boxlist_ops.py:134-148."""
+    if thresh <= 0:
+        return top_boxlist
+    from pet.lib.ops.boxes import box_ml_voting
+    from pet.utils.data.structures.bounding_box import BoxList
+    mode = top_boxlist.mode
+    boxes, scores, labels = box_ml_voting(top_boxlist.convert("xyxy").bbox, top_boxlist.get_field(score_field),
+                                          top_boxlist.get_field("labels"), all_boxlist.convert("xyxy").bbox,
+                                          all_boxlist.get_field(score_field), all_boxlist.get_field("labels"), thresh,
+                                          scoring_method, beta)
+    out = BoxList(boxes, all_boxlist.size, mode="xyxy")
+    out.add_field("scores", scores)
+    out.add_field("labels", labels)
+    return out.convert(mode)

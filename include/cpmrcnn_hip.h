@@ -272,10 +272,11 @@ int cpm_soft_nms_batched(const float* boxes, const float* scores, const int64_t*
  * Replaces _C.box_voting (pet/lib/ops/boxes.py:6-22 -> csrc/Box_ops/box_voting.cu:24-210): every top box becomes the
  * score-weighted mean of the candidate boxes with IoU >= threshold; scoring_method 0 ID, 1 TEMP_AVG, 2 AVG,
  * 3 IOU_AVG, 4 GENERALIZED_AVG, 5 QUASI_SUM re-estimates its score.  boxes [N,4] / scores [N]: top detections;
- * query_* [K,4] / [K]: all detections of the class.  One launch, no [N,K,7] intermediate. */
-int cpm_box_voting(const float* boxes, const float* scores, int N, const float* query_boxes, const float* query_scores,
-                   int K, int scoring_method, float beta, float threshold, float* out_boxes, float* out_scores,
-                   void* stream);
+ * query_* [K,4] / [K]: all detections of the class.  With labels / query_labels (int64; _C.box_ml_voting, boxes.py:25-45 ->
+ * box_ml_voting.cu) only candidates carrying the top box's label vote.  One launch, no [N,K,7] intermediate. */
+int cpm_box_voting(const float* boxes, const float* scores, const int64_t* labels /* NULL: single label */, int N,
+                   const float* query_boxes, const float* query_scores, const int64_t* query_labels, int K,
+                   int scoring_method, float beta, float threshold, float* out_boxes, float* out_scores, void* stream);
 
 /* ---- row-wise top-k for the RPN proposal selection --------------------------------------
  * Replaces `objectness.topk(pre_nms_top_n, dim=1, sorted=True)` of pet/rcnn/modeling/rpn/inference.py:79-84 (torch's

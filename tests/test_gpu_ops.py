@@ -489,3 +489,21 @@ def test_ml_soft_nms_vs_reference_golden():
             keep = ops.ml_nms(dev(boxes[live]), dev(scores[live]), torch.from_numpy(labels[live]).cuda(), float(thr),
                               max(int(topk), 0))
             assert np.array_equal(live[keep.cpu().numpy()], g["m%d_out_idx" % i]), i
+
+
+def test_box_ml_voting_equals_per_label_voting(oracle):
+    """Multi-label voting == single-label voting run label by label (box_ml_voting.cu:17: other labels have IoU 0)."""
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(29)
+    allb = _rand_boxes(rng, 600, 180)
+    alls = rng.uniform(0.05, 1, 600).astype(np.float32)
+    alll = rng.integers(1, 5, 600).astype(np.int64)
+    top = np.sort(rng.choice(600, 80, replace=False))
+    b, s, l = ops.box_ml_voting(dev(allb[top]), dev(alls[top]), torch.from_numpy(alll[top]).cuda(), dev(allb), dev(alls),
+                                torch.from_numpy(alll).cuda(), 0.5, "AVG")
+    assert np.array_equal(l.cpu().numpy(), alll[top])
+    for lab in range(1, 5):
+        ti, ai = np.nonzero(alll[top] == lab)[0], np.nonzero(alll == lab)[0]
+        wb, ws = oracle.box_voting(allb[top][ti], alls[top][ti], allb[ai], alls[ai], 0.5, 2, 1.0)
+        np.testing.assert_allclose(b.cpu().numpy()[ti], wb, rtol=2e-5, atol=1e-4)
+        np.testing.assert_allclose(s.cpu().numpy()[ti], ws, rtol=2e-5, atol=1e-6)
