@@ -258,6 +258,67 @@ int fill_geom(GridGeom& G, int points, int map_size, const int* sub_xy, const in
   return 0;
 }
 
+
+// ---- RPN loss: targets + both losses + both gradients in one pass -----------------------------------------------
+// pet/rcnn/modeling/rpn/loss.py:60-141 after matching and sampling: BoxCoder.encode of the matched gt against the
+// anchor (box_coder.py:13-24), smooth-L1 over the sampled positives, BCE-with-logits over all sampled anchors, both
+// divided by the number of sampled anchors.  The tensor-op formulation is ~60 elementwise / reduction launches over
+// 2 x 268 569 anchors forward and ~40 backward; here one thread per anchor evaluates both terms and their derivatives,
+// workgroups reduce, two atomics per workgroup.  The sums are left UNDIVIDED (the sample count lives on the device).
+__global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__ logits, const float4* __restrict__ reg,
+                                                       const float4* __restrict__ anchors,
+                                                       const int64_t* __restrict__ matched,
+                                                       const float4* __restrict__ gts, const int* __restrict__ gt_off,
+                                                       const bool* __restrict__ pos, const bool* __restrict__ neg,
+                                                       int64_t total, int per_image, float wx, float wy, float ww,
+                                                       float wh, float beta, float* __restrict__ sums,
+                                                       float* __restrict__ dlogits, float4* __restrict__ dreg) {
+  float obj = 0.f, box = 0.f;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const bool p = pos[t], n = neg[t];
+    float dl = 0.f;
+    float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p || n) {
+      const float x = logits[t], z = p ? 1.f : 0.f;
+      obj += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));                   // binary_cross_entropy_with_logits
+      dl = 1.f / (1.f + expf(-x)) - z;
+    }
+    if (p) {
+      const float4 a = anchors[t];
+      const int64_t m = matched[t] < 0 ? 0 : matched[t];
+      const float4 g = gts[gt_off[(int)(t / per_image)] + m];
+      const float pw = a.z - a.x + 1.f, ph = a.w - a.y + 1.f;
+      const float pcx = a.x + 0.5f * pw, pcy = a.y + 0.5f * ph;
+      const float gw = g.z - g.x + 1.f, gh = g.w - g.y + 1.f;
+      const float gcx = g.x + 0.5f * gw, gcy = g.y + 0.5f * gh;
+      const float tg[4] = {wx * (gcx - pcx) / pw, wy * (gcy - pcy) / ph, ww * logf(gw / pw), wh * logf(gh / ph)};
+      const float4 r = reg[t];
+      const float rv[4] = {r.x, r.y, r.z, r.w};
+      float d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float e = rv[k] - tg[k], ae = fabsf(e);
+        if (beta < 1e-5f) { box += ae; d[k] = e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f); }
+        else if (ae < beta) { box += 0.5f * ae * ae / beta; d[k] = e / beta; }
+        else { box += ae - 0.5f * beta; d[k] = e > 0.f ? 1.f : -1.f; }
+      }
+      dr = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    dlogits[t] = dl;
+    dreg[t] = dr;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) { obj += __shfl_xor(obj, d, 64); box += __shfl_xor(box, d, 64); }
+  __shared__ float s_o[4], s_b[4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { s_o[wave] = obj; s_b[wave] = box; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&sums[0], s_o[0] + s_o[1] + s_o[2] + s_o[3]);
+    atomicAdd(&sums[1], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+  }
+}
+
 }  // namespace
 
 CPM_EXPORT int cpm_match_rois(const float* rois, const int* roi_img, const float* gts, const int* gt_off, int R,
@@ -312,6 +373,27 @@ CPM_EXPORT int cpm_grid_decode(const float* logits, const int64_t* strides, cons
                      (const float4*)rois, G, mapping_ratio, roi_img, (const float4*)gts, gt_off, (float4*)out_boxes,
                      keep);
   return cpm::check_launch("grid_decode");
+}
+
+CPM_EXPORT int cpm_rpn_loss(const float* logits, const float* reg, const float* anchors, const int64_t* matched,
+                            const float* gts, const int* gt_off, const uint8_t* pos, const uint8_t* neg, int64_t total,
+                            int per_image, const float* weights4, float beta, float* sums2, float* dlogits, float* dreg,
+                            void* stream) {
+  CPM_REQUIRE(total >= 0 && per_image > 0 && total % per_image == 0, "bad sizes");
+  CPM_REQUIRE(sums2 && weights4, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(sums2, 0, 2 * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
+  if (total == 0) return CPM_OK;
+  CPM_REQUIRE(logits && reg && anchors && matched && gts && gt_off && pos && neg && dlogits && dreg, "null pointer");
+  CPM_REQUIRE((((uintptr_t)reg | (uintptr_t)anchors | (uintptr_t)gts | (uintptr_t)dreg) & 15) == 0,
+              "box tensors must be 16-byte aligned");
+  int64_t b = (total + 255) / 256;
+  if (b > 2048) b = 2048;
+  hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)b), dim3(256), 0, s, logits, (const float4*)reg,
+                     (const float4*)anchors, matched, (const float4*)gts, gt_off, (const bool*)pos, (const bool*)neg,
+                     total, per_image, weights4[0], weights4[1], weights4[2], weights4[3], beta, sums2, dlogits,
+                     (float4*)dreg);
+  return cpm::check_launch("rpn_loss");
 }
 
 CPM_EXPORT int cpm_rpn_decode(const float* reg, const int64_t* topk_idx, const float* anchors, int N, int A, int k,

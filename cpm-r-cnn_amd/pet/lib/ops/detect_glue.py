@@ -153,3 +153,41 @@ def topk_rows(scores, k):
         rc = H.lib().cpm_topk_rows(H.ptr(s), rows, n, k, H.ptr(vals), H.ptr(idx), H.stream())
     H.check(rc, "topk_rows")
     return vals, idx
+
+
+class _RPNLossFn(torch.autograd.Function):
+    """(sum of BCE terms, sum of smooth-L1 terms) over the sampled anchors, gradients produced by the same launch."""
+
+    @staticmethod
+    def forward(ctx, logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta):
+        H.require_gpu(logits, reg, anchors, gts)
+        total = logits.numel()
+        logits_c = logits.contiguous()
+        reg_c = reg.contiguous()
+        sums = torch.empty(2, dtype=torch.float32, device=logits.device)
+        dlog = torch.empty(total, dtype=torch.float32, device=logits.device)
+        dreg = torch.empty((total, 4), dtype=torch.float32, device=logits.device)
+        w4 = (ctypes.c_float * 4)(*[float(v) for v in weights])
+        with H.guard(logits.device):
+            rc = H.lib().cpm_rpn_loss(H.ptr(logits_c), H.ptr(reg_c), H.ptr(_boxes(anchors)), H.ptr(matched.contiguous()),
+                                      H.ptr(_boxes(gts)), H.ptr(gt_off.contiguous()), H.ptr(pos.contiguous()),
+                                      H.ptr(neg.contiguous()), H.c_int64(total), int(per_image), w4, H.f(beta),
+                                      H.ptr(sums), H.ptr(dlog), H.ptr(dreg), H.stream())
+        H.check(rc, "rpn_loss")
+        ctx.save_for_backward(dlog, dreg)
+        ctx.shapes = (logits.shape, reg.shape)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g_obj, g_box):
+        dlog, dreg = ctx.saved_tensors
+        ls, rs = ctx.shapes
+        return ((dlog * g_obj).view(ls), (dreg * g_box).view(rs), None, None, None, None, None, None, None, None, None)
+
+
+def rpn_loss(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta):
+    """logits [T], reg [T,4], anchors [T,4], matched int64 [T], gts [G,4], gt_off int32 [images+1], pos / neg bool [T].
+    Returns the two UNDIVIDED sums (BCE over pos|neg, smooth-L1 over pos), differentiable w.r.t. logits and reg."""
+    if matched.dtype != torch.int64 or pos.dtype != torch.bool or neg.dtype != torch.bool or gt_off.dtype != torch.int32:
+        raise RuntimeError("rpn_loss: matched int64, gt_off int32, pos / neg bool")
+    return _RPNLossFn.apply(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta)

@@ -43,9 +43,9 @@ class RPNLossComputation(object):
 
     def _call_fused(self, anchors, objectness, box_regression, targets):
         """The same loss over the whole batch with no host round trip: one cpm_match_rois launch for every anchor of
-        every image (IoU + thresholds + low-quality matches), one batch-wide sampler, and the two reductions taken
-        over all anchors under the sample masks instead of over nonzero()-gathered subsets (identical values and
-        gradients: a gather's backward scatters into zeros exactly where the mask is zero)."""
+        every image (IoU + thresholds + low-quality matches), one batch-wide sampler, and one launch for the regression
+        targets, both losses and both gradients over all anchors under the sample masks (identical values and gradients
+        to the nonzero()-gathered subsets: a gather's backward scatters into zeros exactly where the mask is zero)."""
         n_img = len(anchors)
         abox = torch.cat([a.bbox for per_img in anchors for a in per_img], dim=0)
         vis = torch.cat([a.get_field("visibility") for per_img in anchors for a in per_img], dim=0)
@@ -69,13 +69,11 @@ class RPNLossComputation(object):
         sampled = pos | neg
         n_sampled = sampled.sum()
         objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
-        objectness = objectness.squeeze(1)
-        target = self.box_coder.encode(gt_all[matched.clamp(min=0) + gt_off.long()[img]], abox)
-        target = torch.where(pos[:, None], target, 0.0)       # unsampled rows never reach the loss (nor its gradient)
-        box_loss = torch.where(pos[:, None], smooth_l1_loss(box_regression, target, beta=cfg.RPN.SMOOTH_L1_BETA),
-                               0.0).sum() / n_sampled
-        bce = F.binary_cross_entropy_with_logits(objectness, lab.clamp(min=0), reduction="none")
-        objectness_loss = (bce * sampled.to(torch.float32)).sum() / n_sampled
+        # targets (BoxCoder.encode of the matched gt), smooth-L1 over the positives, BCE over the sample, and the
+        # gradients of both: ONE launch (cpm_rpn_loss) instead of ~100 elementwise / reduction kernels
+        s_obj, s_box = ops.rpn_loss(objectness.squeeze(1), box_regression, abox, matched, gt_all, gt_off, pos, neg, per,
+                                    self.box_coder.weights, cfg.RPN.SMOOTH_L1_BETA)
+        objectness_loss, box_loss = s_obj / n_sampled, s_box / n_sampled
         return objectness_loss, box_loss
 
     def __call__(self, anchors, objectness, box_regression, targets):
