@@ -69,6 +69,19 @@ def test_reference_yamls_parse_unchanged():
             node = node[part]
         assert node == v, k
     config.reset_cfg()
+    # the offset-regression cascade family (plain / ISM / RSM / ISM+RSM)
+    cas = "/root/reference/cfgs/rcnn/mscoco/cascade/"
+    for sub in ("", "ISM/", "RSM/", "ISM+RSM/"):
+        config.reset_cfg()
+        config.merge_cfg_from_file(cas + sub + "e2e_cascade_rcnn@2_R-50-FPN_1x.yaml")
+        assert config.cfg.MODEL.CASCADE_ON and config.cfg.MODEL.FASTER_RCNN and config.cfg.CASCADE_RCNN.NUM_STAGE == 2
+    ref = dict(zip(CASCADE_OPTS[0::2], CASCADE_OPTS[1::2]))
+    for k, v in ref.items():
+        node = config.cfg
+        for part in k.split("."):
+            node = node[part]
+        assert node == v, k
+    config.reset_cfg()
 
 
 def test_anchor_generator(golden_ops, cpm_cfg):
