@@ -59,12 +59,17 @@ class FlatGradReducer(object):
     def _make_hook(self, ci):
         def hook(_):
             self._pending[ci] -= 1
-            if self._pending[ci] == 0:
-                self._launch(ci)
+            # chunks are reduced strictly in buffer order on every rank -- a collective must be issued in the same
+            # order everywhere, and the order in which chunks BECOME ready may differ between ranks (a rank whose
+            # batch leaves a head without RoIs never completes that head's chunk until finish())
+            while self._next < len(self.chunks) and self._pending[self._next] == 0:
+                self._launch(self._next)
+                self._next += 1
         return hook
 
     def begin_step(self):
         self._pending = [n for (_, _, n) in self.chunks]
+        self._next = 0
         self._handles = []
 
     def _launch(self, ci):
@@ -78,9 +83,9 @@ class FlatGradReducer(object):
         if self.world == 1:
             return
         if self.overlap:
-            for ci, n in enumerate(self._pending):
-                if n != 0:                      # tensors without a gradient this step (unused branch)
-                    self._launch(ci)
+            while self._next < len(self.chunks):   # incl. chunks with tensors that got no gradient this step
+                self._launch(self._next)
+                self._next += 1
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
         else:
             for b, e, _ in self.chunks:
