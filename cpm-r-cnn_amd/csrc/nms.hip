@@ -153,10 +153,16 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
   __syncthreads();
   int nkeep = 0;
   bool done = false;
+  // the diagonal words do not depend on the sweep: the next block's are fetched while this block is resolved
+  uint64_t diag_next = lane < n ? m[(int64_t)lane * nblk] : 0;
   for (int blk = 0; blk < nblk && !done; ++blk) {
     const int row_l = blk * 64 + lane;
     // diagonal tile words, one per lane
-    uint64_t diag = row_l < n ? m[(int64_t)row_l * nblk + blk] : 0;
+    const uint64_t diag = diag_next;
+    {
+      const int rn = row_l + 64;
+      diag_next = (blk + 1 < nblk && rn < n) ? m[(int64_t)rn * nblk + blk + 1] : 0;
+    }
     uint64_t cur = remv[blk];
     const int rows_here = min(n - blk * 64, 64);
     uint64_t kept = 0;
@@ -181,9 +187,15 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
     // of one lane per word walking up to 64 dependent loads
     if ((kept >> lane) & 1ull) {
       const uint64_t* rowp = m + (int64_t)row_l * nblk;
-      for (int j = blk + 1; j < nblk; ++j) {
-        const uint64_t v = rowp[j];
-        if (v) atomicOr(reinterpret_cast<unsigned long long*>(&remv[j]), (unsigned long long)v);
+      // eight words per trip: the loads of a trip are issued together (one word per trip leaves every load waiting out
+      // its full latency in front of the branch that consumes it)
+      for (int j0 = blk + 1; j0 < nblk; j0 += 8) {
+        uint64_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = (j0 + u < nblk) ? rowp[j0 + u] : 0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (v[u]) atomicOr(reinterpret_cast<unsigned long long*>(&remv[j0 + u]), (unsigned long long)v[u]);
       }
     }
     __syncthreads();
