@@ -166,14 +166,17 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
     uint64_t cur = remv[blk];
     const int rows_here = min(n - blk * 64, 64);
     uint64_t kept = 0;
-    for (int b = 0; b < rows_here; ++b) {
-      // wave-uniform control flow: `cur` and `kept` are identical in every lane
-      const uint64_t d = __shfl(diag, b, 64);
-      if (!((cur >> b) & 1ull)) {
-        kept |= 1ull << b;
-        cur |= d;
-        if (topk > 0 && nkeep + __popcll(kept) >= topk) { done = true; break; }
-      }
+    // wave-uniform control flow (`cur`, `alive`, `kept` are identical in every lane).  Only the rows that are still
+    // alive are visited -- find-first-set on the alive mask -- instead of all 64: a kept row removes its victims from
+    // the mask before they are reached.
+    uint64_t alive = (rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull)) & ~cur;
+    while (alive) {
+      const int b = __builtin_ctzll(alive);
+      kept |= 1ull << b;
+      cur |= __shfl(diag, b, 64);
+      alive &= ~cur;
+      alive &= (b == 63) ? 0ull : ~((2ull << b) - 1ull);          // rows up to b are done
+      if (topk > 0 && nkeep + __popcll(kept) >= topk) { done = true; break; }
     }
     // emit kept indices in order
     if ((kept >> lane) & 1ull) {
