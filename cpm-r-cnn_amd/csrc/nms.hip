@@ -206,6 +206,95 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
   if (lane == 0) keep_count[p] = nkeep;
 }
 
+// ---- 3b. the same sweep for segments of at most 2048 boxes (every RPN / RoI-head call) ------------------------------
+// The general kernel above pays one dependent global round trip per 64-row block (the kept rows' remaining words) plus
+// 64 lanes OR-ing into the same LDS word.  Here a lane keeps its WHOLE mask row (<= 32 words) in registers, the rows of
+// block b+1 are fetched while block b is resolved (two register sets, the block loop unrolled by two), and the
+// "removed" words are produced by wave OR-reductions (shuffles) of the kept lanes' registers: no LDS atomics, and
+// the only wait per block is on loads issued a block earlier.
+constexpr int SMALL_NB = 32;
+
+// OR of a 32-bit value over the wavefront, result wave-uniform: four DPP row shifts leave each 16-lane row's OR in its
+// last lane, four readlanes fetch those (ds_bpermute-based shuffles cost ~10x as much and there are 31 of these per
+// 64-row block)
+__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 15) | (uint32_t)__builtin_amdgcn_readlane((int)v, 31) |
+         (uint32_t)__builtin_amdgcn_readlane((int)v, 47) | (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
+  return ((uint64_t)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v);
+}
+
+__device__ __forceinline__ void load_row(const uint64_t* __restrict__ m, int nblk, int row, int n,
+                                         uint64_t (&w)[SMALL_NB]) {
+#pragma unroll
+  for (int j = 0; j < SMALL_NB; ++j) w[j] = (row < n && j < nblk) ? m[(int64_t)row * nblk + j] : 0ull;
+}
+
+__global__ __launch_bounds__(64) void sweep_segments_small(const uint64_t* __restrict__ mask,
+                                                           const int32_t* __restrict__ order, SegTable T, int topk,
+                                                           int64_t* __restrict__ keep,
+                                                           int32_t* __restrict__ keep_count) {
+  const int p = blockIdx.x;
+  const int base = T.off[p], n = T.off[p + 1] - base;
+  const int nblk = (n + 63) >> 6;
+  const int lane = threadIdx.x;
+  const uint64_t* m = mask + T.mask_off[p];
+  __shared__ uint64_t remv[SMALL_NB];                   // words of the boxes removed so far (one wave: no barriers)
+  if (lane < SMALL_NB) remv[lane] = 0;
+  uint64_t wa[SMALL_NB], wb[SMALL_NB];
+  load_row(m, nblk, lane, n, wa);
+  int nkeep = 0;
+  bool done = false;
+  // one block of 64 rows; `w` holds this block's rows, the caller has already issued the next block's loads
+  auto process = [&](int blk, uint64_t (&w)[SMALL_NB]) {
+    const int row_l = blk * 64 + lane;
+    const int rows_here = min(n - blk * 64, 64);
+    uint64_t diag = 0;
+#pragma unroll
+    for (int j = 0; j < SMALL_NB; ++j)
+      if (j == blk) diag = w[j];
+    uint64_t cur = remv[blk];
+    uint64_t kept = 0;
+    uint64_t alive = (rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull)) & ~cur;
+    while (alive) {
+      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));      // wave-uniform -> v_readlane below
+      kept |= 1ull << b;
+      cur |= ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(diag >> 32), b) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)diag, b);
+      alive &= ~cur;
+      alive &= (b == 63) ? 0ull : ~((2ull << b) - 1ull);
+      if (topk > 0 && nkeep + __popcll(kept) >= topk) { done = true; break; }
+    }
+    const bool mine = (kept >> lane) & 1ull;
+    if (mine) {
+      const int pos = nkeep + __popcll(kept & ((1ull << lane) - 1ull));
+      keep[base + pos] = (int64_t)order[base + row_l];
+    }
+    nkeep += __popcll(kept);
+    if (done) return;
+#pragma unroll
+    for (int j = 0; j < SMALL_NB; ++j)
+      if (j > blk && j < nblk) {
+        const uint64_t r = wave_or64(mine ? w[j] : 0ull);
+        if (lane == 0) remv[j] |= r;
+      }
+  };
+  for (int blk = 0; blk < nblk && !done; blk += 2) {
+    if (blk + 1 < nblk) load_row(m, nblk, (blk + 1) * 64 + lane, n, wb);
+    process(blk, wa);
+    if (done || blk + 1 >= nblk) break;
+    if (blk + 2 < nblk) load_row(m, nblk, (blk + 2) * 64 + lane, n, wa);
+    process(blk + 1, wb);
+  }
+  if (lane == 0) keep_count[p] = nkeep;
+}
+
 __global__ void box_iou_kernel(const float* __restrict__ boxes, int N, const float* __restrict__ query, int K,
                                float* __restrict__ out) {
   const int64_t total = (int64_t)N * K;
@@ -335,7 +424,10 @@ CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const in
     const int nblk = (maxn + 63) / 64;
     hipLaunchKernelGGL(mask_tiles, dim3(nblk, nblk, np), dim3(64), 0, s, sboxes, slabels, T, iou_threshold, mask);
     // 3. sweep
-    hipLaunchKernelGGL(sweep_segments, dim3(np), dim3(64), 0, s, mask, order, T, topk, keep, keep_count + p0);
+    if (maxn <= SMALL_NB * 64)
+      hipLaunchKernelGGL(sweep_segments_small, dim3(np), dim3(64), 0, s, mask, order, T, topk, keep, keep_count + p0);
+    else
+      hipLaunchKernelGGL(sweep_segments, dim3(np), dim3(64), 0, s, mask, order, T, topk, keep, keep_count + p0);
   }
   return cpm::check_launch("nms_batched");
 }
