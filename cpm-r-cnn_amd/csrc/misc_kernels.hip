@@ -137,6 +137,47 @@ __global__ void im2col_kernel(const float* __restrict__ x, int layout, int N, in
   }
 }
 
+// The same with Kpad % 4 == 0 and Kpad <= 512 (the 7x7x3 stem: 147 -> 160 columns): the (tap row, tap column,
+// channel) of every column comes from a table built once per workgroup instead of five divisions per element, a
+// thread produces four consecutive columns of one row and stores them as one float4 (the kernel above spent its
+// time in integer division: 281 us for the 344 MB of the 2 x 800 x 1344 stem, HBM floor ~70 us).
+__global__ void __launch_bounds__(256) im2col_vec_kernel(const float* __restrict__ x, int layout, int N, int C, int H,
+                                                         int W, int R, int S, int stride, int pad, int P, int Q,
+                                                         int Kpad, float* __restrict__ out) {
+  __shared__ int s_r[512], s_s[512], s_c[512];
+  const int K = R * S * C;
+  for (int col = threadIdx.x; col < Kpad; col += blockDim.x) {
+    const int c = col % C, t = col / C;
+    s_c[col] = col < K ? c : -1;
+    s_s[col] = t % S;
+    s_r[col] = t / S;
+  }
+  __syncthreads();
+  const int groups = Kpad / 4;
+  const int64_t rows = (int64_t)N * P * Q, total = rows * groups;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (int64_t)gridDim.x * blockDim.x) {
+    const int gidx = (int)(idx % groups);
+    const int64_t m = idx / groups;
+    const int q = (int)(m % Q);
+    const int64_t t2 = m / Q;
+    const int p = (int)(t2 % P), n = (int)(t2 / P);
+    const int ih0 = p * stride - pad, iw0 = q * stride - pad;
+    float v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int col = gidx * 4 + k;
+      const int c = s_c[col];
+      const int ih = ih0 + s_r[col], iw = iw0 + s_s[col];
+      v[k] = 0.f;
+      if (c >= 0 && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+        v[k] = layout == CPM_LAYOUT_NHWC ? x[(((int64_t)n * H + ih) * W + iw) * C + c]
+                                         : x[(((int64_t)n * C + c) * H + ih) * W + iw];
+    }
+    *(float4*)(out + m * Kpad + gidx * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 // ---- 3x3 / stride 2 / pad 1 max-pool, NHWC (4 channels per thread) ---------------------------------------
 __global__ void maxpool_kernel(const float* __restrict__ x, int N, int H, int W, int C, int P, int Q,
                                float* __restrict__ y) {
@@ -390,8 +431,12 @@ CPM_EXPORT int cpm_im2col(const float* x, int layout, int N, int C, int H, int W
   CPM_REQUIRE(N > 0 && C > 0 && H > 0 && W > 0 && R > 0 && S > 0 && stride > 0 && Kpad >= R * S * C, "bad shape");
   CPM_REQUIRE(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1, "bad output size");
   const int64_t total = (int64_t)N * P * Q * Kpad;
-  hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, layout, N,
-                     C, H, W, R, S, stride, pad, P, Q, Kpad, out);
+  if (Kpad % 4 == 0 && Kpad <= 512 && (((uintptr_t)out) & 15) == 0)
+    hipLaunchKernelGGL(im2col_vec_kernel, dim3(grid_for(total / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x,
+                       layout, N, C, H, W, R, S, stride, pad, P, Q, Kpad, out);
+  else
+    hipLaunchKernelGGL(im2col_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, (hipStream_t)stream, x, layout,
+                       N, C, H, W, R, S, stride, pad, P, Q, Kpad, out);
   return cpm::check_launch("im2col");
 }
 
