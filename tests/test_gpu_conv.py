@@ -156,7 +156,8 @@ def test_conv_transpose(cin, cout, groups, hw, n):
     assert relerr(xd.grad, xr.grad) < TOL and relerr(wd.grad, wr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
 
 
-@pytest.mark.parametrize("n,c,hw,g,relu", [(5, 576, 7, 36, True), (4, 576, 14, 9, True), (3, 64, 5, 32, False)])
+@pytest.mark.parametrize("n,c,hw,g,relu", [(5, 576, 7, 36, True), (4, 576, 14, 9, True), (3, 64, 5, 32, False),
+                                            (98, 576, 7, 36, False), (2, 64, 8, 4, True), (3, 640, 3, 40, True)])
 def test_group_norm(n, c, hw, g, relu):
     from pet.lib.ops import conv as ops
     x, gm, bt = rnd(n, c, hw, hw, seed=1) * 2 + 0.3, rnd(c, seed=2) * 0.2 + 1, rnd(c, seed=3) * 0.2
