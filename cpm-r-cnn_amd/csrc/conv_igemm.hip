@@ -1249,7 +1249,8 @@ __global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per
       if (lane < taps && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
         xt = a.x[((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g];
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) acc[t] += dyv * __shfl(xt, t, 64);
+      for (int t = 0; t < TAPS; ++t)                      // v_readlane (the index is a constant): __shfl is a ds_bpermute
+        acc[t] += dyv * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xt), t));
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) red[wave][t][lane] = acc[t];
