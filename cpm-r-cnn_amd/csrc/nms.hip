@@ -171,9 +171,10 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
     // the mask before they are reached.
     uint64_t alive = (rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull)) & ~cur;
     while (alive) {
-      const int b = __builtin_ctzll(alive);
+      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));      // wave-uniform -> v_readlane below
       kept |= 1ull << b;
-      cur |= __shfl(diag, b, 64);
+      cur |= ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(diag >> 32), b) << 32) |
+             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)diag, b);
       alive &= ~cur;
       alive &= (b == 63) ? 0ull : ~((2ull << b) - 1ull);          // rows up to b are done
       if (topk > 0 && nkeep + __popcll(kept) >= topk) { done = true; break; }

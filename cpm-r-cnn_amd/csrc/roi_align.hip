@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
           const int t = __shfl_up(incl, d, 64);
           if (lane >= d) incl += t;
         }
-        const int total = __shfl(incl, 63, 64);
+        const int total = __builtin_amdgcn_readlane(incl, 63);
         if (total <= GLIST) {
           int slot = incl - cnt;
           if (cnt != 0) {
