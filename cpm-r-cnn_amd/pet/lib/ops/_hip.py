@@ -39,7 +39,7 @@ def lib():
                 L = ctypes.CDLL(LIB_PATH)
                 L.cpm_last_error.restype = ctypes.c_char_p
                 for name in ("cpm_nms_workspace_bytes", "cpm_conv2d_workspace_bytes",
-                             "cpm_roi_align_fpn_gather_workspace_bytes"):
+                             "cpm_roi_align_fpn_gather_workspace_bytes", "cpm_sample_pos_neg_workspace_bytes"):
                     getattr(L, name).restype = c_size_t
                 mode = os.environ.get("CPM_CONV_MATH", "").lower()
                 if mode:

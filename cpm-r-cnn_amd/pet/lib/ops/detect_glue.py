@@ -191,3 +191,42 @@ def rpn_loss(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, we
     if matched.dtype != torch.int64 or pos.dtype != torch.bool or neg.dtype != torch.bool or gt_off.dtype != torch.int32:
         raise RuntimeError("rpn_loss: matched int64, gt_off int32, pos / neg bool")
     return _RPNLossFn.apply(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta)
+
+
+_SAMPLE_WS = {}
+_LABEL_DTYPES = {torch.float32: 0, torch.int64: 1, torch.int32: 2}
+
+
+def sample_pos_neg(labels, counts, batch_size_per_image, positive_fraction, seed=None, cand_target=0):
+    """labels [R] (float32 / int64 / int32: >= 1 positive, 0 negative, < 0 ignored), image-contiguous with `counts`
+    elements per image (host ints).  Returns (pos [R] bool, neg [R] bool, quota [images, 2] int32 = (n_pos, n_neg)):
+    BalancedPositiveNegativeSampler (pet/rcnn/utils/balanced_positive_negative_sampler.py:27-67) for all images in
+    three launches and no host round trip (cpm_sample_pos_neg).  seed: None draws one from torch's CPU generator
+    (torch.manual_seed makes the run reproducible); the same seed gives the same sample."""
+    H.require_gpu(labels)
+    if labels.dim() != 1 or labels.dtype not in _LABEL_DTYPES:
+        raise RuntimeError("sample_pos_neg: labels must be 1-d float32 / int64 / int32")
+    counts = [int(c) for c in counts]
+    n_img = len(counts)
+    if sum(counts) != labels.numel() or n_img < 1:
+        raise RuntimeError("sample_pos_neg: counts must sum to len(labels)")
+    offs = (ctypes.c_int64 * (n_img + 1))()
+    for i, c in enumerate(counts):
+        offs[i + 1] = offs[i] + c
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # CPU generator: no device traffic
+    dev = labels.device
+    lab = labels if labels.is_contiguous() else labels.contiguous()
+    pos = torch.empty(lab.numel(), dtype=torch.bool, device=dev)
+    neg = torch.empty(lab.numel(), dtype=torch.bool, device=dev)
+    quota = torch.empty((n_img, 2), dtype=torch.int32, device=dev)
+    ws = _SAMPLE_WS.get(dev)
+    if ws is None:
+        ws = _SAMPLE_WS[dev] = torch.empty(int(H.lib().cpm_sample_pos_neg_workspace_bytes()), dtype=torch.uint8,
+                                           device=dev)
+    with H.guard(dev):
+        rc = H.lib().cpm_sample_pos_neg(H.ptr(lab), _LABEL_DTYPES[lab.dtype], offs, n_img, int(batch_size_per_image),
+                                        int(batch_size_per_image * positive_fraction), ctypes.c_uint64(seed),
+                                        int(cand_target), H.ptr(pos), H.ptr(neg), H.ptr(quota), H.ptr(ws), H.stream())
+    H.check(rc, "sample_pos_neg")
+    return pos, neg, quota

@@ -60,8 +60,8 @@ class CLSLossComputation(object):
         lab = gt_labels[matched.clamp(min=0) + base]
         lab = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, 0, lab)
         lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1, lab)
-        pos, neg = batch_pos_neg_sample(lab, img, n_img, self.fg_bg_sampler.batch_size_per_image,
-                                        self.fg_bg_sampler.positive_fraction)
+        pos, neg, _ = batch_pos_neg_sample(lab, counts, self.fg_bg_sampler.batch_size_per_image,
+                                           self.fg_bg_sampler.positive_fraction)
         # the one host round trip: the selection mask, carrying the labels of the selected rows along (-2 = not
         # selected) so that later label-driven selections (positives for the grid branch, negatives for the RSM
         # sample) are made on the host without another device query

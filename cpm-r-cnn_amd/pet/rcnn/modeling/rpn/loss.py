@@ -64,10 +64,9 @@ class RPNLossComputation(object):
             lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1.0, lab)
         if "not_visibility" in self.discard_cases:
             lab = torch.where(vis, lab, -1.0)
-        pos, neg = batch_pos_neg_sample(lab, img, n_img, self.fg_bg_sampler.batch_size_per_image,
-                                        self.fg_bg_sampler.positive_fraction)
-        sampled = pos | neg
-        n_sampled = sampled.sum()
+        pos, neg, quota = batch_pos_neg_sample(lab, [per] * n_img, self.fg_bg_sampler.batch_size_per_image,
+                                               self.fg_bg_sampler.positive_fraction)
+        n_sampled = quota.sum()
         objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
         # targets (BoxCoder.encode of the matched gt), smooth-L1 over the positives, BCE over the sample, and the
         # gradients of both: ONE launch (cpm_rpn_loss) instead of ~100 elementwise / reduction kernels

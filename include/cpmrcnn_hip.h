@@ -295,6 +295,23 @@ int cpm_rpn_loss(const float* logits, const float* reg, const float* anchors, co
  * that order unspecified).  1 <= k <= min(n, 2048).  NaNs rank above every number, as in torch. */
 int cpm_topk_rows(const float* scores, int rows, int n, int k, float* out_scores, int64_t* out_idx, void* stream);
 
+/* ---- fixed-size positive / negative sampling for the whole batch ---------------------------
+ * Replaces BalancedPositiveNegativeSampler.__call__ (pet/rcnn/utils/balanced_positive_negative_sampler.py:27-67, called
+ * from pet/rcnn/modeling/rpn/loss.py:102 and pet/rcnn/modeling/grid_cascade_rcnn/loss.py:77), which runs per image
+ * nonzero() + torch.randperm on the host's schedule.  labels [total] (label_dtype 0 float32 / 1 int64 / 2 int32;
+ * >= 1 positive, 0 negative, < 0 ignored), image i owns [h_offsets[i], h_offsets[i+1]) (HOST array, images <= 64).
+ * Per image: n_pos = min(#positives, max_pos), n_neg = min(#negatives, batch_size_per_image - n_pos), each a uniformly
+ * random subset of its class (keys from a counter hash of (seed, image, index); the same seed gives the same sample).
+ * pos / neg [total] receive 0/1 for EVERY element; out_quota [images][2] = (n_pos, n_neg).  Sample sizes up to 1024 per
+ * class go through a short candidate list; larger ones through a one-workgroup radix select (slower, same distribution).
+ * cand_target: expected length of the per-class short list the selection works on (0 = 2 * quota + 64); any value
+ * yields exact sample sizes -- small values only exercise the index-order fill path (tests).
+ * workspace: cpm_sample_pos_neg_workspace_bytes() device bytes, contents irrelevant. */
+size_t cpm_sample_pos_neg_workspace_bytes(void);
+int cpm_sample_pos_neg(const void* labels, int label_dtype, const int64_t* h_offsets, int n_img,
+                       int batch_size_per_image, int max_pos, uint64_t seed, int cand_target, uint8_t* pos, uint8_t* neg,
+                       int32_t* out_quota, void* workspace, void* stream);
+
 /* ---- image preparation on the device ---------------------------------
  * Replaces, per image, the host transform chain of pet/rcnn/datasets/transform.py:6-50:
  *   Resize (pet/utils/data/transforms/transforms.py:29-64 -> PIL.Image.resize(BILINEAR), i.e. Pillow's

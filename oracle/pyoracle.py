@@ -371,3 +371,20 @@ def cv_resize_linear(img, scale, flip=False):
     bot = im[y1][:, x0] * a0 + im[y1][:, x1] * a1
     out = top * (np.float32(1) - ay)[:, None, None] + bot * ay[:, None, None]
     return out.astype(np.float32)
+
+
+def balanced_sample_quotas(labels, counts, batch_size_per_image, positive_fraction):
+    """Per-image sample sizes of BalancedPositiveNegativeSampler
+    (pet/rcnn/utils/balanced_positive_negative_sampler.py:36-46): num_pos = min(#(label >= 1), int(batch * fraction)),
+    num_neg = min(#(label == 0), batch - num_pos).  The members are a uniformly random subset (torch.randperm,
+    :49-50), so the checkable facts are the sizes, the membership (a sampled positive IS a positive) and the
+    inclusion frequencies.  labels: 1-d array, image-contiguous; counts: candidates per image.  -> int [images, 2]."""
+    labels = np.asarray(labels)
+    out, o = [], 0
+    for c in counts:
+        seg = labels[o:o + c]
+        num_pos = min(int((seg >= 1).sum()), int(batch_size_per_image * positive_fraction))
+        num_neg = min(int((seg == 0).sum()), batch_size_per_image - num_pos)
+        out.append((num_pos, num_neg))
+        o += c
+    return np.asarray(out, dtype=np.int64).reshape(len(counts), 2)

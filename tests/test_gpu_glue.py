@@ -356,3 +356,123 @@ def test_topk_rows_edge_cases():
         ops.topk_rows(torch.zeros(1, 5000, device="cuda"), 2049)
     with pytest.raises(RuntimeError):
         ops.topk_rows(torch.zeros(1, 50), 5)
+
+
+# ---- cpm_sample_pos_neg (BalancedPositiveNegativeSampler for the whole batch) ----------------------------------------
+
+def _sample_labels(rng, counts, dtype):
+    lab = rng.integers(-1, 3, sum(counts)).astype(np.int64)            # -1 ignore, 0 negative, 1..2 positive
+    return lab.astype(dtype)
+
+
+def _check_sample(oracle, lab, counts, batch, frac, pos, neg, quota):
+    want = oracle.balanced_sample_quotas(lab, counts, batch, frac)
+    assert quota.cpu().numpy().tolist() == want.tolist()
+    p, n = pos.cpu().numpy(), neg.cpu().numpy()
+    assert p.dtype == np.bool_ and n.dtype == np.bool_
+    assert not (p & ~(lab >= 1)).any() and not (n & ~(lab == 0)).any()
+    o = 0
+    for i, c in enumerate(counts):
+        assert int(p[o:o + c].sum()) == want[i, 0] and int(n[o:o + c].sum()) == want[i, 1], (i, want[i])
+        o += c
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.int64, np.int32])
+@pytest.mark.parametrize("cand_target", [0, 1, 40])
+def test_sample_pos_neg_sizes_and_membership(oracle, dtype, cand_target):
+    """Exact sample sizes (pet/rcnn/utils/balanced_positive_negative_sampler.py:36-46) and membership for every label
+    dtype; cand_target 1 / 40 starve the short list so that the index-order fill path produces part of the sample."""
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(5)
+    counts = [6000, 0, 37, 20000, 300]
+    lab = _sample_labels(rng, counts, dtype)
+    lab[6037:6037 + 20000][rng.random(20000) < 0.995] = 0               # image 3: ~30 positives, the rest negatives
+    lab[26037:] = np.where(lab[26037:] == 0, -1, lab[26037:])            # image 4: no negatives at all
+    for batch, frac in ((512, 0.25), (256, 0.5), (16, 0.5), (0, 0.5), (3000, 0.5), (10 ** 7, 0.5)):   # 3000: radix path
+        pos, neg, quota = ops.sample_pos_neg(torch.from_numpy(lab).cuda(), counts, batch, frac, seed=77,
+                                             cand_target=cand_target)
+        _check_sample(oracle, lab, counts, batch, frac, pos, neg, quota)
+
+
+def test_sample_pos_neg_seed_and_uniformity(oracle):
+    """The same seed reproduces the sample, another seed changes it, and over many seeds every member of a bucket is
+    drawn with probability quota / size (the reference draws torch.randperm(size)[:quota], :49-50)."""
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(6)
+    counts = [4000, 2500]
+    lab = _sample_labels(rng, counts, np.int64)
+    t = torch.from_numpy(lab).cuda()
+    a = ops.sample_pos_neg(t, counts, 256, 0.5, seed=1)
+    b = ops.sample_pos_neg(t, counts, 256, 0.5, seed=1)
+    c = ops.sample_pos_neg(t, counts, 256, 0.5, seed=2)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert not torch.equal(a[0], c[0]) and not torch.equal(a[1], c[1])
+    draws = 400
+    hits_p = torch.zeros(sum(counts), device="cuda")
+    hits_n = torch.zeros(sum(counts), device="cuda")
+    for s in range(draws):
+        p, n, _ = ops.sample_pos_neg(t, counts, 256, 0.5, seed=1000 + s)
+        hits_p += p
+        hits_n += n
+    hits_p, hits_n = hits_p.cpu().numpy(), hits_n.cpu().numpy()
+    o = 0
+    for cnt in counts:
+        seg = lab[o:o + cnt]
+        for hits, member, quota in ((hits_p[o:o + cnt], seg >= 1, 128), (hits_n[o:o + cnt], seg == 0, 128)):
+            size = int(member.sum())
+            assert size > quota
+            prob = quota / size
+            rate = hits[member] / draws
+            assert abs(float(rate.mean()) - prob) < 1e-5                # exact sizes every draw
+            sd = np.sqrt(prob * (1 - prob) / draws)
+            assert rate.max() < prob + 6 * sd and rate.min() > prob - 6 * sd
+            # halves of the bucket (low / high indices) are drawn equally often: no positional bias
+            idx = np.flatnonzero(member)
+            lo, hi = hits[idx[: size // 2]].sum(), hits[idx[size // 2:]].sum()
+            assert abs(lo - hi) < 12 * np.sqrt(draws * quota * 0.25)      # sd(lo - hi) = 2 sqrt(draws quota / 4)
+        o += cnt
+
+
+def test_sample_pos_neg_large_quota_uniform(oracle):
+    """Sample sizes above 1024 per class take the radix-select path: exact sizes, inclusion rate quota / size."""
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(9)
+    counts = [9000]
+    lab = _sample_labels(rng, counts, np.int32)
+    t = torch.from_numpy(lab).cuda()
+    draws = 120
+    hits = torch.zeros(9000, device="cuda")
+    for s in range(draws):
+        p, n, q = ops.sample_pos_neg(t, counts, 2400, 0.5, seed=31 + s)
+        if s == 0:
+            _check_sample(oracle, lab, counts, 2400, 0.5, p, n, q)
+        hits += p
+    member = lab >= 1
+    prob = 1200 / int(member.sum())
+    assert 0.2 < prob < 0.6
+    rate = hits.cpu().numpy()[member] / draws
+    sd = np.sqrt(prob * (1 - prob) / draws)
+    assert abs(float(rate.mean()) - prob) < 1e-5 and rate.max() < prob + 6 * sd and rate.min() > prob - 6 * sd
+
+
+def test_sample_pos_neg_rpn_scale(oracle):
+    """BASELINE-size call: 2 x 268569 anchors, ~40 positives per image, a third of the anchors ignored."""
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(8)
+    counts = [268569, 268569]
+    lab = np.where(rng.random(sum(counts)) < 0.33, -1.0, 0.0).astype(np.float32)
+    lab[rng.integers(0, counts[0], 40)] = 1.0
+    lab[counts[0] + rng.integers(0, counts[1], 300)] = 1.0
+    pos, neg, quota = ops.sample_pos_neg(torch.from_numpy(lab).cuda(), counts, 256, 0.5)
+    _check_sample(oracle, lab, counts, 256, 0.5, pos, neg, quota)
+
+
+def test_sample_pos_neg_rejects_bad_arguments():
+    import pet.lib.ops as ops
+    t = torch.zeros(10, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.sample_pos_neg(t, [4, 4], 16, 0.5)                           # counts do not cover the labels
+    with pytest.raises(RuntimeError):
+        ops.sample_pos_neg(t.double(), [10], 16, 0.5)
+    with pytest.raises(RuntimeError):
+        ops.sample_pos_neg(torch.zeros(10), [10], 16, 0.5)               # host tensor: there is no CPU path

@@ -205,35 +205,16 @@ def test_x101_dcn_state_dict_abi(cpm_cfg):
                for m in packs)                                    # resnext.py:248-252
 
 
-def test_batch_pos_neg_sample_quotas():
-    """pet/rcnn/utils/fused_sampling.py (pure torch, runs on the CPU): per image at most batch*fraction positives, the
-    rest negatives up to the batch size, never an ignored candidate, every bucket uniformly sampled."""
-    from pet.rcnn.utils.fused_sampling import batch_pos_neg_sample
-    g = torch.Generator().manual_seed(0)
-    n_img, R = 3, 6000
-    img = torch.randint(0, n_img, (R,), generator=g)
-    lab = torch.randint(-1, 3, (R,), generator=g)                       # -1 ignore, 0 negative, 1..2 positive
-    lab[(img == 1) & (lab >= 1)] = 0                                   # image 1: ...
-    lab[(img == 1) & (torch.arange(R) % 97 == 0)] = 2                  # ... only a handful of positives
-    torch.manual_seed(1)
-    pos, neg = batch_pos_neg_sample(lab, img, n_img, 512, 0.25)
-    assert not bool((pos & (lab < 1)).any()) and not bool((neg & (lab != 0)).any())
-    for i in range(n_img):
-        m = img == i
-        n_pos_avail, n_neg_avail = int(((lab >= 1) & m).sum()), int(((lab == 0) & m).sum())
-        n_pos, n_neg = int((pos & m).sum()), int((neg & m).sum())
-        assert n_pos == min(128, n_pos_avail)
-        assert n_neg == min(512 - n_pos, n_neg_avail)
-    # uniformity: over many draws every positive of image 0 is picked with probability 128 / available
-    m0 = (img == 0) & (lab >= 1)
-    hits = torch.zeros(R)
-    for s in range(60):
-        torch.manual_seed(100 + s)
-        p, _ = batch_pos_neg_sample(lab, img, n_img, 512, 0.25)
-        hits += p.float()
-    rate = hits[m0] / 60
-    expect = 128 / int(m0.sum())
-    assert abs(float(rate.mean()) - expect) < 1e-6 and float(rate.max()) < expect + 0.35 and float(rate.min()) >= 0
+def test_balanced_sample_quotas_oracle():
+    """oracle/pyoracle.py balanced_sample_quotas against hand-worked cases of
+    pet/rcnn/utils/balanced_positive_negative_sampler.py:36-46 (the GPU test checks cpm_sample_pos_neg against it)."""
+    import oracle.pyoracle as po
+    lab = np.array([1, 2, 0, 0, -1, 0,   0, 0, 0, -1,   3, 3, 3, 3, 0], dtype=np.int64)
+    q = po.balanced_sample_quotas(lab, [6, 4, 5], 4, 0.5)
+    assert q.tolist() == [[2, 2], [0, 3], [2, 1]]
+    q = po.balanced_sample_quotas(lab.astype(np.float32), [6, 4, 5], 512, 0.25)
+    assert q.tolist() == [[2, 3], [0, 3], [4, 1]]
+    assert po.balanced_sample_quotas(lab[:0], [0], 4, 0.5).tolist() == [[0, 0]]
 
 
 def test_l2_loss_nosync_matches_reference_quirk(golden_ops):

@@ -30,12 +30,12 @@ for e in prof.events():
         continue
     dt = getattr(e, "device_time_total", 0) or 0
     self_dt = getattr(e, "self_device_time_total", 0) or 0
-    if self_dt < 8:                      # us of kernel time attributed to this op itself
+    if self_dt < float(os.environ.get("MIN_US", "8")):       # us of kernel time attributed to this op itself
         continue
     st = [s for s in (e.stack or []) if "cpm-r-cnn_amd" in s or "bench.py" in s]
     key = (e.name, str(e.input_shapes)[:80], st[0][-90:] if st else "?")
     agg[key][0] += 1
     agg[key][1] += self_dt
-rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]
+rows = sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get("ROWS", "45"))]
 for (name, shp, where), (n, t) in rows:
     print("%7.1f us/step x%-4.1f %-22s %-60s %s" % (t / 2, n / 2, name, shp, where))
