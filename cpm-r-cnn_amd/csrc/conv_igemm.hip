@@ -860,6 +860,8 @@ struct WgradArgs {
   int R, S, stride, pad, dil, groups, Cg, OCg, M;
   int split_k, chunks;  // chunks = ceil(M/32)
   unsigned x_bytes, dy_bytes;
+  float* dshift;    // [OCtot] or null: += sum over pixels of dy (the bias gradient), folded into the dy reads of the
+                    // workgroups that own tap 0 / input-channel tile 0 (every dy element passes exactly one of them)
 };
 
 template <int BM, int BN, int WM, int WN, bool VEC>
@@ -966,12 +968,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       if (b_oh[i] >= a.OH) { b_oh[i] -= a.OH; ++b_n[i]; }
     }
   };
+  const bool do_bias = a.dshift != nullptr && tap == 0 && tile_n == 0;      // block-uniform
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);        // this thread's channel vector (256 % AV == 0: same for all i)
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < APASS; ++i) {
       const int id = tid + i * 256;
       const int pr = id / AV, cv = (id % AV) * 4;
       if (pr < 32) *(float4*)&As[buf][pr][cv] = ra[i];
+      if (do_bias && pr < 32) { bsum.x += ra[i].x; bsum.y += ra[i].y; bsum.z += ra[i].z; bsum.w += ra[i].w; }
     }
 #pragma unroll
     for (int i = 0; i < BPASS; ++i) {
@@ -1014,6 +1019,20 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
     if (it + 1 < nk) store_chunk(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+
+  if (do_bias) {
+    // threads tid % AV share a channel vector: fold the 256 / AV partial sums through LDS, one atomic per channel
+    static_assert(256 % AV == 0 && (256 / AV) * BM <= 2 * 32 * PA, "bias reduction layout");
+    float* sb = &As[0][0][0];
+    *(float4*)&sb[(tid / AV) * BM + (tid % AV) * 4] = bsum;
+    __syncthreads();
+    if (tid < BM && oc0 + tid < a.OCg) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 256 / AV; ++p) t += sb[p * BM + tid];
+      atomicAdd(a.dshift + g * a.OCg + oc0 + tid, t);
+    }
   }
 
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
@@ -1117,10 +1136,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // the 4 pixels of one channel -> one 8-byte hi store and one 8-byte lo store in the channel's row
   const int wa_sw = (((pra >> 1) ^ ((qa >> 2) & 3)) << 2) | ((pra & 1) << 1);
   const int wb_sw = (((prb >> 1) ^ ((qb >> 2) & 3)) << 2) | ((prb & 1) << 1);
+  const bool do_bias = a.dshift != nullptr && tap == 0 && tile_n == 0;      // block-uniform
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);        // channels oc0 + 4*qa .. +3 over this thread's pixel runs
   auto store_chunk = [&](int buf) {
     if (pra < 8) {
       const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
                             make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
+      if (do_bias) {
+        bsum.x += (ch[0].x + ch[0].y) + (ch[0].z + ch[0].w);
+        bsum.y += (ch[1].x + ch[1].y) + (ch[1].z + ch[1].w);
+        bsum.z += (ch[2].x + ch[2].y) + (ch[2].z + ch[2].w);
+        bsum.w += (ch[3].x + ch[3].y) + (ch[3].z + ch[3].w);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint2 hi, lo;
@@ -1191,6 +1218,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (it + 1 < nk) store_chunk(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+
+  if (do_bias) {
+    // the 8 pixel runs of a channel vector sit in 8 threads: fold through LDS (free after the loop's last barrier)
+    static_assert(8 * BM <= LDS_AB, "bias reduction layout");
+    if (pra < 8) *(float4*)&smem[pra * BM + 4 * qa] = bsum;
+    __syncthreads();
+    if (tid < BM && oc0 + tid < a.OCg) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) t += smem[p * BM + tid];
+      atomicAdd(a.dshift + g * a.OCg + oc0 + tid, t);
+    }
+    __syncthreads();
   }
 
   // un-permute through LDS: accumulator row R holds output channel (R % QA) * 4 + R / QA, column C input channel
@@ -1656,13 +1697,10 @@ CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float*
                    "cpm_conv_transpose2d_forward");
 }
 
-CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
-  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
-  CPM_REQUIRE(x && dy && dw, "null pointer");
-  hipStream_t s = (hipStream_t)stream;
+static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                     hipStream_t s) {
   WgradArgs a = {};
-  a.x = x; a.dy = dy; a.dw = dw;
+  a.x = x; a.dy = dy; a.dw = dw; a.dshift = dbias;
   a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C; a.OH = d->P; a.OW = d->Q; a.OCtot = d->K;
   a.R = d->R; a.S = d->S; a.stride = d->stride; a.pad = d->pad; a.dil = d->dilation;
   a.groups = d->groups; a.Cg = d->C / d->groups; a.OCg = d->K / d->groups;
@@ -1694,6 +1732,10 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   ProfScope prof_scope(s, 2);
   if (a.Cg == 1 && taps <= 16) {
+    if (dbias) {
+      cpm::set_error("cpm_conv2d_backward_weight_bias: one input channel per group is not covered, use cpm_epilogue_backward");
+      return CPM_EINVAL;
+    }
     const int ppb = 128;
     dim3 grid((unsigned)cpm::cdiv(a.M, ppb), (unsigned)a.groups);
     hipLaunchKernelGGL((wgrad_cg1_kernel<16>), grid, dim3(256), 0, s, a, ppb);
@@ -1728,6 +1770,20 @@ CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x
   }
 #undef WLAUNCH
   return cpm::check_launch("conv wgrad");
+}
+
+CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && dy && dw, "null pointer");
+  return run_wgrad(d, x, dy, dw, nullptr, (hipStream_t)stream);
+}
+
+CPM_EXPORT int cpm_conv2d_backward_weight_bias(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
+                                               float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && dy && dw && dbias, "null pointer");
+  return run_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);
 }
 
 // ---- profiling hooks (bench.py roofline leg) -----------------------------------------------------------

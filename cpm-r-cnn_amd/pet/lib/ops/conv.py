@@ -170,8 +170,9 @@ def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wpa
     return dx
 
 
-def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None):
-    """dw (+)= x (*) dy.  `out` (same strides as the weight) is accumulated into when given."""
+def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None, dbias=None):
+    """dw (+)= x (*) dy.  `out` (same strides as the weight) is accumulated into when given.
+    dbias [K]: the bias gradient sum_m dy[m, k] is ADDED to it by the same launch (cpm_conv2d_backward_weight_bias)."""
     n, c, h, wd = x.shape
     k, _, r, s = w_like.shape
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
@@ -180,8 +181,12 @@ def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None):
         return dw
     ws = _ws(d, x.device)
     with H.guard(x.device):
-        rc = H.lib().cpm_conv2d_backward_weight(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(ws),
-                                                H.c_size_t(ws.numel()), H.stream())
+        if dbias is not None:
+            rc = H.lib().cpm_conv2d_backward_weight_bias(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(dw),
+                                                         H.ptr(dbias), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+        else:
+            rc = H.lib().cpm_conv2d_backward_weight(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(dw), H.ptr(ws),
+                                                    H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_weight")
     return dw
 
@@ -280,7 +285,10 @@ class _ConvFn(Function):
         want_shift = has_shift and need_shift
         want_res = has_res and need_res
         dpre, g, dshift = dy, dy, None
-        if masked or want_shift:
+        # a bias gradient alone (no gate, no frozen scale to apply) rides on the weight-gradient kernel's dy reads
+        fuse_bias = (want_shift and not masked and need_w and groups == 1 and x_shape[1] > 1 and x.numel() > 0
+                     and dy.numel() > 0)
+        if masked or (want_shift and not fuse_bias):
             split_res = want_res and has_scale          # g and g*scale are both needed
             bp = ctx.bparam if want_shift else None
             dpre_k, dres_k, dshift = epilogue_backward(dy, y, scale, relu, want_dpre=masked, want_dres=split_res,
@@ -321,15 +329,24 @@ class _ConvFn(Function):
         dw = None
         if need_w:
             wp = ctx.wparam
+            dbias = None
+            if fuse_bias:
+                bp = ctx.bparam
+                dbias = bp._cpm_grad_sink if bp is not None else torch.zeros(w.shape[0], dtype=torch.float32,
+                                                                             device=dy.device)
+                if bp is None:
+                    dshift = dbias
             if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
-                conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink)
+                conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias)
                 wp._cpm_uses -= 1
                 if wp._cpm_uses == 0:
                     ready = getattr(wp, "_cpm_grad_ready", None)
                     if ready is not None:
                         ready(wp)
             else:
-                dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups)
+                dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, dbias=dbias)
+            if fuse_bias and ctx.bparam is not None:
+                _sink_done(ctx.bparam)                  # accumulated in place
         return dx, dw, None, dshift, gres, None, None, None, None, None, None, None
 
 

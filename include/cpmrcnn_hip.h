@@ -143,6 +143,12 @@ int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy, const floa
                              void* workspace, size_t workspace_bytes, void* stream);
 int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
                                void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the bias gradient of a `conv + bias` layer (nn.Conv2d(bias=True): FPN laterals / outputs FPN.py:30-50,
+ * RPN predictors rpn/rpn.py:24-31, the grid head's convs grid_heads.py:41-57) folded in: dbias[k] += sum_m dy[m][k],
+ * taken from the dy tiles the weight-gradient workgroups of tap 0 / input-channel tile 0 read anyway, instead of a
+ * separate pass over dy (cpm_epilogue_backward).  groups with one input channel each are not covered (EINVAL). */
+int cpm_conv2d_backward_weight_bias(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                                    void* workspace, size_t workspace_bytes, void* stream);
 /* Data gradient with the epilogue-backward of the layer that PRODUCED x folded into its epilogue:
  *   dx[m][c] = (in_act[m][c] > 0) * in_scale[c] * conv^T(dy, w)[m][c]
  * i.e. when x = relu(prev*in_scale + shift) has this conv as its only consumer, dx is already the gradient at

@@ -52,7 +52,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-@pytest.mark.parametrize("epi", ["plain", "bias_relu", "affine_res_relu"])
+@pytest.mark.parametrize("epi", ["plain", "bias", "bias_relu", "affine_res_relu"])
 def test_conv_fwd_bwd(case, epi):
     from pet.lib.ops import conv as ops
     name, N, C, H, W, K, R, stride, pad, groups = case
@@ -61,7 +61,9 @@ def test_conv_fwd_bwd(case, epi):
     P, Q = ops.out_size(H, R, stride, pad), ops.out_size(W, R, stride, pad)
     scale = shift = res = None
     relu = False
-    if epi == "bias_relu":
+    if epi == "bias":                   # bias gradient folded into the weight-gradient launch (groups == 1)
+        shift = rnd(K, seed=3, scale=0.1)
+    elif epi == "bias_relu":
         shift, relu = rnd(K, seed=3, scale=0.1), True
     elif epi == "affine_res_relu":
         scale = torch.rand(K, generator=torch.Generator().manual_seed(4)) + 0.5
