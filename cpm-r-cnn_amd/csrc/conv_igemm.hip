@@ -773,6 +773,14 @@ __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict
   }
 }
 
+// split-K accumulator seeded with the bias: out[m][oc] = shift[oc] -- when the epilogue is the bias alone (conv + bias
+// feeding a GroupNorm: the grid head), this replaces BOTH the zero fill before the atomics and the epilogue pass after
+__global__ void __launch_bounds__(256) seed_rows_kernel(float* __restrict__ out, const float* __restrict__ shift,
+                                                        int64_t total4, int oc4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x)
+    ((float4*)out)[i] = ((const float4*)shift)[i % oc4];
+}
+
 // KRSC [K][R][S][Cg] (K = groups*Kg)  ->  DGRAD operand [groups*Cg][R][S][Kg]
 // Per (group, tap) this is a Kg x Cg transpose.  32x32 tiles through LDS: the reads run along c and the writes along
 // k, both as contiguous 128-byte rows (a thread-per-destination-element version reads with a stride of R*S*Cg floats
@@ -1543,14 +1551,23 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
   Plan p = plan_igemm(a);
   a.split_k = p.split;
   a.atomic_out = a.split_k > 1;
+  bool seeded = false;
   if (a.atomic_out) {
-    if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
+    if (shift && !scale && !residual && !relu && (a.OCtot & 3) == 0 && (((uintptr_t)shift | (uintptr_t)y) & 15) == 0) {
+      const int64_t total4 = (int64_t)a.M * a.OCtot / 4;
+      const int64_t b = (total4 + 255) / 256;
+      hipLaunchKernelGGL(seed_rows_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, y, shift, total4,
+                         a.OCtot / 4);
+      seeded = true;
+    } else if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) {
+      return CPM_ELAUNCH;
+    }
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = launch_igemm(a, p, s, 0);
   if (rc != CPM_OK) return rc;
-  if (a.atomic_out && (scale || shift || residual || relu)) {
+  if (a.atomic_out && !seeded && (scale || shift || residual || relu)) {
     const int64_t total = (int64_t)a.M * a.OCtot;
     int64_t b = (total + 255) / 256;
     hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, y, scale, shift,
