@@ -88,9 +88,20 @@ __device__ void find_bin(const int* hist, int* tot, int want, int* out_bin, int*
   }
 }
 
-__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(const float* __restrict__ scores, int n, int k,
-                                                                 float* __restrict__ out_scores,
-                                                                 int64_t* __restrict__ out_idx) {
+constexpr int TOPK_LEVELS = 8;
+// blockIdx.y picks the problem: the RPN selects on every FPN level, each a [rows][n_l] matrix of its own
+struct TopkLevels {
+  const float* scores[TOPK_LEVELS];
+  float* out_scores[TOPK_LEVELS];
+  int64_t* out_idx[TOPK_LEVELS];
+  int n[TOPK_LEVELS], k[TOPK_LEVELS];
+};
+
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv) {
+  const float* __restrict__ scores = lv.scores[blockIdx.y];
+  float* __restrict__ out_scores = lv.out_scores[blockIdx.y];
+  int64_t* __restrict__ out_idx = lv.out_idx[blockIdx.y];
+  const int n = lv.n[blockIdx.y], k = lv.k[blockIdx.y];
   __shared__ int hist[256 * COPIES];
   __shared__ int tot[256];
   __shared__ unsigned long long sel[TOPK_MAX];
@@ -201,7 +212,25 @@ CPM_EXPORT int cpm_topk_rows(const float* scores, int rows, int n, int k, float*
   CPM_REQUIRE((int64_t)rows * n < (1ll << 31), "too many elements");
   if (rows == 0) return CPM_OK;
   CPM_REQUIRE(scores && out_scores && out_idx, "null pointer");
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(TOPK_THREADS), 0, (hipStream_t)stream, scores, n, k,
-                     out_scores, out_idx);
+  TopkLevels lv = {};
+  lv.scores[0] = scores; lv.out_scores[0] = out_scores; lv.out_idx[0] = out_idx; lv.n[0] = n; lv.k[0] = k;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, 1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv);
   return cpm::check_launch("topk_rows");
+}
+
+CPM_EXPORT int cpm_topk_rows_multi(const float* const* scores, const int* n, const int* k, int levels, int rows,
+                                   float* const* out_scores, int64_t* const* out_idx, void* stream) {
+  CPM_REQUIRE(levels >= 1 && levels <= TOPK_LEVELS && rows >= 0, "1 <= levels <= 8");
+  CPM_REQUIRE(scores && n && k && out_scores && out_idx, "null pointer");
+  if (rows == 0) return CPM_OK;
+  TopkLevels lv = {};
+  for (int l = 0; l < levels; ++l) {
+    CPM_REQUIRE(n[l] > 0 && k[l] >= 1 && k[l] <= n[l] && k[l] <= TOPK_MAX, "k must be in [1, min(n, 2048)]");
+    CPM_REQUIRE((int64_t)rows * n[l] < (1ll << 31), "too many elements");
+    CPM_REQUIRE(scores[l] && out_scores[l] && out_idx[l], "null pointer");
+    lv.scores[l] = scores[l]; lv.out_scores[l] = out_scores[l]; lv.out_idx[l] = out_idx[l];
+    lv.n[l] = n[l]; lv.k[l] = k[l];
+  }
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, levels), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv);
+  return cpm::check_launch("topk_rows_multi");
 }

@@ -9,5 +9,5 @@ from .conv import conv2d, linear, conv_transpose2d, group_norm, stem_forward, ma
 from .pool_points_interp import pool_points_interp, PoolPointsInterp
 from .boxes import box_iou, box_voting, box_ml_voting
 from .deform_conv import deform_conv, cols_conv, DeformConv, DeformConvPack
-from .detect_glue import match_rois, grid_bce_loss, grid_decode, rpn_decode, topk_rows, rpn_loss, sample_pos_neg
+from .detect_glue import match_rois, grid_bce_loss, grid_decode, rpn_decode, topk_rows, topk_rows_multi, rpn_loss, sample_pos_neg
 from .image_prep import image_prep, resample_tables, value_table, resize_linear

@@ -155,6 +155,34 @@ def topk_rows(scores, k):
     return vals, idx
 
 
+def topk_rows_multi(score_list, ks):
+    """topk_rows for several [rows, n_l] matrices (same rows) in one launch (cpm_topk_rows_multi): the RPN's FPN levels.
+    Returns a list of (values, indices)."""
+    if not score_list or len(score_list) != len(ks) or len(ks) > 8:
+        raise RuntimeError("topk_rows_multi: 1..8 matrices with one k each")
+    H.require_gpu(*score_list)
+    rows = score_list[0].shape[0]
+    ss, outs = [], []
+    for s, k in zip(score_list, ks):
+        if s.dim() != 2 or s.dtype != torch.float32 or s.shape[0] != rows:
+            raise RuntimeError("topk_rows_multi: scores must be fp32 [rows, n] with the same rows")
+        if not 1 <= k <= min(s.shape[1], TOPK_MAX):
+            raise RuntimeError("topk_rows_multi: k must be in [1, min(n, %d)], got %d (n = %d)" % (TOPK_MAX, k, s.shape[1]))
+        s = s if s.is_contiguous() else s.contiguous()
+        ss.append(s)
+        outs.append((torch.empty((rows, k), dtype=torch.float32, device=s.device),
+                     torch.empty((rows, k), dtype=torch.int64, device=s.device)))
+    L = len(ss)
+    vp = ctypes.c_void_p * L
+    ip = ctypes.c_int * L
+    with H.guard(ss[0].device):
+        rc = H.lib().cpm_topk_rows_multi(vp(*[s.data_ptr() for s in ss]), ip(*[s.shape[1] for s in ss]),
+                                         ip(*[int(k) for k in ks]), L, rows, vp(*[o[0].data_ptr() for o in outs]),
+                                         vp(*[o[1].data_ptr() for o in outs]), H.stream())
+    H.check(rc, "topk_rows_multi")
+    return outs
+
+
 class _RPNLossFn(torch.autograd.Function):
     """(sum of BCE terms, sum of smooth-L1 terms) over the sampled anchors, gradients produced by the same launch."""
 

@@ -66,15 +66,20 @@ class RPNPostProcessor(torch.nn.Module):
         dev = objectness[0].device
         sizes = [per_img[0].size for per_img in anchors]
         seg_boxes, seg_scores, offsets, owner = [], [], [0], []
-        for lvl, (o, b) in enumerate(zip(objectness, box_regression)):
+        lvl_scores, lvl_k = [], []
+        for o in objectness:
             _, A, H, W = o.shape
-            scores = permute_and_flatten(o, N, A, 1, H, W).view(N, -1).sigmoid()
-            reg = permute_and_flatten(b, N, A, 4, H, W)
-            k = min(self.pre_nms_top_n, A * H * W)
-            if k <= ops.detect_glue.TOPK_MAX:
-                scores, idx = ops.topk_rows(scores, k)       # all images of the level in one launch
-            else:
-                scores, idx = scores.topk(k, dim=1, sorted=True)
+            lvl_scores.append(permute_and_flatten(o, N, A, 1, H, W).view(N, -1).sigmoid())
+            lvl_k.append(min(self.pre_nms_top_n, A * H * W))
+        if max(lvl_k) <= ops.detect_glue.TOPK_MAX and num_levels <= 8:
+            picked = ops.topk_rows_multi(lvl_scores, lvl_k)  # all images of all levels in one launch
+        else:
+            picked = [s.topk(k, dim=1, sorted=True) for s, k in zip(lvl_scores, lvl_k)]
+        for lvl, b in enumerate(box_regression):
+            _, A4, H, W = b.shape
+            reg = permute_and_flatten(b, N, A4 // 4, 4, H, W)
+            k = lvl_k[lvl]
+            scores, idx = picked[lvl]
             boxes = ops.rpn_decode(reg, idx, anchors[0][lvl].bbox, self.box_coder.weights,
                                    self.box_coder.bbox_xform_clip, sizes)
             seg_boxes.append(boxes.view(N * k, 4))

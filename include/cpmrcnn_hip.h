@@ -300,6 +300,11 @@ int cpm_rpn_loss(const float* logits, const float* reg, const float* anchors, co
  * descending order with their column indices (int64); equal values are ordered by ascending index (torch leaves
  * that order unspecified).  1 <= k <= min(n, 2048).  NaNs rank above every number, as in torch. */
 int cpm_topk_rows(const float* scores, int rows, int n, int k, float* out_scores, int64_t* out_idx, void* stream);
+/* The same for several matrices of `rows` rows each in ONE launch (the RPN's five FPN levels, inference.py:67-114 loops
+ * over them): HOST arrays of `levels` <= 8 device pointers / sizes; level l: scores[l] [rows][n[l]] -> out_scores[l],
+ * out_idx[l] [rows][k[l]]. */
+int cpm_topk_rows_multi(const float* const* scores, const int* n, const int* k, int levels, int rows,
+                        float* const* out_scores, int64_t* const* out_idx, void* stream);
 
 /* ---- fixed-size positive / negative sampling for the whole batch ---------------------------
  * Replaces BalancedPositiveNegativeSampler.__call__ (pet/rcnn/utils/balanced_positive_negative_sampler.py:27-67, called

@@ -358,6 +358,29 @@ def test_topk_rows_edge_cases():
         ops.topk_rows(torch.zeros(1, 50), 5)
 
 
+def test_topk_rows_multi_equals_per_level():
+    """All five FPN levels of the RPN selection in one launch (cpm_topk_rows_multi) == one cpm_topk_rows per level
+    == torch.topk values; also a single short level (k == n) and the argument checks."""
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(21)
+    sizes = [201600, 50400, 12600, 3150, 819]
+    ss = [torch.sigmoid(torch.randn(2, n, generator=g) * 0.05).cuda() for n in sizes]
+    ks = [min(2000, n) for n in sizes]
+    got = ops.topk_rows_multi(ss, ks)
+    for s, k, (v, i) in zip(ss, ks, got):
+        v1, i1 = ops.topk_rows(s, k)
+        assert torch.equal(v, v1) and torch.equal(i, i1)
+        assert torch.equal(v, s.topk(k, dim=1, sorted=True)[0])
+    (v, i), = ops.topk_rows_multi([ss[4]], [819])
+    assert torch.equal(v, ss[4].sort(dim=1, descending=True)[0])
+    with pytest.raises(RuntimeError):
+        ops.topk_rows_multi(ss, ks[:-1])
+    with pytest.raises(RuntimeError):
+        ops.topk_rows_multi([ss[0], ss[1][:1]], [10, 10])                # different row counts
+    with pytest.raises(RuntimeError):
+        ops.topk_rows_multi([ss[4]], [820])
+
+
 # ---- cpm_sample_pos_neg (BalancedPositiveNegativeSampler for the whole batch) ----------------------------------------
 
 def _sample_labels(rng, counts, dtype):
