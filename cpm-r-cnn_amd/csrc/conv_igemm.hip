@@ -1289,17 +1289,37 @@ __global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per
     // lane t < taps fetches the pixel's tap-t input value (one vector load for all 16 taps instead of 16 dependent
     // scalar loads); the values are then broadcast lane by lane
     const int tr = lane / a.S, ts = lane - tr * a.S;
-    for (int m = m_begin + wave; m < m_end; m += 4) {
-      const int ow = m % a.OW, t2 = m / a.OW;
-      const int oh = t2 % a.OH, n = t2 / a.OH;
-      const float dyv = live ? a.dy[(size_t)m * a.OCtot + g * a.OCg + ocl] : 0.f;
-      const int ih = oh * a.stride - a.pad + tr * a.dil, iw = ow * a.stride - a.pad + ts * a.dil;
-      float xt = 0.f;
-      if (lane < taps && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
-        xt = a.x[((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g];
+    // a wave takes runs of 4 consecutive pixels: the 8 loads of a run are issued together and one run AHEAD of the
+    // multiply-adds that consume them (one pixel per iteration left every iteration waiting out its own two
+    // loads); (n, oh, ow) is decoded once per run
+    float dyv[4], xt[4];
+    auto load_run = [&](int mb, float (&dv)[4], float (&xv)[4]) {
+      int ow = mb % a.OW, t2 = mb / a.OW;
+      int oh = t2 % a.OH, n = t2 / a.OH;
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t)                      // v_readlane (the index is a constant): __shfl is a ds_bpermute
-        acc[t] += dyv * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xt), t));
+      for (int j = 0; j < 4; ++j) {
+        const int m = mb + j;
+        const bool in = m < m_end;
+        dv[j] = (live && in) ? a.dy[(size_t)m * a.OCtot + g * a.OCg + ocl] : 0.f;
+        const int ih = oh * a.stride - a.pad + tr * a.dil, iw = ow * a.stride - a.pad + ts * a.dil;
+        xv[j] = 0.f;
+        if (in && lane < taps && (unsigned)ih < (unsigned)a.IH && (unsigned)iw < (unsigned)a.IW)
+          xv[j] = a.x[((size_t)(n * a.IH + ih) * a.IW + iw) * a.Ctot + g];
+        if (++ow == a.OW) { ow = 0; if (++oh == a.OH) { oh = 0; ++n; } }
+      }
+    };
+    int mb = m_begin + 4 * wave;
+    if (mb < m_end) load_run(mb, dyv, xt);
+    for (; mb < m_end; mb += 16) {
+      float ndy[4] = {0.f, 0.f, 0.f, 0.f}, nx[4] = {0.f, 0.f, 0.f, 0.f};
+      if (mb + 16 < m_end) load_run(mb + 16, ndy, nx);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t)                    // v_readlane (the index is a constant): __shfl is a ds_bpermute
+          acc[t] += dyv[j] * __int_as_float(__builtin_amdgcn_readlane(__float_as_int(xt[j]), t));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dyv[j] = ndy[j]; xt[j] = nx[j]; }
     }
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) red[wave][t][lane] = acc[t];
@@ -1753,7 +1773,10 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
       cpm::set_error("cpm_conv2d_backward_weight_bias: one input channel per group is not covered, use cpm_epilogue_backward");
       return CPM_EINVAL;
     }
-    const int ppb = 128;
+    // pixels per workgroup: ~2 workgroups per CU -- every workgroup ends with OCg * taps float atomics on the same
+    // few addresses, so fewer, longer workgroups (128 pixels each: 1215 of them for 88 RoIs) were atomics bound
+    int ppb = (int)(((int64_t)a.M * a.groups / (2 * num_cus()) + 63) / 64 * 64);
+    ppb = ppb < 128 ? 128 : (ppb > 2048 ? 2048 : ppb);
     dim3 grid((unsigned)cpm::cdiv(a.M, ppb), (unsigned)a.groups);
     hipLaunchKernelGGL((wgrad_cg1_kernel<16>), grid, dim3(256), 0, s, a, ppb);
     return cpm::check_launch("conv wgrad (one channel per group)");
