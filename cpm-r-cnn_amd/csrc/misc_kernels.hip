@@ -317,6 +317,114 @@ __global__ __launch_bounds__(256) void gn_bwd_kernel(const float* __restrict__ d
   }
 }
 
+// GroupNorm backward for SMALL groups (the grid head: GroupNorm(36, 576) on 7x7 maps = 49 pixels x 16 channels): one
+// WAVEFRONT per (sample, group) instead of a 256-thread workgroup -- a lane owns up to TRIPS float4 (pixel, channel
+// quad) slots, keeps the gated gradient and the normalised input of all of them in registers between the moment
+// pass and the output pass (the workgroup version re-read dy, y and x), and the two moments are wave reductions (DPP
+// row prefix + four v_readlane) with no barrier.  A lane meets the same channel quad on every trip (the quads per
+// pixel divide 64), so the gamma / beta partials stay in registers and are folded once through a private LDS slab.
+__device__ __forceinline__ float wave_total(float v) {
+  int x = __float_as_int(v);
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true)));
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true)));
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true)));
+  x = __float_as_int(__int_as_float(x) + __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true)));
+  return (__int_as_float(__builtin_amdgcn_readlane(x, 15)) + __int_as_float(__builtin_amdgcn_readlane(x, 31))) +
+         (__int_as_float(__builtin_amdgcn_readlane(x, 47)) + __int_as_float(__builtin_amdgcn_readlane(x, 63)));
+}
+
+// THREADS = 64: one wavefront per (sample, group), four of them per workgroup; THREADS = 256: the whole workgroup on one
+// (sample, group) for the wider groups (GroupNorm(9, 576) on the 14x14 deconvolution output: 196 pixels x 64 channels
+// = 13 float4 per thread), same register-resident single pass, moments folded across the four waves through LDS.
+template <int THREADS, int TRIPS>
+__global__ __launch_bounds__(256) void gn_bwd_wave_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ y,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ mean_in,
+                                                          const float* __restrict__ rstd_in, int N, int HW, int C,
+                                                          int G, int qshift, int relu, float* __restrict__ dx,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ float part[256][9];                        // [thread][4 dgamma + 4 dbeta], padded
+  __shared__ float red2[2][4];
+  constexpr bool WAVE = THREADS == 64;
+  const int wave = threadIdx.x >> 6;
+  const int lane = WAVE ? (threadIdx.x & 63) : threadIdx.x;      // index inside the job's thread set
+  const int job = WAVE ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (job >= N * G) return;                             // WAVE: no block-wide barrier below; else block-uniform
+  const int n = job / G, g = job - n * G;
+  const int Cg = C / G, Q = 1 << qshift, slots = HW << qshift;
+  const int quad = lane & (Q - 1);
+  const size_t base = (size_t)n * HW * C + (size_t)g * Cg + 4 * quad;
+  const float mean = mean_in[job], rstd = rstd_in[job];
+  const float4 gm = *(const float4*)(gamma + g * Cg + 4 * quad);
+  float4 go[TRIPS], xh[TRIPS];
+  float s1 = 0.f, s2 = 0.f;
+  float4 pg = make_float4(0.f, 0.f, 0.f, 0.f), pb = pg;
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int slot = lane + THREADS * t;
+    go[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xh[t] = go[t];
+    if (slot < slots) {
+      const size_t off = base + (size_t)(slot >> qshift) * C;
+      float4 d = *(const float4*)(dy + off);
+      const float4 xv = *(const float4*)(x + off);
+      if (relu) {
+        const float4 yv = *(const float4*)(y + off);
+        d.x = yv.x > 0.f ? d.x : 0.f; d.y = yv.y > 0.f ? d.y : 0.f;
+        d.z = yv.z > 0.f ? d.z : 0.f; d.w = yv.w > 0.f ? d.w : 0.f;
+      }
+      const float4 h = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd,
+                                   (xv.w - mean) * rstd);
+      go[t] = d; xh[t] = h;
+      const float a0 = d.x * gm.x, a1 = d.y * gm.y, a2 = d.z * gm.z, a3 = d.w * gm.w;
+      s1 += (a0 + a1) + (a2 + a3);
+      s2 += (a0 * h.x + a1 * h.y) + (a2 * h.z + a3 * h.w);
+      pg.x += d.x * h.x; pg.y += d.y * h.y; pg.z += d.z * h.z; pg.w += d.w * h.w;
+      pb.x += d.x; pb.y += d.y; pb.z += d.z; pb.w += d.w;
+    }
+  }
+  const float inv = 1.f / (float)(HW * Cg);
+  float m1 = wave_total(s1), m2 = wave_total(s2);
+  if (!WAVE) {
+    if ((threadIdx.x & 63) == 0) { red2[0][wave] = m1; red2[1][wave] = m2; }
+    __syncthreads();
+    m1 = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
+    m2 = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
+  }
+  m1 *= inv; m2 *= inv;
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int slot = lane + THREADS * t;
+    if (slot < slots) {
+      const float4 d = go[t], h = xh[t];
+      float4 o;
+      o.x = rstd * (d.x * gm.x - m1 - h.x * m2); o.y = rstd * (d.y * gm.y - m1 - h.y * m2);
+      o.z = rstd * (d.z * gm.z - m1 - h.z * m2); o.w = rstd * (d.w * gm.w - m1 - h.w * m2);
+      *(float4*)(dx + base + (size_t)(slot >> qshift) * C) = o;
+    }
+  }
+  if (!dgamma && !dbeta) return;
+  float* pr = &part[threadIdx.x][0];
+  pr[0] = pg.x; pr[1] = pg.y; pr[2] = pg.z; pr[3] = pg.w;
+  pr[4] = pb.x; pr[5] = pb.y; pr[6] = pb.z; pr[7] = pb.w;
+  if (WAVE) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+  if (lane < Cg) {                                      // channel `lane` of the group: quad lane >> 2, component lane & 3
+    const int q = lane >> 2, k = lane & 3;
+    const int first = WAVE ? wave * 64 : 0;
+    float a = 0.f, b = 0.f;
+    for (int l = q; l < THREADS; l += Q) { a += part[first + l][k]; b += part[first + l][4 + k]; }
+    if (dgamma) atomicAdd(dgamma + g * Cg + lane, a);
+    if (dbeta) atomicAdd(dbeta + g * Cg + lane, b);
+  }
+}
+
 // ---- FPN top-down backward -----------------------------------------------------------------------------------
 __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, int Q, int C, int accumulate,
                                     float* __restrict__ dtop) {
@@ -467,6 +575,24 @@ CPM_EXPORT int cpm_groupnorm_backward(const float* dy, const float* x, const flo
   CPM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C / G <= 256, "bad shape");
   if (N == 0) return CPM_OK;
   CPM_REQUIRE(dy && x && gamma && mean && rstd && dx && (!relu || y), "null pointer");
+  const int Cg = C / G, Q = Cg / 4;
+  const bool pow2 = Q > 0 && (Q & (Q - 1)) == 0;
+  if ((Cg & 3) == 0 && (C & 3) == 0 && pow2 && Q <= 16 && (int64_t)HW * Q <= 64 * 4 && (int64_t)N * G < (1ll << 30) &&
+      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0)) {
+    int qshift = 0;
+    while ((1 << qshift) < Q) ++qshift;
+    hipLaunchKernelGGL((gn_bwd_wave_kernel<64, 4>), dim3((unsigned)(((int64_t)N * G + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, dy, x, y, gamma, mean, rstd, N, HW, C, G, qshift, relu, dx, dgamma, dbeta);
+    return cpm::check_launch("groupnorm_backward (wave per group)");
+  }
+  if ((Cg & 3) == 0 && (C & 3) == 0 && pow2 && Q <= 16 && (int64_t)HW * Q <= 256 * 13 && (int64_t)N * G < (1ll << 30) &&
+      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0)) {
+    int qshift = 0;
+    while ((1 << qshift) < Q) ++qshift;
+    hipLaunchKernelGGL((gn_bwd_wave_kernel<256, 13>), dim3((unsigned)((int64_t)N * G)), dim3(256), 0,
+                       (hipStream_t)stream, dy, x, y, gamma, mean, rstd, N, HW, C, G, qshift, relu, dx, dgamma, dbeta);
+    return cpm::check_launch("groupnorm_backward (workgroup per group, single pass)");
+  }
   hipLaunchKernelGGL(gn_bwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, dy, x, y, gamma, mean, rstd, HW, C,
                      G, relu, dx, dgamma, dbeta);
   return cpm::check_launch("groupnorm_backward");
