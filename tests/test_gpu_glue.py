@@ -136,7 +136,7 @@ def test_fused_cascade_equals_per_image_path():
             props, _ = m.RPN(to_image_list(images.cuda()), feats, targets)
             props, _ = head._forward_train_cls(feats, props, targets)
         outs = []
-        for fused in (True, False):
+        for fused in (True, True, False):                           # the fused path twice: its run-to-run noise
             head.fused_glue = fused
             for f in feats:
                 f.grad = None
@@ -148,7 +148,7 @@ def test_fused_cascade_equals_per_image_path():
             outs.append((result, {k: float(v.detach()) for k, v in losses.items()}, dict(head.last_counts),
                          [f.grad.clone() for f in feats[:4]]))
         head.fused_glue = True
-        (ra, la, ca, ga), (rb, lb, cb, gb) = outs
+        (ra, la, ca, ga), (_, _, _, gn), (rb, lb, cb, gb) = outs
         assert ca == cb and set(la) == set(lb) == {"loss_grid_1", "loss_grid_2", "loss_grid_3", "loss_iou_3"}
         for k in la:
             assert abs(la[k] - lb[k]) <= 1e-5 * abs(lb[k]) + 1e-7, (k, la[k], lb[k])
@@ -157,11 +157,14 @@ def test_fused_cascade_equals_per_image_path():
             np.testing.assert_allclose(a.bbox.cpu().numpy(), b.bbox.cpu().numpy(), rtol=1e-5, atol=1e-3)
             for f in a.fields():
                 assert torch.equal(a.get_field(f).float(), b.get_field(f).float()), f
-        # split-K atomics of the 8-conv stacks make the two runs differ in the last bits; a level that only a few RoIs
-        # map to has a gradient 1000x smaller than the others, so the bound is taken against the largest level
+        # float atomics (split-K, GroupNorm parameter sums, RoIAlign) make even two IDENTICAL runs differ -- a few 1e-3
+        # of a level's maximum after the 8-conv GroupNorm stacks amplify the last bits, more on a level that only a
+        # few RoIs map to (gradient 1000x smaller than the others).  The two formulations must agree to within that
+        # measured noise: 3x the difference of two fused runs, plus 2e-3 of the level (at least 1 % of the largest)
         scale = max(float(b.abs().max()) for b in gb)
-        for a, b in zip(ga, gb):
-            assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 1e-2 * scale) + 1e-9
+        for a, a2, b in zip(ga, gn, gb):
+            noise = float((a - a2).abs().max())
+            assert float((a - b).abs().max()) <= 3 * noise + 2e-3 * max(float(b.abs().max()), 1e-2 * scale) + 1e-9
     finally:
         config.reset_cfg()
 
