@@ -365,7 +365,16 @@ def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, 
 def linear(x, w, bias=None, relu=False):
     """nn.Linear as a 1x1 conv on a 1x1 image: x [R, C], w [K, C]."""
     r, c = x.shape
-    y = conv2d(x.reshape(r, c, 1, 1), w.reshape(w.shape[0], c, 1, 1), None, bias, None, relu=relu)
+    w4 = w.reshape(w.shape[0], c, 1, 1)
+    sink = getattr(w, "_cpm_grad_sink", None)
+    if sink is not None and w4.data_ptr() == w.data_ptr() and sink.is_contiguous():
+        # the view stands in for the parameter: the weight-gradient kernel accumulates into the parameter's slice of
+        # the flat gradient buffer and the data-parallel reducer hears about it (see _ConvFn.forward)
+        w4._cpm_grad_sink = sink.view(w4.shape)
+        ready = getattr(w, "_cpm_grad_ready", None)
+        if ready is not None:
+            w4._cpm_grad_ready = ready
+    y = conv2d(x.reshape(r, c, 1, 1), w4, None, bias, None, relu=relu)
     return y.reshape(r, w.shape[0])
 
 
@@ -386,7 +395,15 @@ class _ConvTransposeFn(Function):
     def forward(ctx, x, w, bias, stride, pad, groups, relu):
         H.require_gpu(x, w, bias)
         x = nhwc(x)
+        w_in = w
         w = _wmem(w)
+        # parameters owned by the flat optimizer: gradients are accumulated in place (see _ConvFn.forward)
+        sink = getattr(w_in, "_cpm_grad_sink", None)
+        ctx.wparam = w_in if (ctx.needs_input_grad[1] and w is w_in and sink is not None and sink.data_ptr() != 0
+                              and sink.stride() == w.stride()) else None
+        if ctx.wparam is not None:
+            w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+        ctx.bparam = _sink_of(bias, bias is not None and ctx.needs_input_grad[2])
         n, cin, p, q = x.shape
         _, cog, r, s = w.shape
         cout = cog * groups
@@ -414,11 +431,23 @@ class _ConvTransposeFn(Function):
         dy = nhwc(dy)
         dbias = None
         if relu or (has_bias and need_b):
-            dpre, _, dbias = epilogue_backward(dy, y, None, relu, want_dpre=relu, want_dshift=has_bias and need_b)
+            bp = ctx.bparam
+            dpre, _, dbias = epilogue_backward(dy, y, None, relu, want_dpre=relu, want_dshift=has_bias and need_b,
+                                               dshift_out=bp._cpm_grad_sink if bp is not None else None)
+            if bp is not None:
+                dbias = None                    # accumulated in place
+                _sink_done(bp)
             dy = dpre if dpre is not None else dy
         # the transposed conv's data gradient is the plain conv; its weight gradient swaps the operands
         dx = conv2d_forward(dy, w, None, None, None, 0, False, stride, pad, 1, groups) if need_x else None
-        dw = conv2d_backward_weight(dy, x, w, stride, pad, 1, groups) if need_w else None
+        dw = None
+        if need_w:
+            wp = ctx.wparam
+            if wp is not None:
+                conv2d_backward_weight(dy, x, w, stride, pad, 1, groups, out=wp._cpm_grad_sink)
+                _sink_done(wp)
+            else:
+                dw = conv2d_backward_weight(dy, x, w, stride, pad, 1, groups)
         return dx, dw, dbias, None, None, None, None
 
 

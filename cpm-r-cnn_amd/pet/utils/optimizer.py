@@ -75,8 +75,8 @@ class FlatSGD(torch.optim.Optimizer):
         dst.copy_(p.data)
         p.data = dst
         p.grad = self._view(self.flat_grad, p, off, n)
-        if p.dim() == 4 or p.dim() == 1:
-            # conv weights, biases and GroupNorm affine parameters: the HIP backward kernels accumulate straight into
+        if p.dim() in (1, 2, 4):
+            # conv / Linear weights, biases and GroupNorm affine parameters: the HIP backward kernels accumulate straight into
             # this slice of the flat gradient buffer (no temporary, no autograd add)
             p._cpm_grad_sink = p.grad
             p._cpm_uses = 0

@@ -200,6 +200,10 @@ def test_flat_sgd_matches_torch_sgd():
             torch.testing.assert_close(p.detach().cpu().contiguous(), r.detach(), rtol=1e-5, atol=1e-6)
 
 
+def G_of(m):
+    return m.Grid_Cascade_RCNN
+
+
 def test_flat_optimizer_grad_sink_equals_autograd(model, golden_model):
     """With the flat optimizer attached, conv weight gradients are accumulated in place by the wgrad kernel
     (bypassing autograd's accumulation); they must equal the plain autograd path."""
@@ -216,7 +220,9 @@ def test_flat_optimizer_grad_sink_equals_autograd(model, golden_model):
         xg, _ = G.Head_grid_0(p, boxes)
         hm, _ = G.Output_grid_0(xg, None)
         lo, br = model.RPN.head(p)
-        loss = (hm["unfused"] ** 2).mean() + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)
+        logits = G.Output_cls(G.Head_cls(p, boxes))          # fc6 (full-window conv), fc7 and cls_score (Linear)
+        loss = (hm["unfused"] ** 2).mean() + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br) + \
+            (logits ** 2).mean()
         loss.backward()
 
     model.train()
@@ -235,6 +241,9 @@ def test_flat_optimizer_grad_sink_equals_autograd(model, golden_model):
             # order; typical difference 1e-6, rare outliers up to a few 1e-4 -- the bar is north_star's 1e-3
             assert err < 1e-3, (k, err)
     assert model.RPN.head.conv.weight._cpm_uses == 0      # 5 uses (one per FPN level) counted up and back down
+    # Linear weights and the transposed convs of Grid_output take the in-place path too
+    assert hasattr(G_of(model).Head_cls.fc7.weight, "_cpm_grad_sink")
+    assert hasattr(G_of(model).Output_grid_0.deconv_1.weight, "_cpm_grad_sink")
 
 
 def test_dgrad_weight_images_follow_the_optimizer():
