@@ -353,8 +353,9 @@ class _ConvFn(Function):
 def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, groups=1, relu=False, res_mode=0,
            sole_consumer=False):
     tag = None
-    if sole_consumer and relu and residual is None and not (shift is not None and shift.requires_grad) \
-            and torch.is_grad_enabled():
+    # (a trainable bias is fine: once the consumer has applied the gate, this layer's backward takes dy as the
+    # pre-activation gradient and the bias gradient rides on the weight-gradient launch)
+    if sole_consumer and relu and residual is None and torch.is_grad_enabled():
         tag = {"scale": scale, "applied": False}
     y = _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode, tag)
     if tag is not None:
@@ -362,8 +363,17 @@ def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, 
     return y
 
 
-def linear(x, w, bias=None, relu=False):
-    """nn.Linear as a 1x1 conv on a 1x1 image: x [R, C], w [K, C]."""
+def carry_tag(src, dst):
+    """reshape / view make a new tensor object: hand the sole-consumer tag (conv2d) on to it."""
+    tag = getattr(src, "_cpm_epi", None)
+    if tag is not None:
+        dst._cpm_epi = tag
+    return dst
+
+
+def linear(x, w, bias=None, relu=False, sole_consumer=False):
+    """nn.Linear as a 1x1 conv on a 1x1 image: x [R, C], w [K, C].  sole_consumer: see conv2d (the caller promises that
+    the result feeds exactly one further conv2d / linear of this package)."""
     r, c = x.shape
     w4 = w.reshape(w.shape[0], c, 1, 1)
     sink = getattr(w, "_cpm_grad_sink", None)
@@ -374,8 +384,8 @@ def linear(x, w, bias=None, relu=False):
         ready = getattr(w, "_cpm_grad_ready", None)
         if ready is not None:
             w4._cpm_grad_ready = ready
-    y = conv2d(x.reshape(r, c, 1, 1), w4, None, bias, None, relu=relu)
-    return y.reshape(r, w.shape[0])
+    y = conv2d(carry_tag(x, x.reshape(r, c, 1, 1)), w4, None, bias, None, relu=relu, sole_consumer=sole_consumer)
+    return carry_tag(y, y.reshape(r, w.shape[0]))
 
 
 def upsample2x_add_backward(dy, top_shape):

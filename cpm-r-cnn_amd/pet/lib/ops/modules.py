@@ -60,7 +60,9 @@ class Linear(nn.Linear):
         if v is not None and v.dim() == 2 and v.shape[1] == self.in_features:
             state_dict[key] = v.reshape((v.shape[0],) + self.window)
 
-    def forward(self, x, relu=False):
+    def forward(self, x, relu=False, sole_consumer=False):
+        """sole_consumer: the caller promises that the (ReLU) result feeds exactly one further Linear / conv of this
+        package, whose data-gradient epilogue then applies this layer's ReLU gate (F.conv2d)."""
         if x.dim() == 4:
             # flatten of an NHWC feature map: run as a full-window conv so no NCHW repack of x is needed
             n, c, h, w = x.shape
@@ -69,10 +71,10 @@ class Linear(nn.Linear):
                 w4 = self.weight
             else:
                 w4 = self.weight.view(self.out_features, c, h, w)   # reference column order c,h,w; repacked per call
-            y = F.conv2d(x, w4, None, self.bias, None, 1, 0, 1, 1, relu, 0)
-            return y.reshape(n, self.out_features)
+            y = F.conv2d(x, w4, None, self.bias, None, 1, 0, 1, 1, relu, 0, sole_consumer)
+            return F.carry_tag(y, y.reshape(n, self.out_features))
         w2 = self.weight if self.window is None else self.weight.reshape(self.out_features, self.in_features)
-        return F.linear(x, w2, self.bias, relu)
+        return F.linear(x, w2, self.bias, relu, sole_consumer)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):

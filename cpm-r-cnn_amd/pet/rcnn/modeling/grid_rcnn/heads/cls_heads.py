@@ -26,5 +26,7 @@ class roi_cls_head(nn.Module):
 
     def forward(self, x, proposals):
         x = self.pooler(x, proposals)                 # [R, C, 7, 7], NHWC in memory
-        x = self.fc6(x, relu=True)                    # flatten folded into the full-window conv
-        return self.fc7(x, relu=True)
+        # fc6's result feeds fc7 alone, fc7's result the one Linear of Cls_output (outputs.py): their ReLU gates are
+        # applied by those consumers' data-gradient epilogues instead of a pass of their own
+        x = self.fc6(x, relu=True, sole_consumer=True)              # flatten folded into the full-window conv
+        return self.fc7(x, relu=True, sole_consumer=True)

@@ -45,8 +45,8 @@ class Grid_output(nn.Module):
         heat = self.deconv_2(x1)
         iou_logits = None
         if self.has_iou:
-            t = self.iou_fc1(x, relu=True)
-            t = self.iou_fc2(t, relu=True)
+            t = self.iou_fc1(x, relu=True, sole_consumer=True)
+            t = self.iou_fc2(t, relu=True, sole_consumer=True)
             iou_logits = self.iou_pred(t)
         return dict(fused=None, unfused=heat), iou_logits
 
