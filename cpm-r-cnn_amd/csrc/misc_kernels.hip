@@ -425,6 +425,74 @@ __global__ __launch_bounds__(256) void gn_bwd_wave_kernel(const float* __restric
   }
 }
 
+// Forward with the same ownership (see gn_bwd_wave_kernel): x is read ONCE; mean and the centred second moment are
+// taken from the register copy (the two-pass formula of gn_fwd_kernel, without its two extra reads).
+template <int THREADS, int TRIPS>
+__global__ __launch_bounds__(256) void gn_fwd_wave_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int N, int HW, int C, int G,
+                                                          int qshift, float eps, int relu, float* __restrict__ y,
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  __shared__ float red2[2][4];
+  constexpr bool WAVE = THREADS == 64;
+  const int wave = threadIdx.x >> 6;
+  const int lane = WAVE ? (threadIdx.x & 63) : threadIdx.x;
+  const int job = WAVE ? blockIdx.x * 4 + wave : blockIdx.x;
+  if (job >= N * G) return;                             // WAVE: no block-wide barrier below; else block-uniform
+  const int n = job / G, g = job - n * G;
+  const int Cg = C / G, Q = 1 << qshift, slots = HW << qshift;
+  const int quad = lane & (Q - 1);
+  const size_t base = (size_t)n * HW * C + (size_t)g * Cg + 4 * quad;
+  float4 xv[TRIPS];
+  float s = 0.f;
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int slot = lane + THREADS * t;
+    xv[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slot < slots) {
+      xv[t] = *(const float4*)(x + base + (size_t)(slot >> qshift) * C);
+      s += (xv[t].x + xv[t].y) + (xv[t].z + xv[t].w);
+    }
+  }
+  const float inv = 1.f / (float)(HW * Cg);
+  float tot = wave_total(s);
+  if (!WAVE) {
+    if ((threadIdx.x & 63) == 0) red2[0][wave] = tot;
+    __syncthreads();
+    tot = (red2[0][0] + red2[0][1]) + (red2[0][2] + red2[0][3]);
+  }
+  const float mean = tot * inv;
+  float v = 0.f;
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int slot = lane + THREADS * t;
+    if (slot < slots) {
+      const float a = xv[t].x - mean, b = xv[t].y - mean, c = xv[t].z - mean, d = xv[t].w - mean;
+      v += (a * a + b * b) + (c * c + d * d);
+    }
+  }
+  float vt = wave_total(v);
+  if (!WAVE) {
+    if ((threadIdx.x & 63) == 0) red2[1][wave] = vt;
+    __syncthreads();
+    vt = (red2[1][0] + red2[1][1]) + (red2[1][2] + red2[1][3]);
+  }
+  const float rstd = 1.f / sqrtf(vt * inv + eps);
+  if (lane == 0) { mean_out[job] = mean; rstd_out[job] = rstd; }
+  const float4 gm = *(const float4*)(gamma + g * Cg + 4 * quad);
+  const float4 bt = *(const float4*)(beta + g * Cg + 4 * quad);
+#pragma unroll
+  for (int t = 0; t < TRIPS; ++t) {
+    const int slot = lane + THREADS * t;
+    if (slot < slots) {
+      float4 o;
+      o.x = (xv[t].x - mean) * rstd * gm.x + bt.x; o.y = (xv[t].y - mean) * rstd * gm.y + bt.y;
+      o.z = (xv[t].z - mean) * rstd * gm.z + bt.z; o.w = (xv[t].w - mean) * rstd * gm.w + bt.w;
+      if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+      *(float4*)(y + base + (size_t)(slot >> qshift) * C) = o;
+    }
+  }
+}
+
 // ---- FPN top-down backward -----------------------------------------------------------------------------------
 __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, int Q, int C, int accumulate,
                                     float* __restrict__ dtop) {
@@ -564,6 +632,22 @@ CPM_EXPORT int cpm_groupnorm_forward(const float* x, const float* gamma, const f
   CPM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "bad shape");
   if (N == 0) return CPM_OK;
   CPM_REQUIRE(x && gamma && beta && y && mean && rstd, "null pointer");
+  const int Cg = C / G, Q = Cg / 4;
+  const bool pow2 = Q > 0 && (Q & (Q - 1)) == 0;
+  const bool vec = (Cg & 3) == 0 && (C & 3) == 0 && pow2 && Q <= 64 && (int64_t)N * G < (1ll << 30) &&
+                   ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+  int qshift = 0;
+  while ((1 << qshift) < Q) ++qshift;
+  if (vec && (int64_t)HW * Q <= 64 * 4) {
+    hipLaunchKernelGGL((gn_fwd_wave_kernel<64, 4>), dim3((unsigned)(((int64_t)N * G + 3) / 4)), dim3(256), 0,
+                       (hipStream_t)stream, x, gamma, beta, N, HW, C, G, qshift, eps, relu, y, mean, rstd);
+    return cpm::check_launch("groupnorm_forward (wave per group)");
+  }
+  if (vec && (int64_t)HW * Q <= 256 * 13) {
+    hipLaunchKernelGGL((gn_fwd_wave_kernel<256, 13>), dim3((unsigned)((int64_t)N * G)), dim3(256), 0,
+                       (hipStream_t)stream, x, gamma, beta, N, HW, C, G, qshift, eps, relu, y, mean, rstd);
+    return cpm::check_launch("groupnorm_forward (workgroup per group, single pass)");
+  }
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, HW, C, G, eps, relu,
                      y, mean, rstd);
   return cpm::check_launch("groupnorm_forward");
