@@ -260,17 +260,27 @@ __global__ __launch_bounds__(64) void sweep_segments_small(const uint64_t* __res
 #pragma unroll
     for (int j = 0; j < SMALL_NB; ++j)
       if (j == blk) diag = w[j];
-    uint64_t cur = remv[blk];
+    const uint64_t cur = remv[blk];
     uint64_t kept = 0;
     uint64_t alive = (rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull)) & ~cur;
+    // Greedy resolution of the block in ROUNDS instead of one dependent step per kept box: a row that no still-alive
+    // earlier row suppresses is kept whatever happens to the others (its earlier suppressors are all dead, and a kept
+    // one would already have removed it); the rows those suppress are dead; drop both sets and repeat.  The lowest
+    // alive row always qualifies, so the loop ends; with few overlaps it takes 2-3 rounds of two wave OR-reductions
+    // where the sequential form took ~58 find-first-set / readlane steps.  diag holds bits of LATER rows only.
     while (alive) {
-      const int b = __builtin_amdgcn_readfirstlane(__builtin_ctzll(alive));      // wave-uniform -> v_readlane below
-      kept |= 1ull << b;
-      cur |= ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(diag >> 32), b) << 32) |
-             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)diag, b);
-      alive &= ~cur;
-      alive &= (b == 63) ? 0ull : ~((2ull << b) - 1ull);
-      if (topk > 0 && nkeep + __popcll(kept) >= topk) { done = true; break; }
+      const bool live = (alive >> lane) & 1ull;
+      const uint64_t hit = wave_or64(live ? diag : 0ull);          // rows some alive row suppresses
+      const uint64_t k = alive & ~hit;                              // ... the others are kept
+      const bool kl = (k >> lane) & 1ull;
+      const uint64_t dead = wave_or64(kl ? diag : 0ull);           // rows a kept row suppresses
+      kept |= k;
+      alive &= ~(k | dead);
+    }
+    if (topk > 0 && nkeep + __popcll(kept) >= topk) {               // keep the first (topk - nkeep) of them
+      int extra = nkeep + __popcll(kept) - topk;
+      while (extra-- > 0) kept &= ~(1ull << (63 - __builtin_clzll(kept)));
+      done = true;
     }
     const bool mine = (kept >> lane) & 1ull;
     if (mine) {
