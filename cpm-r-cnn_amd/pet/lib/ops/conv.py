@@ -251,7 +251,8 @@ class _ConvFn(Function):
         # data-parallel reducer is told when the last use of the step has been accumulated
         ctx.wparam = w_in if (ctx.needs_input_grad[1] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         if ctx.wparam is not None:
-            w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+            own = getattr(w_in, "_cpm_owner", w_in)     # a Linear's [K,C,1,1] view counts on the parameter itself
+            own._cpm_uses = getattr(own, "_cpm_uses", 0) + 1
         # the parameter itself (not a repacked copy) when `w` aliases it: key of the once-per-step dgrad image
         ctx.wsrc = w_in if (w is w_in and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         ctx.bparam = _sink_of(shift, shift is not None and ctx.needs_input_grad[3])
@@ -338,11 +339,7 @@ class _ConvFn(Function):
                     dshift = dbias
             if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
                 conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias)
-                wp._cpm_uses -= 1
-                if wp._cpm_uses == 0:
-                    ready = getattr(wp, "_cpm_grad_ready", None)
-                    if ready is not None:
-                        ready(wp)
+                _sink_done(getattr(wp, "_cpm_owner", wp))
             else:
                 dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, dbias=dbias)
             if fuse_bias and ctx.bparam is not None:
@@ -380,10 +377,10 @@ def linear(x, w, bias=None, relu=False, sole_consumer=False):
     if sink is not None and w4.data_ptr() == w.data_ptr() and sink.is_contiguous():
         # the view stands in for the parameter: the weight-gradient kernel accumulates into the parameter's slice of
         # the flat gradient buffer and the data-parallel reducer hears about it (see _ConvFn.forward)
+        # uses are counted on the PARAMETER (a fresh view per call would fire the reducer's ready hook once per use
+        # instead of once per step when a Linear is applied more than once)
         w4._cpm_grad_sink = sink.view(w4.shape)
-        ready = getattr(w, "_cpm_grad_ready", None)
-        if ready is not None:
-            w4._cpm_grad_ready = ready
+        w4._cpm_owner = w
     y = conv2d(carry_tag(x, x.reshape(r, c, 1, 1)), w4, None, bias, None, relu=relu, sole_consumer=sole_consumer)
     return carry_tag(y, y.reshape(r, w.shape[0]))
 

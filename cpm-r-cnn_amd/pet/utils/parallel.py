@@ -58,6 +58,7 @@ class FlatGradReducer(object):
 
     def _make_hook(self, ci):
         def hook(_):
+            assert self._pending[ci] > 0, "gradient-ready hook fired more often than chunk %d has tensors" % ci
             self._pending[ci] -= 1
             # chunks are reduced strictly in buffer order on every rank -- a collective must be issued in the same
             # order everywhere, and the order in which chunks BECOME ready may differ between ranks (a rank whose
@@ -90,6 +91,37 @@ class FlatGradReducer(object):
         else:
             for b, e, _ in self.chunks:
                 dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
+
+
+def broadcast_initial_state(model, optimizer, src=0):
+    """Make every rank start from rank `src`'s state -- what DistributedDataParallel's constructor does in the
+    reference (tools/rcnn/train_net.py:134-136: it broadcasts module parameters and buffers).  FPN / RPN / head weights
+    are randomly initialised per process (nn.init.* in FPN.py, rpn.py, outputs.py); without this each rank would apply
+    the averaged gradient to different weights.  ONE broadcast covers every trainable tensor (the flat parameter
+    buffer), one the momentum buffer; frozen parameters and buffers (frozen stem / layer1, AffineChannel2d) follow
+    tensor by tensor -- they are few and small."""
+    if world() == 1:
+        return
+    dist.broadcast(optimizer.flat_param, src=src)
+    dist.broadcast(optimizer.flat_mom, src=src)
+    steps = torch.tensor([optimizer._steps], dtype=torch.int64, device=optimizer.flat_param.device)
+    dist.broadcast(steps, src=src)
+    optimizer._steps = int(steps.item())
+    lo = optimizer.flat_param.data_ptr()
+    hi = lo + optimizer.flat_param.numel() * 4
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if lo <= t.data_ptr() < hi or t.numel() == 0:
+                continue
+            if t.is_contiguous():
+                dist.broadcast(t.data, src=src)
+            else:                                   # channels_last frozen conv weights: broadcast the bytes as they lie
+                buf = t.data.contiguous()
+                dist.broadcast(buf, src=src)
+                t.data.copy_(buf)
+    for p in optimizer._flat_order:                 # cached data-gradient weight images are stale after the broadcast
+        if hasattr(p, "_cpm_wt_version"):
+            p._cpm_wt_version = -1
 
 
 def reduce_losses(losses):

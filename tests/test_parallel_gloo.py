@@ -67,6 +67,64 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _bcast_worker(rank, world, port, q):
+    import sys
+    from conftest import PKG, ROOT
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pet.utils.optimizer import FlatSGD
+        from pet.utils.parallel import broadcast_initial_state
+        torch.manual_seed(1000 + 17 * rank)                     # every rank initialises DIFFERENT weights
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.Linear(13, 37))
+        net[0].weight.requires_grad_(False)                     # a frozen tensor outside the flat buffer
+        net[0].weight.data = net[0].weight.data.contiguous(memory_format=torch.channels_last)
+        named = [(k, p, 1 if "bias" in k else 0) for k, p in net.named_parameters() if p.requires_grad]
+        named.reverse()
+        opt = FlatSGD(named, [dict(weight_decay=1e-4, lr_scale=1), dict(weight_decay=0.0, lr_scale=2),
+                              dict(weight_decay=0.0, lr_scale=1)], 0.9)
+        opt.flat_mom.fill_(float(rank + 1))
+        opt._steps = 3 * (1 - rank)
+        before = [torch.zeros_like(opt.flat_param) for _ in range(world)]
+        dist.all_gather(before, opt.flat_param)
+        assert not torch.equal(before[0], before[1]), "the test needs different initial weights per rank"
+        broadcast_initial_state(net, opt, src=0)
+        for t in [opt.flat_param, opt.flat_mom, net[0].weight.data.contiguous(), net[1].running_var,
+                  net[1].running_mean]:
+            got = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(got, t.contiguous())
+            assert torch.equal(got[0], got[1])
+        assert torch.equal(opt.flat_param, before[0]) and opt._steps == 3
+        assert float(opt.flat_mom[0]) == 1.0
+        # parameters still alias the flat buffer after the broadcast
+        for (_, p, _), b in zip(named, opt.seg_begin.tolist()):
+            assert p.data_ptr() == opt.flat_param.data_ptr() + 4 * b
+        q.put((rank, "ok"))
+    except Exception as e:
+        q.put((rank, "FAIL %r" % (e,)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_initial_state_world2():
+    """ranks that initialise their heads unseeded must hold rank 0's weights before the first step
+    (the reference gets this from DistributedDataParallel's constructor, tools/rcnn/train_net.py:134-136)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
 def test_flat_reducer_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

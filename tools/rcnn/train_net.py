@@ -29,7 +29,7 @@ from pet.utils.checkpointer import CheckPointer  # noqa: E402
 from pet.utils.lr_scheduler import LearningRateScheduler  # noqa: E402
 from pet.utils.net import convert_bn2affine_model, mismatch_params_filter  # noqa: E402
 from pet.utils.optimizer import Optimizer  # noqa: E402
-from pet.utils.parallel import FlatGradReducer, reduce_losses  # noqa: E402
+from pet.utils.parallel import FlatGradReducer, broadcast_initial_state, reduce_losses  # noqa: E402
 
 log = logging.getLogger("train_net")
 
@@ -101,6 +101,10 @@ def main(argv=None):
     optimizer = checkpointer.load_optimizer(Optimizer(model, cfg.SOLVER, local_rank=rank).build())
     log.info("The mismatch keys: %s", mismatch_params_filter(sorted(checkpointer.mismatch_keys)))
     scheduler = checkpointer.load_scheduler(LearningRateScheduler(optimizer, cfg.SOLVER, start_iter=0, local_rank=rank))
+    if distributed:
+        # the reference's DistributedDataParallel broadcasts rank 0's parameters and buffers when it wraps the model
+        # (train_net.py:134-136); the flat reducer replaces DDP, so the broadcast is explicit here
+        broadcast_initial_state(model, optimizer, src=0)
     reducer = FlatGradReducer(optimizer)
     datasets = build_dataset(cfg.TRAIN.DATASETS, is_train=True, local_rank=rank)
     loader = make_train_data_loader(datasets, is_distributed=distributed, start_iter=scheduler.iteration)
