@@ -240,6 +240,101 @@ def box_ml_voting(top_boxes, top_scores, top_labels, all_boxes, all_scores, all_
     return b, s, top_labels
 
 
+# ---- deformable convolution v1: the reference's caller-owned-buffer binding -----------------------------------
+# vision.cpp:38-40 binds deform_conv_forward / deform_conv_backward_input / deform_conv_backward_filter
+# (csrc/Deformable/deform_conv.h:115-259); the reference's Python calls them at pet/lib/ops/deform_conv.py:53-71,
+# 94-112 and 117-136 with output / gradient tensors it allocated itself and two scratch tensors ("columns", "ones").
+# Same argument order and in-place contract here.  The engine differs (pixel-major sampled columns + ONE grouped
+# 1x1 MFMA contraction for the whole batch), so `columns` / `ones` are left untouched and `im2col_step` only has to
+# divide the batch as the reference demands.
+def _deform_args(input, offset, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group, deformable_group,
+                 im2col_step, what):
+    from .deform_conv import _check_offset, _geom
+    H.require_gpu(input, offset, weight)
+    if input.dim() != 4 or offset.dim() != 4 or weight.dim() != 4:
+        raise RuntimeError("%s: input, offset and weight must be 4-D" % what)
+    if weight.size(3) != kW or weight.size(2) != kH:
+        raise RuntimeError("%s: kernel size %dx%d does not match the weight %s" % (what, kH, kW, tuple(weight.shape)))
+    if dW != dH or padW != padH or dilationW != dilationH:
+        raise RuntimeError("%s: only square stride / padding / dilation are built" % what)
+    if im2col_step <= 0 or input.size(0) % im2col_step != 0:
+        raise RuntimeError("%s: im2col step must divide batchsize" % what)
+    geom = _geom(input.shape, weight.shape, dW, padW, dilationW, group, deformable_group)
+    _check_offset(offset, geom)
+    return geom
+
+
+def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW, dH, padW, padH, dilationW,
+                        dilationH, group, deformable_group, im2col_step):
+    """deform_conv.h:115-160: writes `output` [N,K,P,Q] in place, returns 1."""
+    from . import conv as F
+    from .deform_conv import _w1x1, sample_columns
+    geom = _deform_args(input, offset, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                        deformable_group, im2col_step, "deform_conv_forward")
+    n, p, q = geom[0], geom[11], geom[12]
+    if tuple(output.shape) != (n, weight.size(0), p, q):
+        raise RuntimeError("deform_conv_forward: output must be [%d, %d, %d, %d]" % (n, weight.size(0), p, q))
+    H.require_gpu(output)
+    if output.numel() == 0:
+        return 1
+    cols = sample_columns(F.nhwc(input), F.nhwc(offset), geom)
+    y = F.conv2d_forward(cols, _w1x1(F._wmem(weight)), None, None, None, 0, False, 1, 0, 1, int(group))
+    output.copy_(y)
+    return 1
+
+
+def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset, weight, columns, kW, kH, dW, dH, padW,
+                               padH, dilationW, dilationH, group, deformable_group, im2col_step):
+    """deform_conv.h:162-210: writes `gradInput` (like input) and `gradOffset` (like offset) in place, returns 1."""
+    from . import conv as F
+    from .deform_conv import _w1x1
+    geom = _deform_args(input, offset, weight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                        deformable_group, im2col_step, "deform_conv_backward_input")
+    n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
+    H.require_gpu(gradOutput, gradInput, gradOffset)
+    if tuple(gradOutput.shape) != (n, weight.size(0), p, q):
+        raise RuntimeError("deform_conv_backward_input: gradOutput must be [%d, %d, %d, %d]" % (n, weight.size(0), p, q))
+    if tuple(gradInput.shape) != tuple(input.shape) or tuple(gradOffset.shape) != tuple(offset.shape):
+        raise RuntimeError("deform_conv_backward_input: gradInput / gradOffset must match input / offset")
+    if input.numel() == 0 or gradOutput.numel() == 0:
+        return 1
+    x, off = F.nhwc(input), F.nhwc(offset)
+    dcols = F.conv2d_backward_data(F.nhwc(gradOutput), _w1x1(F._wmem(weight)), (n, r * s * c, p, q), 1, 0, 1, groups)
+    dx = F.empty_nhwc((n, c, h, w), x).zero_()
+    doff = torch.empty_like(off)
+    with H.guard(x.device):
+        rc = H.lib().cpm_deform_col2im(H.ptr(dcols), H.ptr(off), *geom, H.ptr(dx), H.stream())
+        H.check(rc, "deform_col2im")
+        rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(off), *geom, H.ptr(doff), H.stream())
+        H.check(rc, "deform_coord_grad")
+    gradInput.copy_(dx)
+    gradOffset.copy_(doff)
+    return 1
+
+
+def deform_conv_backward_filter(input, offset, gradOutput, gradWeight, columns, ones, kW, kH, dW, dH, padW, padH,
+                                dilationW, dilationH, group, deformable_group, scale, im2col_step):
+    """deform_conv.h:212-259: gradWeight += scale * (columns(input, offset) (x) gradOutput), in place, returns 1."""
+    from . import conv as F
+    from .deform_conv import sample_columns
+    if tuple(gradWeight.shape[2:]) != (kH, kW):
+        raise RuntimeError("deform_conv_backward_filter: gradWeight does not match the kernel size")
+    geom = _deform_args(input, offset, gradWeight, kW, kH, dW, dH, padW, padH, dilationW, dilationH, group,
+                        deformable_group, im2col_step, "deform_conv_backward_filter")
+    n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
+    H.require_gpu(gradOutput, gradWeight)
+    k, cg = gradWeight.size(0), gradWeight.size(1)
+    if tuple(gradOutput.shape) != (n, k, p, q):
+        raise RuntimeError("deform_conv_backward_filter: gradOutput must be [%d, %d, %d, %d]" % (n, k, p, q))
+    if input.numel() == 0 or gradOutput.numel() == 0:
+        return 1
+    cols = sample_columns(F.nhwc(input), F.nhwc(offset), geom)
+    w1_like = torch.empty((k, r * s * cg, 1, 1), dtype=torch.float32, device=input.device)
+    dw1 = F.conv2d_backward_weight(cols, F.nhwc(gradOutput), w1_like, 1, 0, 1, groups)       # [K, (r,s,c), 1, 1]
+    gradWeight.add_(dw1.view(k, r, s, cg).permute(0, 3, 1, 2), alpha=float(scale))
+    return 1
+
+
 def _not_on_hot_path(name):
     def fn(*a, **k):
         raise RuntimeError("_C.%s is outside the CPM R-CNN hot path and is not provided by cpm-r-cnn_amd" % name)
@@ -248,7 +343,7 @@ def _not_on_hot_path(name):
 
 
 # names bound by vision.cpp:21-47 that no BASELINE config reaches (out of scope)
-for _n in ("nms_rotated", "poly_nms", "box_iou_rotated",
+for _n in ("nms_rotated", "poly_nms", "box_iou_rotated", "modulated_deform_conv_forward", "modulated_deform_conv_backward",
            "roi_align_rotated_forward", "roi_align_rotated_backward", "roi_pool_forward", "roi_pool_backward",
            "sigmoid_focalloss_forward", "sigmoid_focalloss_backward"):
     globals()[_n] = _not_on_hot_path(_n)

@@ -1,4 +1,5 @@
-"""Operator surface of the hot path (counterpart of pet/lib/ops/__init__.py:1-30, hot-path names only)."""
+"""Operator surface (counterpart of pet/lib/ops/__init__.py:1-30): the hot-path operators over the HIP kernels, plus
+every other name of the reference package as an importable off-path placeholder (offpath.py)."""
 from .nms import nms, ml_nms, nms_segments, soft_nms, ml_soft_nms, soft_nms_segments
 from .roi_align import roi_align, ROIAlign
 from .pooler_fpn import roi_align_fpn
@@ -11,3 +12,4 @@ from .boxes import box_iou, box_voting, box_ml_voting
 from .deform_conv import deform_conv, cols_conv, DeformConv, DeformConvPack
 from .detect_glue import match_rois, grid_bce_loss, grid_decode, rpn_decode, topk_rows, topk_rows_multi, rpn_loss, sample_pos_neg
 from .image_prep import image_prep, resample_tables, value_table, resize_linear
+from .offpath import *  # noqa: F401,F403  (every remaining name of the reference's ops package imports)

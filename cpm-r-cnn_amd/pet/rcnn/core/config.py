@@ -112,6 +112,20 @@ _DEFAULTS = {
             "BG_IOU_THRESHOLD": [0.5, 0.6, 0.7], "GRID_NUM": (9, 9, 9), "RESIZE_ROI": False,
         },
     },
+    # Visualisation options (config.py:1143-1276).  Nothing on the hot path reads them; the subtree exists because the
+    # repo's YAMLs set VIS keys and a merge of an unknown key raises (as in the reference).
+    "VIS": {
+        "ENABLED": False, "VIS_TH": 0.9,
+        "SHOW_BOX": {"ENABLED": True, "COLOR_SCHEME": "green", "COLORMAP": "COCO81", "BORDER_THICK": 2},
+        "SHOW_CLASS": {"ENABLED": True, "COLOR": (218, 227, 218), "FONT_SCALE": 0.45},
+        "SHOW_SEGMS": {"ENABLED": True, "SHOW_MASK": True, "MASK_COLOR_FOLLOW_BOX": True, "MASK_ALPHA": 0.4,
+                       "SHOW_BORDER": True, "BORDER_COLOR": (255, 255, 255), "BORDER_THICK": 2},
+        "SHOW_KPS": {"ENABLED": True, "KPS_TH": 2, "KPS_COLOR_WITH_PARSING": (255, 255, 255), "KPS_ALPHA": 0.7,
+                     "LINK_THICK": 2, "CIRCLE_RADIUS": 3, "CIRCLE_THICK": -1},
+        "SHOW_PARSS": {"ENABLED": True, "COLORMAP": "CIHP20", "PARSING_ALPHA": 0.4, "SHOW_BORDER": True,
+                       "BORDER_COLOR": (255, 255, 255), "BORDER_THICK": 1},
+        "SHOW_UV": {"ENABLED": True, "SHOW_BORDER": True, "BORDER_THICK": 6, "GRID_THICK": 2, "LINES_NUM": 15},
+    },
 }
 
 __C = _tree(_DEFAULTS)

@@ -30,3 +30,15 @@ def oracle():
     from oracle import pyoracle
     pyoracle.lib()
     return pyoracle
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def conv_math(request):
+    """Runs a GPU test under both conv arithmetics (include/cpmrcnn_hip.h: CPM_MATH_*): the exact fp32 MFMA and the
+    3-term split-bf16 MFMA with fp32 accumulation -- the one bench.py's headline is measured in.  Whole-model parity
+    holds north_star's 1e-3 bar in BOTH."""
+    from pet.lib.ops import _hip
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math(request.param)
+    yield request.param
+    _hip.set_conv_math(prev)

@@ -398,6 +398,263 @@ def gen_cascade():
     print("cascade:", len(meta["state_dict"]), "keys;", {k: float(v) for k, v in out.items() if k.startswith("loss::")})
 
 
+def _cpm_cfg():
+    cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
+    cfg.DEVICE = "cpu"
+    return cfg
+
+
+def _det_image(rng, n, h, w):
+    img = rng.uniform(0, 255, (n, 3, h, w)) - np.array([102.9801, 115.9465, 122.7717]).reshape(1, 3, 1, 1)
+    return img.astype(np.float32)
+
+
+def _grad_stats(model, prefix=""):
+    grads = {}
+    for k, q in model.named_parameters():
+        if q.grad is not None and k.startswith(prefix):
+            g = q.grad.double()
+            grads[k] = [float(g.sum()), float(g.abs().sum()), float((g ** 2).sum())]
+    return grads
+
+
+def gen_model_big():
+    """A second structural golden at a size where error accumulation through the 50-layer backbone, the FPN and the
+    8-conv grid stacks is visible: 1 x 3 x 256 x 320 image, 64 RoIs spread over the four RoI levels.
+    Forward tensors are stored sub-sampled (channel and spatial strides) to keep the fixture small; gradients as
+    L1 / L2 statistics of all 196 trainable tensors plus strided samples of eleven of them."""
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    from pet.utils.data.structures.bounding_box import BoxList
+    _cpm_cfg()
+    torch.manual_seed(0)
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True), merge=True)
+    det_fill_(model)
+    model.eval()
+    out, meta = {}, {}
+    rng = np.random.default_rng(11)
+    H, W, R = 256, 320, 64
+    img = _det_image(rng, 1, H, W)
+    out["img"] = img
+    side = np.exp(rng.uniform(np.log(12), np.log(300), R))
+    asp = np.exp(rng.uniform(-0.7, 0.7, R))
+    bw, bh = np.minimum(side * asp, W - 2), np.minimum(side / asp, H - 2)
+    x1, y1 = rng.uniform(0, W - 1 - bw), rng.uniform(0, H - 1 - bh)
+    rois = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+    out["rois"] = rois
+    boxes = [BoxList(torch.from_numpy(rois), (W, H))]
+    g = model.Grid_Cascade_RCNN
+    with torch.no_grad():
+        c = model.Conv_Body(torch.from_numpy(img))
+        for i, t in enumerate(c):
+            out["c%d" % (i + 2)] = t.numpy()[:, ::16, ::2, ::2]
+        p = model.Conv_Body_FPN(c)
+        for i, t in enumerate(p):
+            out["p%d" % (i + 2)] = t.numpy()[:, ::16, ::2, ::2]
+        logits, breg = model.RPN.head(p)
+        for i, (a, b) in enumerate(zip(logits, breg)):
+            out["rpn_logits_%d" % i] = a.numpy()[:, :, ::2, ::2]
+            out["rpn_bbox_%d" % i] = b.numpy()[:, :, ::2, ::2]
+        f = g.Head_cls(p, boxes)
+        out["cls_feat"] = f.numpy()[:, ::4]
+        out["cls_logits"] = g.Output_cls(f).numpy()
+        out["rescore_logits"] = g.Output_rescore(g.Head_rescore(p, boxes)).numpy()
+        for s in range(3):
+            outp = getattr(g, "Output_grid_%d" % s)
+            outp.train()
+            xg, xso = getattr(g, "Head_grid_%d" % s)(p, boxes)
+            hm, iou = outp(xg, xso)
+            out["grid_feat_%d" % s] = xg.numpy()[:, ::16]
+            out["grid_heat_%d" % s] = hm["unfused"].numpy()[:, :, ::2, ::2]
+            if iou is not None:
+                out["grid_iou_%d" % s] = iou.numpy()
+    model.train()
+    for q in model.parameters():
+        q.grad = None
+    p = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(img)))
+    loss = 0
+    for s in range(3):
+        xg, xso = getattr(g, "Head_grid_%d" % s)(p, boxes)
+        hm, iou = getattr(g, "Output_grid_%d" % s)(xg, xso)
+        loss = loss + (hm["unfused"] ** 2).mean()
+        if iou is not None:
+            loss = loss + (iou ** 2).mean()
+    loss = loss + (g.Output_cls(g.Head_cls(p, boxes)) ** 2).mean()
+    loss = loss + (g.Output_rescore(g.Head_rescore(p, boxes)) ** 2).mean()
+    lo, br = model.RPN.head(p)
+    loss = loss + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)
+    loss.backward()
+    out["loss"] = loss.detach().numpy()
+    meta["grad_stats"] = _grad_stats(model)
+    params = dict(model.named_parameters())
+    for k in ("Conv_Body.layer2.0.conv1.weight", "Conv_Body.layer3.5.conv2.weight", "Conv_Body.layer4.2.conv3.weight",
+              "Conv_Body_FPN.fpn_out.2.weight", "Conv_Body_FPN.fpn_in.2.weight", "RPN.head.conv.weight",
+              "Grid_Cascade_RCNN.Head_grid_0.convs.0.0.weight", "Grid_Cascade_RCNN.Head_grid_2.convs.7.0.weight",
+              "Grid_Cascade_RCNN.Head_grid_1.convs.3.1.weight", "Grid_Cascade_RCNN.Output_grid_2.deconv_1.weight",
+              "Grid_Cascade_RCNN.Output_grid_2.iou_fc1.weight", "Grid_Cascade_RCNN.Head_cls.fc6.weight",
+              "Grid_Cascade_RCNN.Output_rescore.cls_score.weight"):
+        gq = params[k].grad
+        out["grad::" + k] = gq.numpy().reshape(-1)[::max(1, gq.numel() // 4096)]
+    np.savez_compressed(os.path.join(HERE, "model_r50_big.npz"), **out)
+    with open(os.path.join(HERE, "model_r50_big_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("big:", len(out), "arrays, loss", float(loss), "grad tensors", len(meta["grad_stats"]))
+
+
+def _jittered_proposals(rng, gt, n_per_gt, n_bg, W, H):
+    props = []
+    for b in gt:
+        w, h = b[2] - b[0], b[3] - b[1]
+        for j in range(n_per_gt):
+            # a ladder of jitter amplitudes: IoUs from ~0.9 down to ~0.2 (positives and negatives of every stage)
+            amp = 0.01 + 0.5 * (j / max(n_per_gt - 1, 1)) ** 1.5
+            d = rng.uniform(-amp, amp, 4) * np.array([w, h, w, h])
+            q = np.clip(b + d, [0, 0, 0, 0], [W - 1, H - 1, W - 1, H - 1])
+            if q[2] - q[0] > 6 and q[3] - q[1] > 6:
+                props.append(q)
+    for _ in range(n_bg):
+        w, h = rng.uniform(10, W / 2), rng.uniform(10, H / 2)
+        x, y = rng.uniform(0, W - 1 - w), rng.uniform(0, H - 1 - h)
+        props.append(np.array([x, y, x + w, y + h]))
+    return np.asarray(props, np.float32)
+
+
+def gen_cpm_train():
+    """Rows a-11 / a-12: the REFERENCE GridCascadeRCNN.forward in training mode
+    (grid_cascade_rcnn.py:57-224) on a 2-image batch whose proposal sets are small enough that every sampler keeps
+    everything (cls sampler <= 128 positives / 384 negatives per image, <= 96 grid positives per image, KEEP_RATIO
+    off), so the run involves no random draw: the 8 losses, the RoI set entering every grid stage, the boxes handed to
+    the RSM head and gradient statistics.  Plus CLSPostProcessor's candidate selection (inference.py:59-124) with the
+    CUDA-only ml_nms replaced by a recorder."""
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    from pet.utils.data.structures.bounding_box import BoxList
+    import pet.rcnn.modeling.grid_cascade_rcnn.inference as ref_inf
+    cfg = _cpm_cfg()
+    assert not cfg.GRID_RCNN.RESCORE_OPTION.KEEP_RATIO and not cfg.GRID_RCNN.RANDOM_JITTER
+    torch.manual_seed(0)
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True), merge=True)
+    det_fill_(model)
+    out, meta = {}, {}
+    rng = np.random.default_rng(2024)
+    H, W = 160, 224
+    img = _det_image(rng, 2, H, W)
+    out["img"] = img
+    gts = [np.array([[12, 20, 96, 130], [100, 8, 215, 90], [60, 70, 180, 150], [150, 100, 200, 155], [5, 5, 40, 44]],
+                    np.float32),
+           np.array([[30, 30, 190, 140], [8, 90, 70, 156], [120, 12, 160, 60]], np.float32)]
+    gt_labels = [np.array([3, 17, 80, 1, 44], np.int64), np.array([9, 9, 62], np.int64)]
+    props = []
+    for i in range(2):
+        pr = _jittered_proposals(rng, gts[i], 12, 14, W, H)
+        pr = np.concatenate([pr, gts[i]])           # the RPN appends the gts in training (rpn/inference.py)
+        props.append(pr)
+        out["gt_%d" % i], out["gt_labels_%d" % i], out["props_%d" % i] = gts[i], gt_labels[i], pr
+
+    def proposals():
+        res = []
+        for pr in props:
+            b = BoxList(torch.from_numpy(pr.copy()), (W, H))
+            b.add_field("objectness", torch.linspace(0.95, 0.05, len(b)))
+            res.append(b)
+        return res
+
+    def targets():
+        res = []
+        for g_, l_ in zip(gts, gt_labels):
+            t = BoxList(torch.from_numpy(g_.copy()), (W, H))
+            t.add_field("labels", torch.from_numpy(l_.copy()))
+            res.append(t)
+        return res
+    head = model.Grid_Cascade_RCNN
+    stage_rois = []
+    orig_ftg = head._forward_train_grid
+
+    def recording_ftg(stage, features, proposals_, targets=None):
+        r = orig_ftg(stage, features, proposals_, targets=targets)
+        stage_rois.append([b.bbox.detach().numpy().copy() for b in r[2]])
+        return r
+    head._forward_train_grid = recording_ftg
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        model.train()
+        for q in model.parameters():
+            q.grad = None
+        feats = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(img)))
+        x, result, losses = head(feats, proposals(), targets())
+        for k, v in losses.items():
+            out["loss::" + k] = np.asarray(float(v), np.float64)
+        for s, per_img in enumerate(stage_rois):
+            for i, b in enumerate(per_img):
+                out["stage%d_rois_%d" % (s, i)] = b
+        for i, b in enumerate(result):
+            out["rescore_rois_%d" % i] = b.bbox.detach().numpy()
+            out["rescore_labels_%d" % i] = b.get_field("labels").numpy()
+        cls_props = head.cls_loss_evaluator._proposals
+        for i, b in enumerate(cls_props):
+            out["cls_rois_%d" % i] = b.bbox.numpy()
+            out["cls_labels_%d" % i] = b.get_field("labels").numpy()
+        out["last_x"] = x.detach().numpy()[:, ::16]
+        sum(losses.values()).backward()
+        meta["grad_stats"] = _grad_stats(model)
+        # margins that decide whether the fixture is robust against 1e-6-level differences of another conv arithmetic
+        from pet.utils.data.structures.boxlist_ops import boxlist_iou
+        thr = cfg.GRID_RCNN.CASCADE_MAPPING_OPTION.FG_IOU_THRESHOLD
+        margin = 1.0
+        for s, per_img in enumerate(stage_rois):
+            for i, b in enumerate(per_img):
+                q = boxlist_iou(BoxList(torch.from_numpy(gts[i]), (W, H)), BoxList(torch.from_numpy(b), (W, H)))
+                margin = min(margin, float((q.max(dim=0)[0] - thr[s]).abs().min()))
+        meta["min_iou_margin"] = margin
+    finally:
+        torch.Tensor.cuda = saved_cuda
+        head._forward_train_grid = orig_ftg
+    # ---- CLSPostProcessor candidate selection (test mode), ml_nms recorded instead of run -----------------------
+    rec = {}
+    orig_nms = ref_inf.boxlist_ml_nms
+
+    def recording_nms(boxlist, thresh, *a, **k):
+        rec["bbox"] = boxlist.bbox.numpy().copy()
+        rec["scores"] = boxlist.get_field("scores").numpy().copy()
+        rec["labels"] = boxlist.get_field("labels").numpy().copy()
+        rec["thresh"] = thresh
+        return boxlist
+    ref_inf.boxlist_ml_nms = recording_nms
+    try:
+        n = 60
+        w_, h_ = rng.uniform(20, 500, n), rng.uniform(20, 400, n)
+        x_, y_ = rng.uniform(-30, 1333 - 0.6 * w_), rng.uniform(-20, 800 - 0.6 * h_)      # some stick out: clip_to_image
+        pbox = np.stack([x_, y_, x_ + w_, y_ + h_], 1).astype(np.float32)
+        logits = (rng.standard_normal((n, 81)) * 2.5).astype(np.float32)
+        post = ref_inf.post_processor(type="cls")
+        res = post(torch.from_numpy(logits), [BoxList(torch.from_numpy(pbox.copy()), (1333, 800))])
+        out["post_logits"], out["post_boxes"] = logits, pbox
+        out["post_cand_bbox"], out["post_cand_scores"], out["post_cand_labels"] = rec["bbox"], rec["scores"], rec["labels"]
+        prob = torch.softmax(torch.from_numpy(logits), -1).numpy()
+        meta["post_score_margin"] = float(np.abs(prob - cfg.GRID_RCNN.SCORE_THRESH).min())
+        meta["post_thresh"], meta["post_nms"] = float(post.score_thresh), float(rec["thresh"])
+        # RSM re-scoring branch (inference.py:62-76): s^0.8 * p^0.2 on the label's probability
+        bl = BoxList(torch.from_numpy(pbox.copy()), (1333, 800))
+        sc = rng.uniform(0.05, 1, n).astype(np.float32)
+        lb = rng.integers(1, 81, n).astype(np.int64)
+        bl.add_field("scores", torch.from_numpy(sc.copy()))
+        bl.add_field("labels", torch.from_numpy(lb.copy()))
+        r2 = post(torch.from_numpy(logits), [bl], rescore=True)
+        out["post_rs_scores_in"], out["post_rs_labels"] = sc, lb
+        out["post_rs_scores_out"] = r2[0].get_field("scores").numpy()
+    finally:
+        ref_inf.boxlist_ml_nms = orig_nms
+    np.savez_compressed(os.path.join(HERE, "model_cpm.npz"), **out)
+    with open(os.path.join(HERE, "model_cpm_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("cpm:", {k: float(v) for k, v in out.items() if k.startswith("loss::")})
+    print("stage RoI counts:", [[len(b) for b in per] for per in stage_rois], "cls", [len(b) for b in cls_props],
+          "rescore", [len(b) for b in result])
+    print("min IoU margin to a stage threshold: %.2e; min |score - thresh|: %.2e; candidates %d"
+          % (meta["min_iou_margin"], meta["post_score_margin"], len(rec["scores"])))
+
+
 def gen_soft_nms(ref_ext):
     """soft_nms_cpu of the reference (csrc/NMS/soft_nms.cpp compiled into oracle/_ref) on seeded box sets: all three
     methods, ties in the scores, heavy overlap (many removals), n = 0 / 1."""
@@ -537,6 +794,10 @@ def main():
         return gen_data_pipeline()
     if sys.argv[1:] == ["cascade"]:
         return gen_cascade()
+    if sys.argv[1:] == ["big"]:
+        return gen_model_big()
+    if sys.argv[1:] == ["cpm"]:
+        return gen_cpm_train()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
     cfg.DEVICE = "cpu"
     ops = {}

@@ -55,7 +55,7 @@ def _targets(g):
     return [t]
 
 
-def test_cascade_eval_matches_reference(model, golden):
+def test_cascade_eval_matches_reference(model, golden, conv_math):
     g = golden
     model.eval()
     head = model.Cascade_RCNN
@@ -78,7 +78,7 @@ def test_cascade_eval_matches_reference(model, golden):
         assert float(np.abs(result[0].get_field("scores").cpu().numpy() - g["eval_scores"]).max()) < 2e-3
 
 
-def test_cascade_training_matches_reference(model, golden):
+def test_cascade_training_matches_reference(model, golden, conv_math):
     g = golden
     with open(os.path.join(ROOT, "tests", "golden", "model_cascade_meta.json")) as f:
         meta = json.load(f)

@@ -53,6 +53,52 @@ def test_cols_conv_vs_oracle(oracle, case, with_offset):
         assert _rel(og.grad.cpu().numpy(), want[2]) < 5 * TOL
 
 
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[6]])
+def test_C_deform_conv_binding_as_the_reference_calls_it(oracle, case):
+    """_C.deform_conv_forward / _backward_input / _backward_filter with the reference's caller-owned-buffer contract
+    (csrc/Deformable/deform_conv.h:115-259, bound at vision.cpp:38-40), driven exactly as the reference's
+    pet/lib/ops/deform_conv.py:41-139 drives them: contiguous NCHW tensors, new_empty output, zero-filled gradient
+    buffers, two scratch tensors, argument order (kW, kH, dW, dH, padW, padH, dilW, dilH, group, deformable_group,
+    [scale,] im2col_step)."""
+    from pet.lib.ops import _C
+    N, C, H, W, K, stride, pad, dil, groups, dg = case
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(N, C, H, W, generator=g)
+    w = torch.randn(K, C // groups, 3, 3, generator=g) * (2.0 / (9 * C // groups)) ** 0.5
+    P = (H + 2 * pad - dil * 2 - 1) // stride + 1
+    Q = (W + 2 * pad - dil * 2 - 1) // stride + 1
+    off = torch.rand(N, dg * 18, P, Q, generator=g) * 6 - 3
+    dy = torch.randn(N, K, P, Q, generator=g)
+    want = oracle.deform_conv(x.numpy(), off.numpy(), w.numpy(), stride, pad, dil, groups, dg, dy=dy.numpy())
+    input, offset, weight, grad_output = x.cuda(), off.cuda(), w.cuda(), dy.cuda()
+    output = input.new_empty((N, K, P, Q))
+    bufs = [input.new_empty(0), input.new_empty(0)]
+    step = min(N, 64)
+    rc = _C.deform_conv_forward(input, weight, offset, output, bufs[0], bufs[1], weight.size(3), weight.size(2),
+                                stride, stride, pad, pad, dil, dil, groups, dg, step)
+    assert rc == 1 and _rel(output.cpu().numpy(), want[0]) < TOL
+    grad_input, grad_offset = torch.zeros_like(input), torch.zeros_like(offset)
+    _C.deform_conv_backward_input(input, offset, grad_output, grad_input, grad_offset, weight, bufs[0], weight.size(3),
+                                  weight.size(2), stride, stride, pad, pad, dil, dil, groups, dg, step)
+    assert _rel(grad_input.cpu().numpy(), want[1]) < TOL
+    assert _rel(grad_offset.cpu().numpy(), want[2]) < 5 * TOL
+    grad_weight = torch.zeros_like(weight)
+    _C.deform_conv_backward_filter(input, offset, grad_output, grad_weight, bufs[0], bufs[1], weight.size(3),
+                                   weight.size(2), stride, stride, pad, pad, dil, dil, groups, dg, 1, step)
+    assert _rel(grad_weight.cpu().numpy(), want[3]) < TOL
+    _C.deform_conv_backward_filter(input, offset, grad_output, grad_weight, bufs[0], bufs[1], weight.size(3),
+                                   weight.size(2), stride, stride, pad, pad, dil, dil, groups, dg, 0.5, step)
+    assert _rel(grad_weight.cpu().numpy(), 1.5 * want[3]) < TOL           # accumulates, scaled (deform_conv.h:229)
+    with pytest.raises(RuntimeError, match="im2col step"):
+        _C.deform_conv_forward(input, weight, offset, output, bufs[0], bufs[1], 3, 3, stride, stride, pad, pad, dil,
+                               dil, groups, dg, N + 1)
+    with pytest.raises(RuntimeError):
+        _C.deform_conv_forward(x, w, off, output.cpu(), bufs[0], bufs[1], 3, 3, stride, stride, pad, pad, dil, dil,
+                               groups, dg, step)                            # CPU tensors: "Not implemented on the CPU"
+    with pytest.raises(RuntimeError, match="outside the CPM R-CNN hot path"):
+        _C.modulated_deform_conv_forward()
+
+
 def test_zero_offset_equals_grouped_conv_kernel():
     """Known answer inside the HIP path: zero offsets through the sampler == the implicit-GEMM grouped conv."""
     import pet.lib.ops as ops
@@ -119,7 +165,7 @@ X_OPTS = ["BACKBONE.CONV_BODY", "resnext", "BACKBONE.RESNEXT.LAYERS", (3, 4, 6, 
           "BACKBONE.RESNEXT.WIDTH", 4, "GRID_RCNN.MAX_SAMPLE_NUM_GRID", 32]
 
 
-def test_resnext_dcn_body_vs_cpu_oracle():
+def test_resnext_dcn_body_vs_cpu_oracle(conv_math):
     """X-50-64x4d + DCN body (the X-101 block types at a depth the CPU oracle finishes quickly): C2..C5 and FPN
     features vs oracle/cpu_model.resnext_backbone on the same name-seeded weights, with non-zero offsets."""
     from test_host_logic import CPM_OPTS

@@ -20,6 +20,19 @@ def rel(a, b):
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
 
 
+def check_grad_entries(got, want, name, log=None):
+    """Element-wise gradient parity at north_star's 1e-3 of the tensor maximum.  ReLU gates of pre-activations that are
+    zero to within rounding can flip between two arithmetics (CPU fp32 vs MFMA accumulation order); a flipped gate
+    moves the few gradient entries behind it by more than rounding.  Those entries are COUNTED and BOUNDED instead of
+    widening the bar for everything: at most 0.5 % of the sampled entries may exceed 1e-3, none may exceed 1e-2."""
+    err = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64)) / (np.abs(want).max() + 1e-30)
+    over = int((err > 1e-3).sum())
+    if log is not None:
+        log.append((name, float(err.max()), over, err.size))
+    assert over <= max(1, int(0.005 * err.size)), (name, "entries over 1e-3: %d of %d" % (over, err.size), float(err.max()))
+    assert float(err.max()) < 1e-2, (name, float(err.max()))
+
+
 @pytest.fixture(scope="module")
 def model():
     from detfill import det_fill_
@@ -35,7 +48,7 @@ def model():
     config.reset_cfg()
 
 
-def test_forward_matches_reference(model, golden_model):
+def test_forward_matches_reference(model, golden_model, conv_math):
     from pet.utils.data.structures.bounding_box import BoxList
     g = golden_model
     model.eval()
@@ -69,7 +82,7 @@ def test_forward_matches_reference(model, golden_model):
                 assert iou is None
 
 
-def test_backward_matches_reference(model, golden_model):
+def test_backward_matches_reference(model, golden_model, conv_math):
     from pet.utils.data.structures.bounding_box import BoxList
     g = golden_model
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_r50_meta.json")))
@@ -102,12 +115,99 @@ def test_backward_matches_reference(model, golden_model):
             k = key[len("m_grad::"):]
             gq = params[k].grad.detach().contiguous().reshape(-1)       # logical (NCHW) order
             sub = gq[::max(1, gq.numel() // 4096)].cpu().numpy()
-            # element-wise: a few ReLU masks of near-zero pre-activations flip between the CPU and GPU forward
-            # (8 conv+GN+ReLU layers, 6 RoIs); that moves single weight-gradient entries by a few 1e-3 of the
-            # tensor max while the L1/L2 norms above stay within 2e-3
-            assert rel(sub, g[key]) < 1e-2, k
+            check_grad_entries(sub, g[key], k)
     frozen = [k for k, q in params.items() if not q.requires_grad]
     assert all(params[k].grad is None for k in frozen)
+
+
+@pytest.fixture(scope="module")
+def golden_big():
+    return np.load(os.path.join(ROOT, "tests", "golden", "model_r50_big.npz"))
+
+
+def test_forward_big_matches_reference(model, golden_big, conv_math):
+    """1 x 3 x 256 x 320 image, 64 RoIs over all four RoI levels (make_golden.py big): error accumulation through the
+    whole backbone / FPN / 8-conv grid stacks, in both conv arithmetics, at north_star's 1e-3."""
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_big
+    model.eval()
+    worst = {}
+    with torch.no_grad():
+        c = model.Conv_Body(torch.from_numpy(g["img"]).cuda())
+        for i, t in enumerate(c):
+            worst["c%d" % (i + 2)] = rel(t[:, ::16, ::2, ::2], g["c%d" % (i + 2)])
+        p = model.Conv_Body_FPN(c)
+        for i, t in enumerate(p):
+            worst["p%d" % (i + 2)] = rel(t[:, ::16, ::2, ::2], g["p%d" % (i + 2)])
+        lo, br = model.RPN.head(p)
+        for i in range(5):
+            worst["rpn_logits_%d" % i] = rel(lo[i][:, :, ::2, ::2], g["rpn_logits_%d" % i])
+            worst["rpn_bbox_%d" % i] = rel(br[i][:, :, ::2, ::2], g["rpn_bbox_%d" % i])
+        boxes = [BoxList(torch.from_numpy(g["rois"]).cuda(), (320, 256))]
+        G = model.Grid_Cascade_RCNN
+        f = G.Head_cls(p, boxes)
+        worst["cls_feat"] = rel(f[:, ::4], g["cls_feat"])
+        worst["cls_logits"] = rel(G.Output_cls(f), g["cls_logits"])
+        worst["rescore_logits"] = rel(G.Output_rescore(G.Head_rescore(p, boxes)), g["rescore_logits"])
+        for s in range(3):
+            xg, _ = getattr(G, "Head_grid_%d" % s)(p, boxes)
+            worst["grid_feat_%d" % s] = rel(xg[:, ::16], g["grid_feat_%d" % s])
+            hm, iou = getattr(G, "Output_grid_%d" % s)(xg, None)
+            worst["grid_heat_%d" % s] = rel(hm["unfused"][:, :, ::2, ::2], g["grid_heat_%d" % s])
+            if s == 2:
+                worst["grid_iou_2"] = rel(iou, g["grid_iou_2"])
+    _log("forward_big[%s] worst %.2e: %s" % (conv_math, max(worst.values()),
+                                              ", ".join("%s %.1e" % kv for kv in sorted(worst.items()))))
+    for k, v in worst.items():
+        assert v < 1e-3, (k, v)
+
+
+def _log(line):
+    d = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "parity_log.txt"), "a") as f:
+        f.write(line + "\n")
+
+
+def test_backward_big_matches_reference(model, golden_big, conv_math):
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_big
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_r50_big_meta.json")))
+    model.train()
+    model.zero_grad(set_to_none=True)
+    boxes = [BoxList(torch.from_numpy(g["rois"]).cuda(), (320, 256))]
+    G = model.Grid_Cascade_RCNN
+    p = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(g["img"]).cuda()))
+    loss = 0
+    for s in range(3):
+        xg, _ = getattr(G, "Head_grid_%d" % s)(p, boxes)
+        hm, iou = getattr(G, "Output_grid_%d" % s)(xg, None)
+        loss = loss + (hm["unfused"] ** 2).mean()
+        if iou is not None:
+            loss = loss + (iou ** 2).mean()
+    loss = loss + (G.Output_cls(G.Head_cls(p, boxes)) ** 2).mean()
+    loss = loss + (G.Output_rescore(G.Head_rescore(p, boxes)) ** 2).mean()
+    lo, br = model.RPN.head(p)
+    loss = loss + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["loss"])) / abs(float(g["loss"])) < 1e-3
+    params = dict(model.named_parameters())
+    assert len(meta["grad_stats"]) == 196
+    worst = 0.0
+    for k, (s1, sabs, s2) in meta["grad_stats"].items():
+        gd = params[k].grad.double()
+        e2 = abs(float((gd ** 2).sum()) ** 0.5 - s2 ** 0.5) / (s2 ** 0.5 + 1e-30)
+        e1 = abs(float(gd.abs().sum()) - sabs) / (abs(sabs) + 1e-30)
+        worst = max(worst, e1, e2)
+        assert e1 < 1e-3 and e2 < 1e-3, (k, e1, e2)
+    log = []
+    for key in g.files:
+        if key.startswith("grad::"):
+            k = key[len("grad::"):]
+            gq = params[k].grad.detach().contiguous().reshape(-1)
+            check_grad_entries(gq[::max(1, gq.numel() // 4096)].cpu().numpy(), g[key], k, log)
+    _log("backward_big[%s] worst norm err %.2e; entries: %s" % (
+        conv_math, worst, ", ".join("%s max %.1e over %d/%d" % (n.split(".", 1)[1], m, o, t) for n, m, o, t in log)))
 
 
 def synthetic_batch(n, h, w, gts, seed):
@@ -128,7 +228,7 @@ def synthetic_batch(n, h, w, gts, seed):
     return images, targets
 
 
-def test_training_step_small(model):
+def test_training_step_small(model, conv_math):
     """Full train-mode forward + backward (RPN proposals, NMS, sampling, 3 grid stages, ISM, RSM)."""
     model.train()
     model.zero_grad(set_to_none=True)
@@ -151,7 +251,7 @@ def test_training_step_small(model):
     assert counts["cls"] > 0 and counts["grid_0"] >= 12          # at least the gt boxes are positives
 
 
-def test_inference_single_image(model):
+def test_inference_single_image(model, conv_math):
     """Test-mode forward (one image per forward): cls -> ml_nms -> 3 stages -> ISM -> RSM."""
     from pet.rcnn.core.config import cfg
     model.eval()

@@ -52,6 +52,49 @@ def test_cfg_yaml_merge(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists(R50_YAML), reason="reference tree not present on this box")
+def test_every_reference_yaml_merges():
+    """All 55 files under cfgs/rcnn/mscoco merge into the config tree unchanged ("cfgs/rcnn/*.yaml run
+    unchanged"), including the nine that set VIS keys (config.py:1143-1276)."""
+    import glob
+    from pet.rcnn.core import config
+    files = sorted(glob.glob("/root/reference/cfgs/rcnn/mscoco/**/*.yaml", recursive=True))
+    assert len(files) >= 55
+    try:
+        for f in files:
+            config.reset_cfg()
+            config.merge_cfg_from_file(f)
+            assert config.cfg.MODEL.NUM_CLASSES == 81, f
+    finally:
+        config.reset_cfg()
+
+
+def test_every_reference_ops_name_imports():
+    """pet/lib/ops/__init__.py:1-30 of the reference: every exported name exists here (callers type-check against
+    them); the ones outside the hot path raise on use, never silently fall back."""
+    import pet.lib.ops as ops
+    names = ["nms", "ml_nms", "nms_rotated", "poly_nms", "soft_nms", "ml_soft_nms", "box_voting", "box_ml_voting",
+             "box_iou", "box_iou_rotated", "l2_loss", "IOULoss", "BoundedIoULoss", "MaskIOULoss", "DICELoss",
+             "smooth_l1_loss", "smooth_l1_loss_LW", "SigmoidFocalLoss", "equalization_loss", "LovaszHinge",
+             "LovaszSoftmax", "lovasz_softmax_loss", "LabelSmoothing", "FrozenBatchNorm2d", "NaiveSyncBatchNorm",
+             "Conv2dSamePadding", "Conv2dWS", "SplAtConv2d", "DeformConv", "ModulatedDeformConv", "DeformConvPack",
+             "ModulatedDeformConvPack", "L2Norm", "MixtureBatchNorm2d", "MixtureGroupNorm", "Mish", "H_Swish",
+             "H_Sigmoid", "Swish", "SwishX", "DropBlock2D", "Scale", "SeConv2d", "GlobalContextBlock", "ECA",
+             "PoolPointsInterp", "roi_align", "ROIAlign", "roi_align_rotated", "ROIAlignRotated", "roi_pool", "ROIPool",
+             "AffineChannel2d"]
+    for n in names:
+        assert hasattr(ops, n), n
+    assert isinstance(ops.MixtureBatchNorm2d, type) and isinstance(ops.ModulatedDeformConvPack, type)
+    with pytest.raises(RuntimeError, match="outside the CPM R-CNN hot path"):
+        ops.MixtureBatchNorm2d(8)
+    with pytest.raises(RuntimeError, match="outside the CPM R-CNN hot path"):
+        ops.roi_pool(None, None, (7, 7), 1.0)
+    import torch
+    bn = ops.FrozenBatchNorm2d(4)
+    assert sorted(bn.state_dict()) == ["bias", "running_mean", "running_var", "weight"]
+    assert torch.allclose(bn(torch.ones(1, 4, 2, 2)), torch.ones(1, 4, 2, 2), atol=1e-4)
+
+
+@pytest.mark.skipif(not os.path.exists(R50_YAML), reason="reference tree not present on this box")
 def test_reference_yamls_parse_unchanged():
     from pet.rcnn.core import config
     base = os.path.dirname(R50_YAML)
