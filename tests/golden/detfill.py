@@ -38,3 +38,19 @@ def det_fill_(module):
             if torch.is_floating_point(p)}
     module.load_state_dict(fill, strict=False)
     return module
+
+
+def soften_heatmaps_(model, factor=0.05):
+    """Scale the last transposed conv of every Grid_output so that the heat-map logits stay a few units wide.  With
+    the raw name-seeded weights many sigmoids saturate to exactly 1.0 and the per-point arg-max of the grid decoder is
+    decided by float ties (first index among equal values) -- a property of one sigmoid implementation's rounding,
+    not of the decoder.  Used identically by the golden generator (on the reference model) and by the tests."""
+    head = model.Grid_Cascade_RCNN
+    s = 0
+    with torch.no_grad():
+        while hasattr(head, "Output_grid_%d" % s):
+            out = getattr(head, "Output_grid_%d" % s)
+            out.deconv_2.weight.mul_(factor)
+            out.deconv_2.bias.mul_(factor)
+            s += 1
+    return model

@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 REF = "/root/reference"
 
-from detfill import det_fill_  # noqa: E402
+from detfill import det_fill_, soften_heatmaps_  # noqa: E402
 from oracle.build_ref import build as build_ref  # noqa: E402
 
 
@@ -535,29 +535,15 @@ def gen_cpm_train():
     torch.manual_seed(0)
     model = convert_bn2affine_model(Generalized_RCNN(is_train=True), merge=True)
     det_fill_(model)
-    out, meta = {}, {}
-    rng = np.random.default_rng(2024)
+    soften_heatmaps_(model)
+    from pet.utils.data.structures.boxlist_ops import boxlist_iou
     H, W = 160, 224
-    img = _det_image(rng, 2, H, W)
-    out["img"] = img
     gts = [np.array([[12, 20, 96, 130], [100, 8, 215, 90], [60, 70, 180, 150], [150, 100, 200, 155], [5, 5, 40, 44]],
                     np.float32),
            np.array([[30, 30, 190, 140], [8, 90, 70, 156], [120, 12, 160, 60]], np.float32)]
     gt_labels = [np.array([3, 17, 80, 1, 44], np.int64), np.array([9, 9, 62], np.int64)]
-    props = []
-    for i in range(2):
-        pr = _jittered_proposals(rng, gts[i], 12, 14, W, H)
-        pr = np.concatenate([pr, gts[i]])           # the RPN appends the gts in training (rpn/inference.py)
-        props.append(pr)
-        out["gt_%d" % i], out["gt_labels_%d" % i], out["props_%d" % i] = gts[i], gt_labels[i], pr
-
-    def proposals():
-        res = []
-        for pr in props:
-            b = BoxList(torch.from_numpy(pr.copy()), (W, H))
-            b.add_field("objectness", torch.linspace(0.95, 0.05, len(b)))
-            res.append(b)
-        return res
+    head = model.Grid_Cascade_RCNN
+    thr = cfg.GRID_RCNN.CASCADE_MAPPING_OPTION.FG_IOU_THRESHOLD
 
     def targets():
         res = []
@@ -566,25 +552,89 @@ def gen_cpm_train():
             t.add_field("labels", torch.from_numpy(l_.copy()))
             res.append(t)
         return res
-    head = model.Grid_Cascade_RCNN
-    stage_rois = []
+
+    # Recorders around the reference's own methods (nothing of the reference is modified): the RoI set entering each
+    # stage, and the two margins that decide whether the fixture is robust against the 1e-5-level differences of
+    # another conv arithmetic -- the distance of every decoded RoI's best IoU from the stage threshold it is matched
+    # at, and the gap between the best and second-best cell of every decoded heat map.
+    stage_rois, gaps, iou_margins = [], [], []
     orig_ftg = head._forward_train_grid
 
     def recording_ftg(stage, features, proposals_, targets=None):
         r = orig_ftg(stage, features, proposals_, targets=targets)
         stage_rois.append([b.bbox.detach().numpy().copy() for b in r[2]])
         return r
+    restore = [(head, "_forward_train_grid", orig_ftg)]
     head._forward_train_grid = recording_ftg
+    for s_ in range(3):
+        ev = getattr(head, "grid_loss_evaluator_%d" % s_)
+        orig_sub = ev.subsample
+
+        def recording_sub(proposals_, targets_, _orig=orig_sub, _s=s_):
+            if _s > 0:
+                for p_, t_ in zip(proposals_, targets_):
+                    q = boxlist_iou(t_, p_).max(dim=0)[0]
+                    iou_margins.append(float((q - thr[_s]).abs().min()))
+            return _orig(proposals_, targets_)
+        ev.subsample = recording_sub
+        restore.append((ev, "subsample", orig_sub))
+    for s_ in range(2):
+        pp = getattr(head, "grid_post_processor_%d" % s_)
+        orig_gb = pp.get_boxes
+
+        def recording_gb(proposals_, grid_pred, is_train, _orig=orig_gb):
+            lg = grid_pred.detach().reshape(-1, grid_pred.shape[-1] * grid_pred.shape[-2])
+            top = lg.topk(2, dim=1)[0]
+            # best-vs-second-best cell, in units of the largest logit (the scale conv parity is measured in)
+            gaps.append(((top[:, 0] - top[:, 1]).min() / lg.abs().max()).item())
+            gaps.append(-float(lg.sigmoid().max()))     # (negated) largest probability: saturation check
+            return _orig(proposals_, grid_pred, is_train)
+        pp.get_boxes = recording_gb
+        restore.append((pp, "get_boxes", orig_gb))
     saved_cuda = torch.Tensor.cuda
     torch.Tensor.cuda = lambda self, *a, **k: self
     try:
-        model.train()
-        for q in model.parameters():
-            q.grad = None
-        feats = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(img)))
-        x, result, losses = head(feats, proposals(), targets())
+        best = (-1.0, None)
+        seeds = list(range(2024, 2064))
+        for trial in range(len(seeds) + 1):
+            seed = seeds[trial] if trial < len(seeds) else best[1]      # last pass: re-run the best seed and keep it
+            out, meta = {}, {}
+            del stage_rois[:], gaps[:], iou_margins[:]
+            rng = np.random.default_rng(seed)
+            img = _det_image(rng, 2, H, W)
+            out["img"] = img
+            props = []
+            for i in range(2):
+                pr = _jittered_proposals(rng, gts[i], 4, 5, W, H)
+                pr = np.concatenate([pr, gts[i]])           # the RPN appends the gts in training (rpn/inference.py)
+                props.append(pr)
+                out["gt_%d" % i], out["gt_labels_%d" % i], out["props_%d" % i] = gts[i], gt_labels[i], pr
+            proposals = []
+            for pr in props:
+                b = BoxList(torch.from_numpy(pr.copy()), (W, H))
+                b.add_field("objectness", torch.linspace(0.95, 0.05, len(b)))
+                proposals.append(b)
+            model.train()
+            for q in model.parameters():
+                q.grad = None
+            feats = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(img)))
+            x, result, losses = head(feats, proposals, targets())
+            meta["seed"] = seed
+            meta["min_iou_margin"] = min(iou_margins)
+            meta["min_argmax_gap"] = min(g_ for g_ in gaps if g_ >= 0)
+            meta["max_heat_prob"] = max(-g_ for g_ in gaps if g_ < 0)
+            counts = [[len(b) for b in per] for per in stage_rois]
+            print("seed %d: stage RoI counts %s, IoU margin %.2e, argmax gap %.2e, max heat prob %.4f"
+                  % (seed, counts, meta["min_iou_margin"], meta["min_argmax_gap"], meta["max_heat_prob"]))
+            refined_in_last = sum(counts[2]) - sum(len(g_) for g_ in gts)
+            if trial == len(seeds):
+                break
+            score = min(meta["min_iou_margin"] / 3e-3, meta["min_argmax_gap"] / 3e-4) if refined_in_last >= 1 else 0.0
+            if score > best[0]:
+                best = (score, seed)
+        assert best[0] > 0.5, "no seed gave a usable fixture"
         for k, v in losses.items():
-            out["loss::" + k] = np.asarray(float(v), np.float64)
+            out["loss::" + k] = np.asarray(float(v.detach()), np.float64)
         for s, per_img in enumerate(stage_rois):
             for i, b in enumerate(per_img):
                 out["stage%d_rois_%d" % (s, i)] = b
@@ -598,18 +648,10 @@ def gen_cpm_train():
         out["last_x"] = x.detach().numpy()[:, ::16]
         sum(losses.values()).backward()
         meta["grad_stats"] = _grad_stats(model)
-        # margins that decide whether the fixture is robust against 1e-6-level differences of another conv arithmetic
-        from pet.utils.data.structures.boxlist_ops import boxlist_iou
-        thr = cfg.GRID_RCNN.CASCADE_MAPPING_OPTION.FG_IOU_THRESHOLD
-        margin = 1.0
-        for s, per_img in enumerate(stage_rois):
-            for i, b in enumerate(per_img):
-                q = boxlist_iou(BoxList(torch.from_numpy(gts[i]), (W, H)), BoxList(torch.from_numpy(b), (W, H)))
-                margin = min(margin, float((q.max(dim=0)[0] - thr[s]).abs().min()))
-        meta["min_iou_margin"] = margin
     finally:
         torch.Tensor.cuda = saved_cuda
-        head._forward_train_grid = orig_ftg
+        for obj, name, fn in restore:
+            setattr(obj, name, fn)
     # ---- CLSPostProcessor candidate selection (test mode), ml_nms recorded instead of run -----------------------
     rec = {}
     orig_nms = ref_inf.boxlist_ml_nms
@@ -653,6 +695,8 @@ def gen_cpm_train():
           "rescore", [len(b) for b in result])
     print("min IoU margin to a stage threshold: %.2e; min |score - thresh|: %.2e; candidates %d"
           % (meta["min_iou_margin"], meta["post_score_margin"], len(rec["scores"])))
+    print("decode: min relative top1-top2 gap of a heat map %.2e, largest heat-map probability %.6f"
+          % (meta["min_argmax_gap"], meta["max_heat_prob"]))
 
 
 def gen_soft_nms(ref_ext):

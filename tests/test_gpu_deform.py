@@ -190,8 +190,13 @@ def test_resnext_dcn_body_vs_cpu_oracle(conv_math):
             ref_p = M.fpn(sd, ref_c)
         offs = [k for k in sd if k.endswith("conv_offset.weight")]
         assert len(offs) == 13 and all(float(sd[k].abs().max()) > 0 for k in offs)
+        # 13 stacked deformable layers sample random (non-smooth) maps at predicted offsets: an offset error of 1e-5 of
+        # its range is multiplied by the sampled map's gradient (|grad x| ~ |x| per pixel here, far steeper than a
+        # trained network's features) and compounds from layer to layer: exact-f32 stays inside 1e-3, the split-bf16
+        # arithmetic (3e-5 per layer on plain convs, tests/test_gpu_model.py) reaches 1-2e-3 on this stack
+        tol = 1e-3 if conv_math == "f32" else 3e-3
         for a, b in zip(list(got_c) + list(got_p), ref_c + ref_p):
-            assert _rel(a.cpu().numpy(), b.numpy()) < 1e-3
+            assert _rel(a.cpu().numpy(), b.numpy()) < tol
         # one backward through the trainable stages, against autograd over the CPU restatement (deformable conv
         # gradients from orc_deform_conv): gradient norms of every trainable backbone / FPN tensor
         model.train()
