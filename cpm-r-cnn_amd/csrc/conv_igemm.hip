@@ -1283,7 +1283,6 @@ struct ProfScope {
 // conv arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 3-term split-bf16 MFMA (fp32 accumulate)
 static int g_conv_split = 0;
 
-struct Plan { int bm, bn, wm, wn, split; };
 
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -1373,6 +1372,7 @@ Plan plan_igemm(const IgemmArgs& a) {
 
 int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t s) {
   const int rows = a.M - a.m_base;
+  if (g_conv_split && bn >= 64 && sp_eligible(a)) return launch_igemm_sp(a, bm, bn, s);
 #define LAUNCH(BM, BN, WM, WN)                                                                       \
   do {                                                                                               \
     dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);          \
@@ -1403,7 +1403,7 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
   a.m_base = 0;
   ProfScope prof_scope(s, prof_kind);
   static const int use_halo = env_int("CPM_IGEMM_HALO", 1);
-  if (use_halo && g_conv_split && vec && a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 &&
+  if (use_halo && !(g_conv_split && sp_eligible(a)) && g_conv_split && vec && a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 &&
       a.ihmul == 1 && a.iwmul == 1 && (a.hstep == 1 || a.hstep == -1) && (a.wstep == 1 || a.wstep == -1) &&
       a.osh == 1 && a.osw == 1 && a.oah == 0 && a.oaw == 0 && a.groups == 1 && a.CgR == a.Ctot && a.Ctot % 32 == 0 &&
       a.OHp == a.OH && a.OWp == a.OW && a.IH == a.OH && a.IW == a.OW && a.split_k == 1 && !a.atomic_out &&
@@ -1466,14 +1466,15 @@ CPM_EXPORT size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d) {
   return dgrad_weight_bytes(d) + 256;
 }
 
-CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,
-                                  const float* shift, const float* residual, int res_mode, int relu, float* y,
-                                  void* workspace, size_t workspace_bytes, void* stream) {
-  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
-  CPM_REQUIRE(x && w && y, "null pointer");
-  CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
-  hipStream_t s = (hipStream_t)stream;
+static int split_into(const float* x, int64_t rows, int channels, void* sp, hipStream_t s) {
+  return cpm_split_planes(x, rows, channels, sp, (void*)s);
+}
+
+static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w, const void* w_sp,
+                             const float* scale, const float* shift, const float* residual, int res_mode, int relu,
+                             float* y, void* y_sp, hipStream_t s) {
   IgemmArgs a = {};
+  a.in_sp = x_sp; a.wm_sp = w_sp; a.out_sp = y_sp;
   a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
   a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C;
   a.OH = d->P; a.OW = d->Q; a.OCtot = d->K; a.OHp = d->P; a.OWp = d->Q;
@@ -1514,13 +1515,37 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
                        residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode, relu);
     rc = cpm::check_launch("conv epilogue");
   }
+  // an SP copy the kernel's own epilogue could not write (split-K partial sums, a kernel without the SP store)
+  if (rc == CPM_OK && y_sp && !(a.split_k == 1 && g_conv_split && sp_eligible(a)))
+    rc = split_into(y, (int64_t)a.M, a.OCtot, y_sp, s);
   return rc;
+}
+
+CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,
+                                  const float* shift, const float* residual, int res_mode, int relu, float* y,
+                                  void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && w && y, "null pointer");
+  CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
+  return conv_forward_impl(d, x, nullptr, w, nullptr, scale, shift, residual, res_mode, relu, y, nullptr,
+                           (hipStream_t)stream);
+}
+
+CPM_EXPORT int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w,
+                                     const void* w_sp, const float* scale, const float* shift, const float* residual,
+                                     int res_mode, int relu, float* y, void* y_sp, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && w && y, "null pointer");
+  CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
+  CPM_REQUIRE(!y_sp || d->K % 4 == 0, "an SP output needs a multiple of 4 output channels");
+  return conv_forward_impl(d, x, x_sp, w, w_sp, scale, shift, residual, res_mode, relu, y, y_sp, (hipStream_t)stream);
 }
 
 static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
                      const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr,
-                     bool prepared = false) {
+                     bool prepared = false, const void* dy_sp = nullptr, const void* wt_sp = nullptr,
+                     void* dx_sp = nullptr) {
   const size_t need = dgrad_weight_bytes(d);
   if (!prepared && (!workspace || workspace_bytes < need)) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
@@ -1535,6 +1560,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
                        d->R * d->S, Cg, (float*)workspace);
   }
   IgemmArgs a = {};
+  if (prepared) { a.in_sp = dy_sp; a.wm_sp = wt_sp; }     // wt_sp: the SP form of the prepared [g][c][tap][k] image
   a.in = dy; a.wm = wt; a.out = dx; a.shift = shift; a.relu = relu;
   a.N = d->N; a.IH = d->P; a.IW = d->Q; a.Ctot = d->K;      // the GEMM's "input" is dy
   a.OH = d->H; a.OW = d->W; a.OCtot = d->C;                 // its "output" is dx
@@ -1564,6 +1590,9 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   if (a.atomic_out && !accumulate) {
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
+  // the kernel's own epilogue writes the SP copy unless the sums are partial (atomics) or a phase has no taps
+  bool sp_in_kernel = dx_sp && !a.atomic_out && g_conv_split;
+  if (sp_in_kernel) a.out_sp = dx_sp;
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = CPM_OK;
@@ -1583,7 +1612,9 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
       a.M = d->N * a.OHp * a.OWp;
       a.ksteps = a.nr * a.ns * a.ksteps_per_tap;
       if (a.ksteps == 0 && (a.atomic_out || acc_via_res)) continue;      // nothing to add
+      if (sp_in_kernel && !sp_eligible(a)) { sp_in_kernel = false; a.out_sp = nullptr; }
       Plan pp = plan_igemm(a);
+      if (pp.bn < 64 && sp_in_kernel) { sp_in_kernel = false; a.out_sp = nullptr; }
       pp.split = a.split_k;
       if (a.ksteps < a.split_k) { a.split_k = 1; pp.split = 1; }
       rc = launch_igemm(a, pp, s, 1);
@@ -1600,6 +1631,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
                        relu, out_mask);
     rc = cpm::check_launch("dgrad epilogue");
   }
+  if (rc == CPM_OK && dx_sp && !sp_in_kernel) rc = split_into(dx, (int64_t)whole.M, a.OCtot, dx_sp, s);
   return rc;
 }
 
@@ -1631,6 +1663,18 @@ CPM_EXPORT int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const f
   CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
   return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, nullptr, 0, (hipStream_t)stream,
                    "cpm_conv2d_backward_data_prepared", in_scale, in_act, true);
+}
+
+CPM_EXPORT int cpm_conv2d_backward_data_sp(const cpm_conv_desc* d, const float* dy, const void* dy_sp, const float* wt,
+                                           const void* wt_sp, float* dx, void* dx_sp, int accumulate,
+                                           const float* in_scale, const float* in_act, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(dy && wt && dx, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
+  CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
+  CPM_REQUIRE(!dx_sp || d->C % 4 == 0, "an SP output needs a multiple of 4 channels");
+  return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, nullptr, 0, (hipStream_t)stream,
+                   "cpm_conv2d_backward_data_sp", in_scale, in_act, true, dy_sp, wt_sp, dx_sp);
 }
 
 CPM_EXPORT int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs, int n, int64_t total_tiles, const float* src_base,

@@ -86,6 +86,17 @@ struct IgemmArgs {
   unsigned in_bytes, wm_bytes;
   int xcd_swizzle;
   int m_base;          // first GEMM row of this launch (rows [m_base, M) are tiled)
+  // split-plane operands (conv_sp.hip): the same tensors stored as bf16 hi / lo planes, [row][2][C] -- per pixel (or per
+  // weight row (oc, tap)) C hi values then C lo values, 4*C bytes like the fp32 row.  Null: fp32 operands only.
+  const void* in_sp;
+  const void* wm_sp;
+  void* out_sp;        // optional: the output written a second time in that format for the consuming convolution
 };
+
+struct Plan { int bm, bn, wm, wn, split; };
+
+// conv_sp.hip: the LDS-DMA kernel for split-plane operands; false when the problem is outside its shape rules
+bool sp_eligible(const IgemmArgs& a);
+int launch_igemm_sp(const IgemmArgs& a, int bm, int bn, hipStream_t s);
 
 }  // namespace cpmconv

@@ -1,0 +1,125 @@
+"""GPU: the split-plane (SP) convolution path -- operands stored as bf16 hi / lo planes, staged by LDS-DMA
+(cpm-r-cnn_amd/csrc/conv_sp.hip) -- against torch-CPU fp32 and against the in-kernel-split bf16x3 path it replaces.
+Both compute a_hi*b_hi + a_hi*b_lo + a_lo*b_hi with fp32 accumulation; the bar is the conv family's 1e-4 of the
+tensor maximum (north_star: 1e-3)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+CL = torch.channels_last
+TOL = 1e-4
+
+
+@pytest.fixture(autouse=True)
+def bf16x3():
+    from pet.lib.ops import _hip
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    yield
+    _hip.set_conv_math(prev)
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def test_split_planes_roundtrip():
+    """hi + lo reproduces the fp32 value to 2^-17 relative; layout [rows][2][C] bf16."""
+    from pet.lib.ops import sp as SP
+    x = rnd(3, 40, 5, 7, seed=1).cuda().contiguous(memory_format=CL)
+    x[0, 0, 0, 0] = 0.0
+    sp = SP.split(x)
+    raw = sp.permute(0, 2, 3, 1).contiguous().view(torch.bfloat16).view(3, 5, 7, 2, 40).float()     # [N,H,W,2,C]
+    xs = x.permute(0, 2, 3, 1)
+    hi, lo = raw[..., 0, :], raw[..., 1, :]
+    assert torch.equal(hi, xs.to(torch.bfloat16).float())
+    assert torch.equal(lo, (xs - hi).to(torch.bfloat16).float())
+    assert float(((hi + lo) - xs).abs().max() / xs.abs().max()) < 2.0 ** -16
+
+
+CASES = [
+    # name, N, C, H, W, K, R, stride, pad, groups
+    ("1x1", 2, 64, 9, 13, 256, 1, 1, 0, 1),
+    ("1x1_s2", 2, 256, 10, 14, 128, 1, 2, 0, 1),
+    ("3x3", 2, 64, 11, 7, 64, 3, 1, 1, 1),
+    ("3x3_wide", 1, 128, 40, 37, 128, 3, 1, 1, 1),
+    ("3x3_s2_grid0", 5, 256, 14, 14, 576, 3, 2, 1, 1),
+    ("3x3_grid", 3, 576, 7, 7, 576, 3, 1, 1, 1),
+    ("fc_as_7x7", 9, 256, 7, 7, 1024, 7, 1, 0, 1),
+    ("grouped16", 2, 64, 8, 8, 128, 3, 1, 1, 4),
+    ("c40_tail", 2, 40, 9, 10, 72, 3, 1, 1, 1),             # C % 32 != 0: the last chunk block is partly masked
+    ("7x7_s2", 1, 32, 20, 24, 64, 7, 2, 3, 1),
+    ("3x3_big", 2, 256, 101, 115, 192, 3, 1, 1, 1),         # many tiles, ragged M and N edges
+    ("1x1_big", 2, 256, 100, 168, 512, 1, 1, 0, 1),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("epi", ["plain", "affine_res_relu"])
+def test_sp_forward_and_dgrad(case, epi):
+    from pet.lib.ops import conv as ops
+    from pet.lib.ops import sp as SP
+    name, N, C, H, W, K, R, stride, pad, groups = case
+    x = rnd(N, C, H, W, seed=1)
+    w = rnd(K, C // groups, R, R, seed=2, scale=1.0 / np.sqrt(C // groups * R * R))
+    P, Q = ops.out_size(H, R, stride, pad), ops.out_size(W, R, stride, pad)
+    scale = shift = res = None
+    relu = False
+    if epi == "affine_res_relu":
+        scale = torch.rand(K, generator=torch.Generator().manual_seed(4)) + 0.5
+        shift, relu = rnd(K, seed=3, scale=0.1), True
+        res = rnd(N, K, P, Q, seed=5)
+    yr = F.conv2d(x, w, None, stride, pad, 1, groups)
+    if scale is not None:
+        yr = F.relu(yr * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    xd, wd = x.cuda().contiguous(memory_format=CL), w.cuda().contiguous(memory_format=CL)
+    cu = lambda t: None if t is None else (t.cuda().contiguous(memory_format=CL) if t.dim() == 4 else t.cuda())
+    x_sp, w_sp = SP.split(xd), SP.split(wd)
+    y = ops.conv2d_forward(xd, wd, cu(scale), cu(shift), cu(res), 0, relu, stride, pad, 1, groups, x_sp=x_sp, w_sp=w_sp,
+                           want_sp=True)
+    assert relerr(y, yr) < TOL, "forward"
+    y_old = ops.conv2d_forward(xd, wd, cu(scale), cu(shift), cu(res), 0, relu, stride, pad, 1, groups)
+    assert relerr(y, y_old) < 2e-5, "SP vs in-kernel split"
+    # the SP twin written by the epilogue == the split of y
+    if K % 4 == 0:
+        assert torch.equal(y._cpm_sp, SP.split(y)), "epilogue SP output"
+    # data gradient on the prepared weight image
+    dy = rnd(N, K, P, Q, seed=6)
+    xr = x.clone().requires_grad_(True)
+    F.conv2d(xr, w, None, stride, pad, 1, groups).backward(dy)
+    dyd = dy.cuda().contiguous(memory_format=CL)
+    kg, cg = K // groups, C // groups
+    wt = wd.reshape(groups, kg, cg, R * R).permute(0, 2, 3, 1).contiguous()        # [g][c][tap][k]
+    wt2 = wt.reshape(groups * cg * R * R, kg)
+    wt_sp = SP.split(wt2)
+    dx = ops.conv2d_backward_data_sp(dyd, SP.split(dyd), wt2, wt_sp, (N, C, H, W), tuple(w.shape), stride, pad, 1,
+                                     groups, want_sp=True)
+    assert relerr(dx, xr.grad) < TOL, "dgrad"
+    if C % 4 == 0 and getattr(dx, "_cpm_sp", None) is not None:
+        assert torch.equal(dx._cpm_sp, SP.split(dx)), "dgrad SP output"
+    # accumulate: dx += ...
+    acc = dx.clone()
+    ops.conv2d_backward_data_sp(dyd, SP.split(dyd), wt2, wt_sp, (N, C, H, W), tuple(w.shape), stride, pad, 1, groups,
+                                accumulate_into=acc)
+    assert relerr(acc, 2 * xr.grad) < TOL, "dgrad accumulate"
+
+
+def test_sp_missing_twin_falls_back_to_in_kernel_split():
+    """x_sp / w_sp are accelerators, never requirements: without them (or for shapes outside the DMA kernel's rules)
+    the same entry point gives the same result through the in-kernel split."""
+    from pet.lib.ops import conv as ops
+    from pet.lib.ops import sp as SP
+    x, w = rnd(2, 36, 9, 9, seed=1), rnd(20, 36, 3, 3, seed=2, scale=0.1)          # C % 8 != 0, K <= 32
+    xd, wd = x.cuda().contiguous(memory_format=CL), w.cuda().contiguous(memory_format=CL)
+    y = ops.conv2d_forward(xd, wd, None, None, None, 0, False, 1, 1, 1, 1, x_sp=SP.split(xd), w_sp=SP.split(wd),
+                           want_sp=True)
+    assert relerr(y, F.conv2d(x, w, None, 1, 1)) < TOL
+    assert torch.equal(y._cpm_sp, SP.split(y))

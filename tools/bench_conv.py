@@ -59,15 +59,20 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--filter", default="")
     ap.add_argument("--iters", type=int, default=10)
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3"])
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "sp"],
+                    help="sp = bf16x3 arithmetic on pre-split (split-plane) operands, LDS-DMA kernel")
     a = ap.parse_args()
     from pet.lib.ops import _hip
+    from pet.lib.ops import sp as SP
+    use_sp = a.math == "sp"
+    if use_sp:
+        a.math = "bf16x3"
     _hip.set_conv_math(a.math)
     tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
     print("%-20s %9s | %8s %7s | %8s %7s | %8s %7s" % ("layer", "GFLOP", "fwd us", "TF/s", "dgrad us", "TF/s",
                                                        "wgrad us", "TF/s"))
     for name, N, C, H, W, K, R, st, pad, g, cnt in LAYERS:
-        if a.filter and a.filter not in name:
+        if a.filter and not any(f in name for f in a.filter.split(",")):
             continue
         x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=CL)
         w = (torch.randn(K, C // g, R, R, device="cuda") * 0.05).contiguous(memory_format=CL)
@@ -76,17 +81,31 @@ def main():
         dw = torch.zeros_like(w)
         gf = 2.0 * N * P * Q * K * R * R * (C // g) / 1e9
         err = ""
+        fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g)
+        dgr = lambda: ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g)
+        if use_sp:
+            x_sp, w_sp, dy_sp = SP.split(x), SP.split(w), SP.split(dy)
+            kg, cg = K // g, C // g
+            wt = w.reshape(g, kg, cg, R * R).permute(0, 2, 3, 1).contiguous().reshape(g * cg * R * R, kg)
+            wt_sp = SP.split(wt)
+            fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g, x_sp=x_sp, w_sp=w_sp,
+                                             want_sp=True)
+            dgr = lambda: ops.conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, (N, C, H, W), tuple(w.shape), st, pad, 1, g,
+                                                      want_sp=True)
         if a.math != "f32":
-            y1 = ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g)
-            d1 = ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g)
+            y1 = fwd()
+            d1 = dgr()
             _hip.set_conv_math("f32")
             y0 = ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g)
             d0 = ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g)
             _hip.set_conv_math(a.math)
             err = "  err fwd %.1e dgrad %.1e" % (float((y1 - y0).abs().max() / y0.abs().max()),
                                                float((d1 - d0).abs().max() / d0.abs().max()))
-        t_f = timeit(lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g), a.iters)
-        t_d = timeit(lambda: ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g), a.iters)
+        t_f = timeit(fwd, a.iters)
+        t_d = timeit(dgr, a.iters)
+        if use_sp:
+            err += "  split x %.1f us dy %.1f us" % (timeit(lambda: SP.split(x), a.iters) * 1e3,
+                                                     timeit(lambda: SP.split(dy), a.iters) * 1e3)
         t_w = timeit(lambda: ops.conv2d_backward_weight(x, dy, w, st, pad, 1, g, out=dw), a.iters)
         print("%-20s %9.1f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (
             name, gf, t_f * 1e3, gf / t_f, t_d * 1e3, gf / t_d, t_w * 1e3, gf / t_w) + err)
