@@ -321,6 +321,20 @@ def gen_x101_meta():
     print("x101:", len(meta["state_dict"]), "keys,", len(meta["trainable"]), "trainable")
 
 
+def gen_r101_meta():
+    """State-dict ABI of BASELINE config #4 (R-101-FPN CPM R-CNN): names, shapes, trainable set."""
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/backbone/"
+             "e2e_grid_cascade@567_rcnn_R-101-FPN_2x.yaml").DEVICE = "cpu"
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True), merge=True)
+    meta = {"state_dict": [[k, list(v.shape)] for k, v in model.state_dict().items()],
+            "trainable": [k for k, p in model.named_parameters() if p.requires_grad]}
+    with open(os.path.join(HERE, "model_r101_meta.json"), "w") as f:
+        json.dump(meta, f)
+    print("r101:", len(meta["state_dict"]), "keys,", len(meta["trainable"]), "trainable")
+
+
 def gen_cascade():
     """Offset-regression Cascade R-CNN with ISM + RSM (cfgs/rcnn/mscoco/cascade/ISM+RSM): state-dict ABI,
     the RoI head in evaluation mode (decode / refine / ensemble / IoU-merged scores) and in training mode on a
@@ -834,6 +848,8 @@ def main():
     install_standins(ref_ext)
     if sys.argv[1:] == ["x101"]:
         return gen_x101_meta()
+    if sys.argv[1:] == ["r101"]:
+        return gen_r101_meta()
     if sys.argv[1:] == ["data"]:
         return gen_data_pipeline()
     if sys.argv[1:] == ["cascade"]:

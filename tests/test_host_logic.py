@@ -248,6 +248,22 @@ def test_x101_dcn_state_dict_abi(cpm_cfg):
                for m in packs)                                    # resnext.py:248-252
 
 
+def test_r101_state_dict_abi(cpm_cfg):
+    """BASELINE config #4 (R-101-FPN, LAYERS (3, 4, 23, 3)): every key / shape and the trainable set equal the
+    reference's (tests/golden/model_r101_meta.json, dumped from the reference model by make_golden.py r101)."""
+    import json
+    from conftest import ROOT
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    config.merge_cfg_from_list(["BACKBONE.RESNET.LAYERS", (3, 4, 23, 3)])
+    meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_r101_meta.json")))
+    model = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+    assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == meta["state_dict"]
+    assert [k for k, p in model.named_parameters() if p.requires_grad] == meta["trainable"]
+    assert len(meta["state_dict"]) == 471 and len(meta["trainable"]) == 247
+
+
 def test_balanced_sample_quotas_oracle():
     """oracle/pyoracle.py balanced_sample_quotas against hand-worked cases of
     pet/rcnn/utils/balanced_positive_negative_sampler.py:36-46 (the GPU test checks cpm_sample_pos_neg against it)."""
