@@ -378,6 +378,9 @@ class _ConvFn(Function):
                 _sink_done(getattr(wp, "_cpm_owner", wp))
             else:
                 dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, dbias=dbias)
+                if wp is not None:                      # this use reaches the parameter through autograd's accumulation
+                    own = getattr(wp, "_cpm_owner", wp)
+                    own._cpm_uses -= 1
             if fuse_bias and ctx.bparam is not None:
                 _sink_done(ctx.bparam)                  # accumulated in place
         return dx, dw, None, dshift, gres, None, None, None, None, None, None, None

@@ -106,6 +106,8 @@ class _ColsConvFn(Function):
                     if ready is not None:
                         ready(wp)
             else:
+                if wp is not None:                      # this use reaches the parameter through autograd's accumulation
+                    wp._cpm_uses -= 1
                 dw1 = F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups)
                 k, cg = w.shape[0], w.shape[1]
                 dw = dw1.view(k, r, s, cg).permute(0, 3, 1, 2)

@@ -39,6 +39,7 @@ class FlatGradReducer(object):
         self.overlap = overlap and self.world > 1 and self.flat.is_cuda
         self.stream = torch.cuda.Stream(device=self.flat.device) if self.overlap else None
         self._pending = None
+        self._done = set()
         self._handles = []
         if self.overlap:
             params = [p for g in optimizer.param_groups for p in g["params"]]
@@ -51,13 +52,22 @@ class FlatGradReducer(object):
             for p in by_id.values():
                 off = (p.grad.data_ptr() - base) // 4
                 ci = next(i for i, (b, e, _) in enumerate(self.chunks) if b <= off < e)
-                hook = self._make_hook(ci)
+                hook = self._make_hook(ci, p)
                 p.register_post_accumulate_grad_hook(hook)
                 if hasattr(p, "_cpm_grad_sink"):
                     p._cpm_grad_ready = hook        # conv weights bypass autograd's accumulation (pet.lib.ops.conv)
 
-    def _make_hook(self, ci):
-        def hook(_):
+    def _make_hook(self, ci, p):
+        """A parameter's gradient is complete either when autograd has accumulated it (post-accumulate hook) or when
+        the last in-place use of the step has been queued by a HIP backward kernel (`_cpm_grad_ready`, called by
+        pet.lib.ops.conv when the parameter's use count returns to 0).  Both routes can fire for one parameter in one
+        step: torch runs the post-accumulate hooks of a leaf even when the Function handed it no gradient (the sink
+        route returns None), and for a weight used twice it does so after the FIRST of the two backward calls.  So: an
+        event counts only when no in-place use is outstanding, and only once per step."""
+        def hook(_=None):
+            if self._pending is None or id(p) in self._done or getattr(p, "_cpm_uses", 0) > 0:
+                return
+            self._done.add(id(p))
             assert self._pending[ci] > 0, "gradient-ready hook fired more often than chunk %d has tensors" % ci
             self._pending[ci] -= 1
             # chunks are reduced strictly in buffer order on every rank -- a collective must be issued in the same
@@ -70,6 +80,7 @@ class FlatGradReducer(object):
 
     def begin_step(self):
         self._pending = [n for (_, _, n) in self.chunks]
+        self._done = set()
         self._next = 0
         self._handles = []
 

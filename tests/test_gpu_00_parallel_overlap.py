@@ -1,0 +1,66 @@
+"""GPU: the data-parallel overlap path of pet/utils/parallel.py on real device tensors.
+
+Two fresh child ranks (gloo backend, both on GPU 0) run a small network of the package's conv / GroupNorm / Linear
+modules -- the Linear applied twice per step -- with the flat optimizer and FlatGradReducer(overlap=True): post-
+accumulate hooks + the HIP kernels' in-place gradient sinks trigger chunk all-reduces on a side stream during
+backward.  Checked: the reduced flat gradient equals the sum of the two ranks' local gradients, chunks are launched
+in the same (buffer) order on both ranks, every parameter's ready hook fires exactly once per step, and the ranks
+start from rank 0's weights although they were initialised differently (broadcast_initial_state).
+
+The file name sorts first among the GPU tests on purpose: the children are started from a parent that has not
+initialised the GPU yet (the pool forbids exec from a GPU-initialised process)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
+    import torch
+    if torch.cuda.is_initialized():
+        pytest.skip("must start its child ranks before this process touches the GPU (run the file on its own)")
+    port = str(_free_port())
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs, outs = [], []
+    for r in range(2):
+        out = str(tmp_path / ("rank%d.json" % r))
+        outs.append(out)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "parallel_overlap_worker.py"), str(r), "2",
+                                       port, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            o, _ = p.communicate()
+        logs.append(o.decode(errors="replace")[-2000:])
+    res = []
+    for out, log in zip(outs, logs):
+        assert os.path.exists(out), log
+        with open(out) as f:
+            res.append(json.load(f))
+    for r in res:
+        assert r["ok"], r.get("error")
+        assert r["overlap"] and r["same_start"] and r["nonzero"]
+        assert r["err"] < 1e-4 and r["err_first"] < 1e-4, r          # float-atomic order between two backward passes
+        assert r["ready_fires_per_param_max"] == 2                    # once per step, two steps (Linear used twice)
+        assert r["fc_uses_after"] == 0
+        assert r["launched_in_backward"] >= 1                         # at least one chunk went out before finish()
+    assert res[0]["order"] == res[1]["order"]
+    per_step = res[0]["chunks"]
+    assert res[0]["order"] == list(range(per_step)) * 2               # buffer order, every step
