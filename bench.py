@@ -255,43 +255,66 @@ def hbm_kernel_rooflines(device, batch, h, w, rois_per_head):
             for k, (b, t) in out.items()]
 
 
-def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3)):
-    """oracle/cpu_model.py on the host cores: forward+backward conv/FC/RoIAlign work of one training iteration
-    for ONE image (bounded sample), RoI counts = this run's per-image averages."""
-    from oracle import cpu_model as M
+def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3), batch=2):
+    """oracle/cpu_pipeline.py on the host cores, a bounded sample of the SAME workload:
+    (b) whole training iterations at this run's batch size -- backbone / FPN / RPN, proposal NMS, matching, sampling,
+        cls head, three grid stages with rasterised targets and the grid decoder, ISM, RSM, backward; torch-CPU fp32
+        convs + the C oracle (RoIAlign, NMS, matcher, targets, decoder);
+    (a) BASELINE config #1: forward-only inference, the images as separate forwards (the reference's test path is one
+        image per forward), including multi-label NMS and the ISM / RSM re-scoring."""
+    import numpy as np
+    from oracle import cpu_pipeline as P
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
     cores = max(1, min(cores, 16))             # the GPU box's CPU share for one GPU is 16 cores
     torch.set_num_threads(cores)
-    sd = {k: v.detach().float().cpu().contiguous().clone().requires_grad_(v.requires_grad and v.dtype.is_floating_point)
-          for k, v in trainer.model.state_dict(keep_vars=True).items() if "cell_anchors" not in k}
-    counts = trainer.model.Grid_Cascade_RCNN.last_counts
-    gen = torch.Generator().manual_seed(seed)
-    hp = (h + 31) // 32 * 32
-    wp = (w + 31) // 32 * 32
-    img = torch.rand(1, 3, hp, wp, generator=gen) * 255 - 110
 
-    def rois(k):
-        k = max(int(k), 1)
-        x1, y1 = torch.rand(k, generator=gen) * (w - 64), torch.rand(k, generator=gen) * (h - 64)
-        bw, bh = torch.rand(k, generator=gen) * 300 + 32, torch.rand(k, generator=gen) * 300 + 32
-        return torch.stack([torch.zeros(k), x1, y1, (x1 + bw).clamp(max=w - 1), (y1 + bh).clamp(max=h - 1)], 1)
-
-    per_img = {k: v / 2 for k, v in counts.items()}
-    args = (rois(per_img.get("cls", 512)), [rois(per_img.get("grid_%d" % s, 16)) for s in range(3)],
-            rois(per_img.get("rescore", 512)))
-    M.train_step_compute(sd, img, *args, layers=layers)             # untimed warm-up (allocator, oneDNN primitives)
-    n, t0 = 0, time.time()
-    while n < 3 or (time.time() - t0 < 12.0 and n < 12):
-        M.train_step_compute(sd, img, *args, layers=layers)
+    def state(grad):
+        sd = {}
+        for k, v in trainer.model.state_dict(keep_vars=True).items():
+            if "cell_anchors" in k:
+                continue
+            t = v.detach().float().cpu().contiguous().clone()
+            if t.dim() == 4 and (k.endswith("fc6.weight") or k.endswith("iou_fc1.weight")):
+                t = t.reshape(t.shape[0], -1)
+            sd[k] = t.requires_grad_(grad and v.requires_grad and v.dtype.is_floating_point)
+        return sd
+    rng = np.random.default_rng(seed)
+    hp, wp = (h + 31) // 32 * 32, (w + 31) // 32 * 32
+    images = torch.zeros(batch, 3, hp, wp)
+    images[:, :, :h, :w] = torch.from_numpy((rng.uniform(0, 255, (batch, 3, h, w)) - 110).astype(np.float32))
+    gts, labels = [], []
+    for _ in range(batch):
+        bw, bh = rng.uniform(32, 400, 16), rng.uniform(32, 400, 16)
+        x1, y1 = rng.uniform(0, w - 33, 16), rng.uniform(0, h - 33, 16)
+        gts.append(np.stack([x1, y1, np.minimum(x1 + bw, w - 1), np.minimum(y1 + bh, h - 1)], 1).astype(np.float32))
+        labels.append(rng.integers(1, 81, 16))
+    sd = state(True)
+    P.train_step(sd, images, gts, labels, rng, layers)            # untimed warm-up (allocator, oneDNN primitives)
+    n, t0, counts = 0, time.time(), None
+    while n < 2 or (time.time() - t0 < 14.0 and n < 6):
+        for t in sd.values():
+            t.grad = None
+        _, counts = P.train_step(sd, images, gts, labels, rng, layers)
         n += 1
     dt = (time.time() - t0) / n
-    return {"value": round(1.0 / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
-            "sample": "%d timed iterations (after 1 warm-up) of 1 image (bs=1): forward+backward of the "
-                      "conv/FC/RoIAlign stacks, RoIs per image: %s; torch-CPU fp32 convs + C-oracle RoIAlign; "
-                      "%.2f s per iteration" % (n, {k: int(v) for k, v in per_img.items()}, dt)}
+    sd = state(False)
+    P.infer_image(sd, images[:1], layers)
+    m, t1 = 0, time.time()
+    while m < batch or (time.time() - t1 < 6.0 and m < 3 * batch):
+        P.infer_image(sd, images[m % batch:m % batch + 1], layers)
+        m += 1
+    di = (time.time() - t1) / m
+    return {"value": round(batch / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
+            "sample": "%d timed training iterations (after 1 warm-up) at bs=%d, %dx%d: forward + backward of the whole "
+                      "model incl. proposal NMS, matching / sampling, grid targets, grid decoder, ISM, RSM; RoIs %s; "
+                      "torch-CPU fp32 convs + the C oracle; %.2f s per iteration" % (n, batch, h, w, counts, dt),
+            "forward_only_config1": {"value": round(1.0 / di, 4), "unit": "img/s", "what": "BASELINE config #1: "
+                                     "test-time forward, one image per forward (%d forwards after 1 warm-up, %.2f s "
+                                     "each): RPN 1000 proposals, cls head, multi-label NMS, 3 grid stages, ISM, RSM"
+                                     % (m, di)}}
 
 
 def main():
@@ -317,6 +340,9 @@ def main():
     ap.add_argument("--host-input", action="store_true", help="extra leg (N=1): every step starts from decoded uint8 "
                     "images in HOST memory (480x800) -> one pinned copy + cpm_image_prep -> train step; reported as "
                     "config.host_input (the PCIe-inclusive rate); `value` stays the HBM-resident number")
+    ap.add_argument("--no-full-rois", action="store_true", help="skip the worst-case-workload leg: 96 gt boxes per "
+                    "image, which fill the 96-positives-per-image cap of every grid stage (>= 192 RoIs per stage at "
+                    "bs=2, the RoI counts BASELINE.md's 6.3 TFLOP/step model assumes); reported as config.full_rois")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
                     "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
@@ -396,6 +422,33 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_other = float(t.item())
         _hip.set_conv_math(a.conv_math)
+    full_rois = None
+    if not a.no_full_rois and a.body == "resnet":
+        # every rank takes part (the gradient all-reduce is collective)
+        f_images, f_targets = synthetic_batch(a.batch, a.height, a.width, 96, 5678 + rank, device)
+        for _ in range(2):
+            trainer.step(f_images, f_targets)
+        sync()
+        k_f = max(1, min(a.steps, 8))
+        t1 = time.perf_counter()
+        for _ in range(k_f):
+            trainer.step(f_images, f_targets)
+        sync()
+        el_f = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el_f], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_f = float(t.item())
+        f_counts = dict(trainer.model.Grid_Cascade_RCNN.last_counts)
+        f_roof = conv_roofline(trainer, f_images, f_targets, steps=1, math=a.conv_math) if not a.no_roofline else None
+        full_rois = {"img_per_s": round(a.batch * world * k_f / el_f, 3), "ms_per_step": round(1000.0 * el_f / k_f, 2),
+                     "steps": k_f, "gt_boxes_per_image": 96, "roi_counts_last_step": f_counts,
+                     "conv_gflop_per_step": None if f_roof is None else round(
+                         sum(v["gflop"] for v in f_roof["per_step"].values()), 1),
+                     "conv_tflops": None if f_roof is None else f_roof["all_conv_kernels"]["tflops"]}
+        for _ in range(2):
+            trainer.step(images, targets)
+        sync()
     host_input = None
     if a.host_input and world == 1:
         from pet.utils.data.collate_batch import DeferredBatch
@@ -433,8 +486,8 @@ def main():
     if not a.no_roofline and rank == 0:
         hbm = hbm_kernel_rooflines(device, a.batch, a.height, a.width, counts.get("cls", 512 * a.batch))
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.body == "resnet":
-        cpu = cpu_baseline(trainer, a.height, a.width, 99, layers)   # (the scalar deformable-conv oracle is too
-        #                                                              slow to be a bounded sample for x101dcn)
+        cpu = cpu_baseline(trainer, a.height, a.width, 99, layers, a.batch)   # (the scalar deformable-conv oracle is
+        #                                                              too slow to be a bounded sample for x101dcn)
 
     if rank == 0:
         n_img = a.batch * world * a.steps
@@ -457,6 +510,7 @@ def main():
                            "ms_per_step": round(1000.0 * el_other / k_other, 2), "steps": k_other},
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        **({"host_input": host_input} if host_input else {}),
+                       **({"full_rois": full_rois} if full_rois else {}),
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,

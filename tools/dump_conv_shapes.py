@@ -18,10 +18,10 @@ def load(path, steps=2):
 
 def main():
     tabs = [load(p) for p in sys.argv[1:]]
-    keys = sorted(tabs[0], key=lambda k: -tabs[0][k][1])[:40]
+    keys = sorted(tabs[0], key=lambda k: -tabs[0][k][1])[:60]
     kinds = {"0": "fwd", "1": "dgrad", "2": "wgrad"}
     for k in keys:
-        cols = ["%7.3f" % t[k][1] if k in t else "   -   " for t in tabs]
+        cols = ["%7.3f ms %6.1f TF" % (t[k][1], t[k][2]) if k in t else "   -   " for t in tabs]
         print("%-5s %-34s x%-4.1f %s" % (kinds[k[0]], " ".join(k[1:]), tabs[0][k][0], " ".join(cols)))
     print("total", ["%.2f" % sum(v[1] for v in t.values()) for t in tabs])
 
