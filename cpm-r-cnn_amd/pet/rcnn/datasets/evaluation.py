@@ -1,8 +1,8 @@
 """Detections -> COCO result records and their evaluation (counterpart of pet/rcnn/datasets/evaluation.py:21-153, box
 part).  `post_processing` maps the boxes of a batch back to the original image sizes and emits COCO json records;
-`evaluation` writes `<CKPT>/test/bbox.json` and, when pycocotools is importable, runs its COCOeval on it (the
-reference evaluates with its own copy of that class, mycocoeval.py, over pycocotools' C mask/IoU code -- neither is a
-dependency of this tree, so without pycocotools the records are written and the scoring is skipped with a notice)."""
+`evaluation` writes `<CKPT>/test/bbox.json` and scores it with pet.rcnn.datasets.cocoeval (the published COCOeval
+algorithm restated in numpy: the reference evaluates with its own copy of that class, mycocoeval.py, over pycocotools'
+compiled IoU code, and pycocotools is absent from the reference tree and from this image)."""
 import json
 import logging
 import os
@@ -52,18 +52,10 @@ def evaluation(dataset, all_boxes, *unused):
     with open(path, "w") as f:
         json.dump(all_boxes, f)
     _log.info("Wrote %d detections to %s", len(all_boxes), path)
-    try:
-        from pycocotools.coco import COCO
-        from pycocotools.cocoeval import COCOeval
-    except ImportError:
-        _log.warning("pycocotools is not installed: detections written, COCO scoring skipped")
-        return None, {"bbox": all_boxes}
+    from pet.rcnn.datasets.cocoeval import evaluate_boxes
     ann_file = getattr(dataset, "ann_file", None)
-    gt = COCO(ann_file)
-    dt = gt.loadRes(path) if all_boxes else COCO()
-    ev = COCOeval(gt, dt, "bbox")
-    ev.evaluate()
-    ev.accumulate()
-    ev.summarize()
-    names = ["AP", "AP50", "AP75", "APs", "APm", "APl"]
-    return {"bbox": dict(zip(names, (float(v) for v in ev.stats[:6])))}, {"bbox": all_boxes}
+    with open(ann_file) as f:
+        gt = json.load(f)
+    stats = evaluate_boxes(gt, all_boxes)
+    _log.info("bbox: %s", ", ".join("%s %.4f" % kv for kv in stats.items()))
+    return {"bbox": dict(stats)}, {"bbox": all_boxes}
