@@ -295,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN)
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
   const bool dense_rows = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
-  if (a.res && !a.atomic_out) {
+  if ((a.res || a.staged_epi) && !a.atomic_out) {
     // Residual epilogue (bottleneck conv3, FPN laterals): memory bound on thin reductions.  Stage the tile through
     // LDS (the operand buffers are free after the last barrier) and finish it row-wise with 16-byte accesses, so
     // that the residual reads and the stores are whole 512-byte rows instead of 4-byte column slices.
@@ -323,6 +323,57 @@ __global__ __launch_bounds__(64 * WM * WN)
           if (a.scale) scp[k] = a.scale[oc + k];
           if (a.shift) shp[k] = a.shift[oc + k];
         }
+    }
+    if (vec_out) {
+      // Rows in groups of UNR: the group's residual reads are issued together, THEN the tile values are finished and
+      // stored.  One row at a time every residual read sat behind the previous row's store (the compiler cannot move a
+      // load above a store that may alias it -- and in the accumulating data gradient res IS out), so a 128-row tile
+      // paid 16 dependent memory round trips; on the thin 1x1 layers (2-8 k-steps) that was most of the workgroup's life.
+      constexpr int UNR = (BM / RPS) >= 4 ? 4 : (BM / RPS);
+      for (int rb = r0; rb < BM; rb += RPS * UNR) {
+        float4 rv[UNR], gv[UNR];
+        size_t oo[UNR];
+        bool ok[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          const int r = rb + u * RPS, m = m0 + r;
+          ok[u] = r < BM && m < a.M;
+          const int mm = ok[u] ? m : m0;
+          int orow = mm, oh = 0, ow = 0, n = 0;
+          if (!dense_rows || a.res_mode == 1) {
+            const int jj = mm % a.OWp, t = mm / a.OWp;
+            const int ii = t % a.OHp;
+            n = t / a.OHp;
+            oh = ii * a.osh + a.oah;
+            ow = jj * a.osw + a.oaw;
+            orow = (n * a.OH + oh) * a.OW + ow;
+          }
+          oo[u] = (size_t)orow * a.OCtot + oc;
+          rv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+          gv[u] = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (a.res && ok[u]) {
+            const float* rp = a.res_mode == 0
+                                  ? a.res + oo[u]
+                                  : a.res + ((size_t)(n * ((a.OH + 1) / 2) + oh / 2) * ((a.OW + 1) / 2) + ow / 2) * a.OCtot + oc;
+            rv[u] = *(const float4*)rp;
+          }
+          if (a.mask && ok[u]) gv[u] = *(const float4*)(a.mask + oo[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          if (!ok[u]) continue;
+          float4 v = *(const float4*)&Cs[rb + u * RPS][cv];
+          v.x = v.x * sc.x + sh.x + rv[u].x; v.y = v.y * sc.y + sh.y + rv[u].y;
+          v.z = v.z * sc.z + sh.z + rv[u].z; v.w = v.w * sc.w + sh.w + rv[u].w;
+          if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          if (a.mask) {
+            v.x = gv[u].x > 0.f ? v.x : 0.f; v.y = gv[u].y > 0.f ? v.y : 0.f;
+            v.z = gv[u].z > 0.f ? v.z : 0.f; v.w = gv[u].w > 0.f ? v.w : 0.f;
+          }
+          *(float4*)(a.out + oo[u]) = v;
+        }
+      }
+      return;
     }
     for (int r = r0; r < BM; r += RPS) {
       const int m = m0 + r;
@@ -354,7 +405,9 @@ __global__ __launch_bounds__(64 * WM * WN)
         float* vp = &v.x;
         for (int k = 0; k < 4 && ocl + k < a.OCg; ++k) {
           float o = vp[k] + (rp ? rp[k] : 0.f);
-          dst[k] = a.relu ? fmaxf(o, 0.f) : o;
+          if (a.relu) o = fmaxf(o, 0.f);
+          if (a.mask) o = a.mask[(size_t)orow * a.OCtot + oc + k] > 0.f ? o : 0.f;
+          dst[k] = o;
         }
       }
     }
@@ -1401,6 +1454,8 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
   static const int tail_split = env_int("CPM_IGEMM_TAIL", 1);
   a.xcd_swizzle = swz;
   a.m_base = 0;
+  static const int staged = env_int("CPM_IGEMM_STAGED_EPI", 0);   // measured: no gain without a residual (direct stores)
+  a.staged_epi = staged;
   ProfScope prof_scope(s, prof_kind);
   static const int use_halo = env_int("CPM_IGEMM_HALO", 1);
   if (use_halo && !(g_conv_split && sp_eligible(a)) && g_conv_split && vec && a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 &&

@@ -10,7 +10,7 @@ import threading
 import torch
 
 _PKG_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-LIB_PATH = os.path.join(_PKG_ROOT, "lib", "libcpmrcnn_hip.so")
+LIB_PATH = os.environ.get("CPM_LIB") or os.path.join(_PKG_ROOT, "lib", "libcpmrcnn_hip.so")   # CPM_LIB: A/B builds
 _lib = None
 _lock = threading.Lock()
 

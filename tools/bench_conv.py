@@ -59,6 +59,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--filter", default="")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--epi", default="plain", choices=["plain", "res"], help="res: forward with frozen affine + residual "
+                    "+ ReLU (bottleneck conv3), data gradient accumulating into an existing tensor")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "sp"],
                     help="sp = bf16x3 arithmetic on pre-split (split-plane) operands, LDS-DMA kernel")
     a = ap.parse_args()
@@ -83,6 +85,12 @@ def main():
         err = ""
         fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g)
         dgr = lambda: ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g)
+        if a.epi == "res":
+            sc, sh = torch.rand(K, device="cuda") + 0.5, torch.randn(K, device="cuda")
+            res = torch.randn_like(dy)
+            acc = torch.zeros_like(x)
+            fwd = lambda: ops.conv2d_forward(x, w, sc, sh, res, 0, True, st, pad, 1, g)
+            dgr = lambda: ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g, accumulate_into=acc)
         if use_sp:
             x_sp, w_sp, dy_sp = SP.split(x), SP.split(w), SP.split(dy)
             kg, cg = K // g, C // g
@@ -92,7 +100,7 @@ def main():
                                              want_sp=True)
             dgr = lambda: ops.conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, (N, C, H, W), tuple(w.shape), st, pad, 1, g,
                                                       want_sp=True)
-        if a.math != "f32":
+        if a.math != "f32" and a.epi == "plain":
             y1 = fwd()
             d1 = dgr()
             _hip.set_conv_math("f32")
