@@ -464,7 +464,8 @@ __global__ __launch_bounds__(64 * WM * WN)
         float v = acc[i][j][e];
         float* dst = a.out + (size_t)orow * a.OCtot + oc;
         if (a.atomic_out) {
-          atomicAdd(dst, v);
+          if (a.slab) a.slab[(size_t)split * a.slab_stride + (size_t)orow * a.OCtot + oc] = v;
+          else atomicAdd(dst, v);
         } else {
           if (a.scale) v *= e_sc[j];
           if (a.shift) v += e_sh[j];
@@ -746,6 +747,49 @@ __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict
   }
 }
 
+// split-K, slab form: out[m][oc] = epilogue( (acc ? out : 0) + slab[0] + slab[1] + ... ) in split order -- one pass
+// instead of zero-fill + float atomics + epilogue pass, and bit-reproducible
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, int splits, size_t stride,
+                                                            float* __restrict__ out, int accumulate,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift,
+                                                            const float* __restrict__ res, int64_t M, int OC, int OH,
+                                                            int OW, int res_mode, int relu,
+                                                            const float* __restrict__ mask) {
+  const int64_t total4 = M * OC / 4;                      // OC % 4 == 0 (host)
+  for (int64_t i4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t idx = i4 * 4;
+    float4 v = *(const float4*)(slab + idx);
+    for (int s = 1; s < splits; ++s) {
+      const float4 t = *(const float4*)(slab + (size_t)s * stride + idx);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (accumulate) { const float4 o = *(const float4*)(out + idx); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    const int oc = (int)(idx % OC);
+    const int64_t m = idx / OC;
+    if (scale) { const float4 t = *(const float4*)(scale + oc); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+    if (shift) { const float4 t = *(const float4*)(shift + oc); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+    if (res) {
+      int64_t ri = idx;
+      if (res_mode == 1) {
+        const int ow = (int)(m % OW);
+        const int64_t t = m / OW;
+        const int oh = (int)(t % OH);
+        const int64_t n = t / OH;
+        ri = ((n * ((OH + 1) / 2) + oh / 2) * ((OW + 1) / 2) + ow / 2) * OC + oc;
+      }
+      const float4 t = *(const float4*)(res + ri);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    if (mask) {
+      const float4 t = *(const float4*)(mask + idx);
+      v.x = t.x > 0.f ? v.x : 0.f; v.y = t.y > 0.f ? v.y : 0.f; v.z = t.z > 0.f ? v.z : 0.f; v.w = t.w > 0.f ? v.w : 0.f;
+    }
+    *(float4*)(out + idx) = v;
+  }
+}
+
 // split-K accumulator seeded with the bias: out[m][oc] = shift[oc] -- when the epilogue is the bias alone (conv + bias
 // feeding a GroupNorm: the grid head), this replaces BOTH the zero fill before the atomics and the epilogue pass after
 __global__ void __launch_bounds__(256) seed_rows_kernel(float* __restrict__ out, const float* __restrict__ shift,
@@ -841,6 +885,11 @@ struct WgradArgs {
   int R, S, stride, pad, dil, groups, Cg, OCg, M;
   int split_k, chunks;  // chunks = ceil(M/32)
   unsigned x_bytes, dy_bytes;
+  int debug_nostore;
+  float* slab;      // split_k > 1: [split][OCtot][R][S][Cg] partial sums, one plane per reduction split, written with
+                    // plain stores and folded into dw in split order by wgrad_reduce_kernel (deterministic; the
+                    // float-atomic epilogue it replaces cost 23 % of the weight-gradient time).  null: see the epilogues
+  size_t slab_stride;   // floats per plane
   float* dshift;    // [OCtot] or null: += sum over pixels of dy (the bias gradient), folded into the dy reads of the
                     // workgroups that own tap 0 / input-channel tile 0 (every dy element passes exactly one of them)
 };
@@ -1027,7 +1076,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
       for (int e = 0; e < 16; ++e) {
         const int ocl = oc0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
         if (ocl >= a.OCg) continue;
-        atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl, acc[i][j][e]);
+        const size_t o = ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl;
+        if (a.slab) a.slab[(size_t)split * a.slab_stride + o] = acc[i][j][e];      // this split's plane
+        else if (a.split_k == 1) a.dw[o] += acc[i][j][e];                           // the element's only writer
+        else atomicAdd(a.dw + o, acc[i][j][e]);
       }
   }
 }
@@ -1232,11 +1284,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   __syncthreads();
+  if (a.debug_nostore) return;
+  if (a.slab || a.split_k == 1) {
+    // plain 16-byte accesses: into this split's slab plane, or (a single split: the tile's only writer) added to dw
+    float* const base = a.slab ? a.slab + (size_t)split * a.slab_stride : a.dw;
+    for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+      const int row = idx / (BN / 4), col = (idx - row * (BN / 4)) * 4;
+      const int ocl = oc0 + row, cl = c0 + col;
+      if (ocl >= a.OCg || cl >= a.Cg) continue;
+      float* p = base + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl;
+      float4 v = *(const float4*)&Cs[row][col];
+      if (cl + 3 < a.Cg) {                                   // Cg % 4 == 0 on this kernel (wvec)
+        if (!a.slab) { const float4 o = *(const float4*)p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *(float4*)p = v;
+      }
+    }
+    return;
+  }
   for (int idx = tid; idx < BM * BN; idx += 256) {
     const int row = idx / BN, col = idx - row * BN;
     const int ocl = oc0 + row, cl = c0 + col;
     if (ocl < a.OCg && cl < a.Cg)
       atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl, Cs[row][col]);
+  }
+}
+
+// dw += slab[0] + slab[1] + ... in split order (fixed association: bit-reproducible weight gradients)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t stride,
+                                                           int64_t n, float* __restrict__ dw) {
+  const int64_t n4 = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 acc = ((const float4*)slab)[i];
+    for (int s = 1; s < splits; ++s) {
+      const float4 v = *(const float4*)(slab + (size_t)s * stride + 4 * i);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4 o = ((float4*)dw)[i];
+    o.x += acc.x; o.y += acc.y; o.z += acc.z; o.w += acc.w;
+    ((float4*)dw)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const int64_t i = n4 * 4 + threadIdx.x;
+    float acc = 0.f;
+    for (int s = 0; s < splits; ++s) acc += slab[(size_t)s * stride + i];
+    dw[i] += acc;
   }
 }
 
@@ -1516,18 +1607,55 @@ size_t dgrad_weight_bytes(const cpm_conv_desc* d) {
 
 }  // namespace
 
+static size_t wgrad_slab_bytes(const cpm_conv_desc* d);
+
+// bytes of split-K slab planes the planner would use for the forward (or the data gradient) of `d`
+static size_t splitk_slab_bytes(const cpm_conv_desc* d, bool dgrad) {
+  IgemmArgs a = {};
+  a.groups = d->groups;
+  if (!dgrad) {
+    a.M = d->N * d->P * d->Q; a.OCg = d->K / d->groups; a.OCtot = d->K;
+    a.ksteps = d->R * d->S * cpm::cdiv(d->C / d->groups, BK);
+  } else {
+    const int st = d->stride;
+    a.M = d->N * d->H * d->W; a.OCg = d->C / d->groups; a.OCtot = d->C;
+    a.ksteps = cpm::cdiv(d->R, st) * cpm::cdiv(d->S, st) * cpm::cdiv(d->K / d->groups, BK);
+  }
+  const Plan p = plan_igemm(a);
+  if (p.split <= 1 || (a.OCtot & 3)) return 0;
+  return (size_t)p.split * (((size_t)a.M * a.OCtot + 63) / 64 * 64) * sizeof(float);
+}
+
 CPM_EXPORT size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d) {
   if (validate(d) != CPM_OK) return 0;
-  return dgrad_weight_bytes(d) + 256;
+  // the larger of: data-gradient weight image + its split-K slab, weight-gradient slab, forward split-K slab
+  const size_t dg = dgrad_weight_bytes(d) + 256 + splitk_slab_bytes(d, true), wg = wgrad_slab_bytes(d),
+               fw = splitk_slab_bytes(d, false);
+  size_t m = dg > wg ? dg : wg;
+  m = m > fw ? m : fw;
+  return m + 256;
 }
 
 static int split_into(const float* x, int64_t rows, int channels, void* sp, hipStream_t s) {
   return cpm_split_planes(x, rows, channels, sp, (void*)s);
 }
 
+// a split-K slab of `split` planes fits the workspace region [off, bytes)?
+static float* slab_in(void* workspace, size_t bytes, size_t off, int split, size_t plane_floats, int oc_tot) {
+  // Measured slower than the float-atomic form on the forward / data-gradient splits (grid head 3x3 at 64 RoIs: 87 vs
+  // 83 us; iou_fc1: 46 vs 36 us -- the bias-seeded accumulator needs no epilogue pass, the planes cost split x the
+  // output in stores and again in loads), so it is the DETERMINISTIC mode's path, not the default one.  (The weight
+  // gradient's planes ARE the default: there the atomics cost 23 % of the kernel.)
+  static const int on = env_int("CPM_SPLITK_SLAB", env_int("CPM_DETERMINISTIC", 0));
+  if (!on || split <= 1 || !workspace || (oc_tot & 3)) return nullptr;
+  off = (off + 255) / 256 * 256;
+  if (bytes < off + (size_t)split * plane_floats * sizeof(float)) return nullptr;
+  return (float*)((char*)workspace + off);
+}
+
 static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w, const void* w_sp,
                              const float* scale, const float* shift, const float* residual, int res_mode, int relu,
-                             float* y, void* y_sp, hipStream_t s) {
+                             float* y, void* y_sp, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0) {
   IgemmArgs a = {};
   a.in_sp = x_sp; a.wm_sp = w_sp; a.out_sp = y_sp;
   a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
@@ -1548,7 +1676,12 @@ static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void*
   a.split_k = p.split;
   a.atomic_out = a.split_k > 1;
   bool seeded = false;
-  if (a.atomic_out) {
+  const size_t plane = ((size_t)a.M * a.OCtot + 63) / 64 * 64;
+  a.slab = slab_in(workspace, workspace_bytes, 0, a.split_k, plane, a.OCtot);
+  a.slab_stride = plane;
+  if (a.slab) {
+    // partial sums in slab planes: no zero fill, no atomics; the reduce pass below also runs the epilogue
+  } else if (a.atomic_out) {
     if (shift && !scale && !residual && !relu && (a.OCtot & 3) == 0 && (((uintptr_t)shift | (uintptr_t)y) & 15) == 0) {
       const int64_t total4 = (int64_t)a.M * a.OCtot / 4;
       const int64_t b = (total4 + 255) / 256;
@@ -1563,7 +1696,13 @@ static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void*
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = launch_igemm(a, p, s, 0);
   if (rc != CPM_OK) return rc;
-  if (a.atomic_out && !seeded && (scale || shift || residual || relu)) {
+  if (a.slab) {
+    const int64_t b = ((int64_t)a.M * a.OCtot / 4 + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, a.slab,
+                       a.split_k, a.slab_stride, y, 0, scale, shift, residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode,
+                       relu, (const float*)nullptr);
+    rc = cpm::check_launch("conv split-K reduce");
+  } else if (a.atomic_out && !seeded && (scale || shift || residual || relu)) {
     const int64_t total = (int64_t)a.M * a.OCtot;
     int64_t b = (total + 255) / 256;
     hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, y, scale, shift,
@@ -1583,7 +1722,7 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
   CPM_REQUIRE(x && w && y, "null pointer");
   CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
   return conv_forward_impl(d, x, nullptr, w, nullptr, scale, shift, residual, res_mode, relu, y, nullptr,
-                           (hipStream_t)stream);
+                           (hipStream_t)stream, workspace, workspace_bytes);
 }
 
 CPM_EXPORT int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w,
@@ -1642,7 +1781,22 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
     a.res = dx;
     a.res_mode = 0;
   }
-  if (a.atomic_out && !accumulate) {
+  // split-K partial sums in slab planes (plain stores, folded in split order with the epilogue in one pass) when the
+  // workspace has room behind the weight image and every stride phase has taps (a phase without taps writes nothing)
+  bool all_phases = true;
+  for (int pa = 0; pa < st; ++pa)
+    for (int pb = 0; pb < st; ++pb) {
+      const int r0 = (pa + d->pad) % st, s0 = (pb + d->pad) % st;
+      if ((d->H - pa + st - 1) / st <= 0 || (d->W - pb + st - 1) / st <= 0) continue;
+      const int nr = r0 < d->R ? (d->R - r0 + st - 1) / st : 0, ns = s0 < d->S ? (d->S - s0 + st - 1) / st : 0;
+      if (nr * ns * a.ksteps_per_tap < a.split_k) all_phases = false;   // (such a phase runs unsplit: one plane only)
+    }
+  const size_t plane = ((size_t)whole.M * a.OCtot + 63) / 64 * 64;
+  a.slab = (a.split_k > 1 && all_phases) ? slab_in(workspace, workspace_bytes, prepared ? 0 : need, a.split_k, plane, a.OCtot)
+                                         : nullptr;
+  a.slab_stride = plane;
+  if (a.slab) a.atomic_out = 1;
+  if (a.atomic_out && !accumulate && !a.slab) {
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   // the kernel's own epilogue writes the SP copy unless the sums are partial (atomics) or a phase has no taps
@@ -1678,7 +1832,13 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
     }
   }
   if (rc != CPM_OK) return rc;
-  if (a.atomic_out && (shift || relu || out_scale || out_mask)) {
+  if (a.slab) {
+    const int64_t b = ((int64_t)whole.M * a.OCtot / 4 + 255) / 256;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, a.slab,
+                       a.split_k, a.slab_stride, dx, accumulate ? 1 : 0, out_scale, shift, (const float*)nullptr,
+                       (int64_t)whole.M, a.OCtot, a.OH, a.OW, 0, relu, out_mask);
+    rc = cpm::check_launch("dgrad split-K reduce");
+  } else if (a.atomic_out && (shift || relu || out_scale || out_mask)) {
     const int64_t total = (int64_t)whole.M * a.OCtot;
     int64_t b = (total + 255) / 256;
     hipLaunchKernelGGL(epilogue_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, dx,
@@ -1711,12 +1871,12 @@ CPM_EXPORT int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const floa
 
 CPM_EXPORT int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
                                                  int accumulate, const float* in_scale, const float* in_act,
-                                                 void* stream) {
+                                                 void* workspace, size_t workspace_bytes, void* stream) {
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(dy && wt && dx, "null pointer");
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
   CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
-  return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, nullptr, 0, (hipStream_t)stream,
+  return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
                    "cpm_conv2d_backward_data_prepared", in_scale, in_act, true);
 }
 
@@ -1753,8 +1913,10 @@ CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float*
                    "cpm_conv_transpose2d_forward");
 }
 
-static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
-                     hipStream_t s) {
+// tile and reduction split of a weight-gradient problem (shared by the launcher and the workspace query)
+struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; };
+
+static WgradArgs wgrad_args(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias) {
   WgradArgs a = {};
   a.x = x; a.dy = dy; a.dw = dw; a.dshift = dbias;
   a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C; a.OH = d->P; a.OW = d->Q; a.OCtot = d->K;
@@ -1764,7 +1926,11 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   a.chunks = cpm::cdiv(a.M, 32);
   a.x_bytes = (unsigned)((size_t)d->N * d->H * d->W * d->C * 4);
   a.dy_bytes = (unsigned)((size_t)d->N * d->P * d->Q * d->K * 4);
-  const int taps = d->R * d->S;
+  return a;
+}
+
+static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
+  const int taps = a.R * a.S;
   auto blocks = [&](int bm, int bn) {
     return (int64_t)cpm::cdiv(a.OCg, bm) * cpm::cdiv(a.Cg, bn) * taps * a.groups;
   };
@@ -1776,16 +1942,49 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
     int best = 1;
     double best_cost = 1e30;
     for (int sk = 1; sk <= maxs; ++sk) {
-      const int64_t blocks = nb * sk;
-      const int64_t rounds = (blocks + slots - 1) / slots;
-      // time ~ rounds * (work per block) ~ rounds / sk; small penalty per extra split (atomic traffic)
+      const int64_t nblk = nb * sk;
+      const int64_t rounds = (nblk + slots - 1) / slots;
+      // time ~ rounds * (work per block) ~ rounds / sk; small penalty per extra split (slab traffic)
       const double cost = (double)rounds / sk * (1.0 + 0.01 * sk);
       if (cost < best_cost - 1e-12) { best_cost = cost; best = sk; }
     }
     return best;
   };
+  WgradPlan p;
+  if (a.OCg <= 32 || a.Cg <= 32) {
+    if (a.OCg <= 32 && a.Cg > 32) p = {32, 128, 1, 4, 1, false};
+    else if (a.Cg <= 32 && a.OCg > 32) p = {128, 32, 4, 1, 1, false};
+    else p = {64, 64, 2, 2, 1, false};
+  } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && a.chunks >= 64) {
+    p = {128, 128, 2, 2, 1, false};     // the reduction (pixels) is split until the grid fills the chip
+  } else if (g_conv_split && wvec && a.OCg >= 96 && a.Cg >= 96 && a.chunks >= 16) {
+    // the split-bf16 kernel only pays off on the 128x128 tile (the 64x64 one is LDS/convert bound): ragged channel
+    // counts (576 = 4.5 tiles) and short reductions with many tiles (FC layers) take it with masked edges
+    p = {128, 128, 2, 2, 1, false};
+  } else {
+    p = {64, 64, 2, 2, 1, false};
+  }
+  p.split = split_for(blocks(p.bm, p.bn), p.bm * p.bn >= 128 * 128 ? 2 : 4);
+  p.bf16 = wvec && g_conv_split && p.bm % 64 == 0 && p.bn % 64 == 0;
+  return p;
+}
+
+static size_t wgrad_slab_bytes(const cpm_conv_desc* d) {
+  if (d->C / d->groups == 1 && d->R * d->S <= 16) return 0;           // wgrad_cg1_kernel: no reduction split
+  const WgradArgs a = wgrad_args(d, nullptr, nullptr, nullptr, nullptr);
+  const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0);
+  const WgradPlan p = plan_wgrad(a, wvec);
+  return p.split > 1 ? (size_t)p.split * dgrad_weight_bytes(d) : 0;
+}
+
+static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                     void* workspace, size_t workspace_bytes, hipStream_t s) {
+  WgradArgs a = wgrad_args(d, x, dy, dw, dbias);
+  const int taps = d->R * d->S;
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
+  static const int nostore = env_int("CPM_WGRAD_NOSTORE", 0);
+  a.debug_nostore = nostore;
   ProfScope prof_scope(s, 2);
   if (a.Cg == 1 && taps <= 16) {
     if (dbias) {
@@ -1802,47 +2001,54 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   }
   const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) &&
                     (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
-#define WLAUNCH(BM, BN, WM, WN)                                                                      \
-  do {                                                                                               \
-    a.split_k = split_for(blocks(BM, BN), (BM) * (BN) >= 128 * 128 ? 2 : 4);                          \
-    dim3 grid((unsigned)(cpm::cdiv(a.OCg, BM) * cpm::cdiv(a.Cg, BN)), taps, a.groups * a.split_k);  \
-    if (wvec && g_conv_split && (BM) % 64 == 0 && (BN) % 64 == 0)                                    \
+  const WgradPlan p = plan_wgrad(a, wvec);
+  a.split_k = p.split;
+  // A split reduction lands in one slab plane per split (plain stores) and is folded into dw in split order; without
+  // a workspace (or with CPM_WGRAD_SLAB=0) the splits add into dw with float atomics as before.
+  static const int use_slab = env_int("CPM_WGRAD_SLAB", 1);
+  const size_t dw_elems = (size_t)d->K * d->R * d->S * (d->C / d->groups);
+  const size_t plane = (dw_elems + 63) / 64 * 64;                     // 256-byte aligned planes
+  if (use_slab && a.split_k > 1 && workspace && workspace_bytes >= (size_t)a.split_k * plane * sizeof(float) &&
+      ((uintptr_t)workspace & 15) == 0) {
+    a.slab = (float*)workspace;
+    a.slab_stride = plane;
+  }
+  dim3 grid((unsigned)(cpm::cdiv(a.OCg, p.bm) * cpm::cdiv(a.Cg, p.bn)), taps, a.groups * a.split_k);
+#define WCASE(BM, BN, WM, WN)                                                                        \
+  if (p.bm == BM && p.bn == BN) {                                                                    \
+    if (p.bf16)                                                                                      \
       hipLaunchKernelGGL((wgrad_split_kernel<(BM) % 64 == 0 ? BM : 64, (BN) % 64 == 0 ? BN : 64, 2, 2>), grid, \
                          dim3(256), 0, s, a);                                                        \
     else if (wvec)                                                                                   \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
     else                                                                                             \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);           \
-  } while (0)
-  if (a.OCg <= 32 || a.Cg <= 32) {
-    if (a.OCg <= 32 && a.Cg > 32) WLAUNCH(32, 128, 1, 4);
-    else if (a.Cg <= 32 && a.OCg > 32) WLAUNCH(128, 32, 4, 1);
-    else WLAUNCH(64, 64, 2, 2);
-  } else if (a.OCg % 128 == 0 && a.Cg % 128 == 0 && a.chunks >= 64) {
-    WLAUNCH(128, 128, 2, 2);        // the reduction (pixels) is split until the grid fills the chip
-  } else if (g_conv_split && wvec && a.OCg >= 96 && a.Cg >= 96 && a.chunks >= 16) {
-    // the split-bf16 kernel only pays off on the 128x128 tile (the 64x64 one is LDS/convert bound): ragged channel
-    // counts (576 = 4.5 tiles) and short reductions with many tiles (FC layers) take it with masked edges
-    WLAUNCH(128, 128, 2, 2);
-  } else {
-    WLAUNCH(64, 64, 2, 2);
   }
-#undef WLAUNCH
-  return cpm::check_launch("conv wgrad");
+  WCASE(32, 128, 1, 4) else WCASE(128, 32, 4, 1) else WCASE(64, 64, 2, 2) else WCASE(128, 128, 2, 2)
+#undef WCASE
+  int rc = cpm::check_launch("conv wgrad");
+  if (rc == CPM_OK && a.slab) {
+    const int64_t n = (int64_t)dw_elems;
+    int64_t b = (n / 4 + 255) / 256;
+    b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, n, dw);
+    rc = cpm::check_launch("conv wgrad reduce");
+  }
+  return rc;
 }
 
 CPM_EXPORT int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
                                           void* workspace, size_t workspace_bytes, void* stream) {
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(x && dy && dw, "null pointer");
-  return run_wgrad(d, x, dy, dw, nullptr, (hipStream_t)stream);
+  return run_wgrad(d, x, dy, dw, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 CPM_EXPORT int cpm_conv2d_backward_weight_bias(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
                                                float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(x && dy && dw && dbias, "null pointer");
-  return run_wgrad(d, x, dy, dw, dbias, (hipStream_t)stream);
+  return run_wgrad(d, x, dy, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 // ---- profiling hooks (bench.py roofline leg) -----------------------------------------------------------

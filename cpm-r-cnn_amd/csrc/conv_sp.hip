@@ -208,7 +208,10 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int ocl = n0 + wn * WTN + j * 32 + ecol;
-          if (ocl < a.OCg) atomicAdd(a.out + (size_t)orow * a.OCtot + g * a.OCg + ocl, acc[i][j][e]);
+          if (ocl >= a.OCg) continue;
+          const size_t o = (size_t)orow * a.OCtot + g * a.OCg + ocl;
+          if (a.slab) a.slab[(size_t)split * a.slab_stride + o] = acc[i][j][e];
+          else atomicAdd(a.out + o, acc[i][j][e]);
         }
       }
     return;

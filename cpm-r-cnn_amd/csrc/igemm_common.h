@@ -86,6 +86,9 @@ struct IgemmArgs {
   unsigned in_bytes, wm_bytes;
   int xcd_swizzle;
   int m_base;          // first GEMM row of this launch (rows [m_base, M) are tiled)
+  float* slab;         // split-K: partial sums go to plane `split` of this [split_k][rows][OCtot] buffer with plain stores
+  size_t slab_stride;  //   (floats per plane) and splitk_reduce_kernel folds the planes in split order + runs the epilogue;
+                       //   null: float atomics into the zeroed output (no workspace)
   int staged_epi;      // finish every non-atomic epilogue row-wise through LDS (16-byte accesses), not only residual ones
   // split-plane operands (conv_sp.hip): the same tensors stored as bf16 hi / lo planes, [row][2][C] -- per pixel (or per
   // weight row (oc, tap)) C hi values then C lo values, 4*C bytes like the fp32 row.  Null: fp32 operands only.

@@ -148,11 +148,12 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
             return acc
         d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
         with H.guard(dy.device):
+            ws = _ws(d, dy.device)
             if wt is not None:
                 rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(acc), 1,
-                                                               None, None, H.stream())
+                                                               None, None, H.ptr(ws), H.c_size_t(ws.numel()),
+                                                               H.stream())
             else:
-                ws = _ws(d, dy.device)
                 rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(acc), 1,
                                                       H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
         H.check(rc, "conv2d_backward_data(accumulate)")
@@ -171,11 +172,11 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
     if dy.numel() == 0:
         return dx.zero_()
     with H.guard(dy.device):
+        ws = _ws(d, dy.device)
         if wt is not None:
             rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0, None,
-                                                           None, H.stream())
+                                                           None, H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
         else:
-            ws = _ws(d, dy.device)
             rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), 0, H.ptr(ws),
                                                   H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_data")
@@ -194,11 +195,12 @@ def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wpa
     if dy.numel() == 0:
         return dx.zero_()
     with H.guard(dy.device):
+        ws = _ws(d, dy.device)
         if wt is not None:
             rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0,
-                                                           H.ptr(in_scale), H.ptr(x), H.stream())
+                                                           H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()),
+                                                           H.stream())
         else:
-            ws = _ws(d, dy.device)
             rc = H.lib().cpm_conv2d_backward_data_gated(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx),
                                                         H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()),
                                                         H.stream())

@@ -116,7 +116,11 @@ int cpm_pool_points_interp_backward(const float* grad_output, const float* pts, 
  *   nn.ConvTranspose2d); accumulate!=0 adds into dx.
  * cpm_conv2d_backward_weight: dw += x (*) dy   (always accumulates: dw is a
  *   slice of the flat gradient buffer zeroed once per step).
- * split_k <= 0 lets the library choose.  Workspace: cpm_conv2d_workspace_bytes. */
+ * split_k <= 0 lets the library choose.  Workspace: cpm_conv2d_workspace_bytes -- it holds the data gradient's
+ * re-laid weight image and the SLAB PLANES of split reductions: when a reduction (the k loop of a thin forward / data
+ * gradient, the pixel loop of a weight gradient) is split over workgroups, every split stores its partial tile into its
+ * own plane with plain stores and one pass folds the planes in split order (and runs the fused epilogue): bit-
+ * reproducible results, no float atomics.  With a NULL / short workspace the splits add with float atomics instead. */
 typedef struct {
   int N, H, W, C;        /* input  [N,H,W,C]  */
   int K, R, S;           /* weight [K,R,S,C/groups] */
@@ -170,7 +174,8 @@ typedef struct {
 int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs /* DEVICE table, sorted by tile_start */, int n,
                                  int64_t total_tiles, const float* src_base, float* dst_base, void* stream);
 int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
-                                      int accumulate, const float* in_scale, const float* in_act, void* stream);
+                                      int accumulate, const float* in_scale, const float* in_act, void* workspace,
+                                      size_t workspace_bytes, void* stream);
 
 /* ---- split-plane ("SP") operands for the CPM_MATH_BF16X3 arithmetic ------------------------------------------------
  * The 3-term split-bf16 product needs hi = bf16(v), lo = bf16(v - hi) of every operand.  The plain entry points above

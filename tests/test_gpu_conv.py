@@ -104,6 +104,36 @@ def test_conv_fwd_bwd(case, epi):
         assert relerr(rd.grad, rr.grad) < TOL, "residual grad"
 
 
+@pytest.mark.parametrize("case", [(2, 256, 50, 84, 256, 3, 1, 1), (37, 576, 7, 7, 576, 3, 1, 1), (2, 64, 100, 168, 256, 1, 1, 0),
+                                  (2, 40, 33, 31, 24, 3, 2, 1)],
+                         ids=["3x3_split", "grid_ragged_576", "1x1_deep_split", "narrow_tiles"])
+def test_weight_gradient_is_bit_reproducible(case):
+    """The pixel reduction of the weight gradient is split over workgroups; every split writes its own slab plane and
+    wgrad_reduce_kernel folds the planes into dw in split order -- no float atomics, so two runs agree bit for bit
+    (deterministic reductions instead of noise-relative test bounds) and equal torch to 1e-4."""
+    from pet.lib.ops import conv as ops
+    N, C, H, W, K, R, stride, pad = case
+    x, dy_shape = rnd(N, C, H, W, seed=1), None
+    w = rnd(K, C, R, R, seed=2, scale=0.05)
+    xr, wr = x.clone(), w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    dy = rnd(*yr.shape, seed=3)
+    yr.backward(dy)
+    xd = x.cuda().contiguous(memory_format=CL)
+    dyd = dy.cuda().contiguous(memory_format=CL)
+    wd = w.cuda().contiguous(memory_format=CL)
+    outs = []
+    for _ in range(3):
+        dw = torch.zeros_like(wd)
+        ops.conv2d_backward_weight(xd, dyd, wd, stride, pad, 1, 1, out=dw)
+        outs.append(dw.clone())
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert relerr(outs[0], wr.grad) < TOL
+    acc = outs[0].clone()
+    ops.conv2d_backward_weight(xd, dyd, wd, stride, pad, 1, 1, out=acc)          # accumulates into dw
+    assert relerr(acc, 2 * wr.grad) < TOL
+
+
 def test_fpn_topdown_residual():
     """lateral 1x1 conv + nearest-2x upsampled top (FPN.py:100-106) fused through res_mode=1."""
     from pet.lib.ops import conv as ops

@@ -173,7 +173,9 @@ def test_fused_cascade_equals_per_image_path():
             # relative to the level's own L2 norm -- a flipped gate moves a handful of entries and barely shows in it,
             # an indexing or scaling error confined to one level is O(1)
             nb = float(b.double().norm())
-            assert nb > 0, lvl
+            if nb == 0:                                     # no RoI maps to this level in either formulation
+                assert float(a.abs().max()) == 0, lvl
+                continue
             rel = float((a.double() - b.double()).norm()) / nb
             rel_noise = float((a.double() - a2.double()).norm()) / nb
             assert rel <= 3 * rel_noise + 5e-3, (lvl, rel, rel_noise, _hip_mode())
