@@ -790,6 +790,39 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
   }
 }
 
+// the same for outputs whose channel count is not a multiple of 4 (cls_score: 81, iou_pred: 2, RPN predictors: 3 / 12)
+__global__ __launch_bounds__(256) void splitk_reduce_scalar_kernel(const float* __restrict__ slab, int splits, size_t stride,
+                                                                   float* __restrict__ out, int accumulate,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift,
+                                                                   const float* __restrict__ res, int64_t M, int OC,
+                                                                   int OH, int OW, int res_mode, int relu,
+                                                                   const float* __restrict__ mask) {
+  const int64_t total = M * OC;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    float v = slab[idx];
+    for (int s = 1; s < splits; ++s) v += slab[(size_t)s * stride + idx];
+    if (accumulate) v += out[idx];
+    const int oc = (int)(idx % OC);
+    const int64_t m = idx / OC;
+    v = v * (scale ? scale[oc] : 1.f) + (shift ? shift[oc] : 0.f);
+    if (res) {
+      if (res_mode == 0) {
+        v += res[idx];
+      } else {
+        const int ow = (int)(m % OW);
+        const int64_t t = m / OW;
+        const int oh = (int)(t % OH);
+        const int64_t n = t / OH;
+        v += res[((n * ((OH + 1) / 2) + oh / 2) * ((OW + 1) / 2) + ow / 2) * OC + oc];
+      }
+    }
+    if (relu) v = fmaxf(v, 0.f);
+    if (mask) v = mask[idx] > 0.f ? v : 0.f;
+    out[idx] = v;
+  }
+}
+
 // split-K accumulator seeded with the bias: out[m][oc] = shift[oc] -- when the epilogue is the bias alone (conv + bias
 // feeding a GroupNorm: the grid head), this replaces BOTH the zero fill before the atomics and the epilogue pass after
 __global__ void __launch_bounds__(256) seed_rows_kernel(float* __restrict__ out, const float* __restrict__ shift,
@@ -1391,7 +1424,9 @@ __global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per
     if (wave == 0 && live) {
       for (int t = 0; t < taps; ++t) {
         const float v = red[0][t][lane] + red[1][t][lane] + red[2][t][lane] + red[3][t][lane];
-        atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * taps + t), v);
+        const size_t o = (size_t)(g * a.OCg + ocl) * taps + t;
+        if (a.slab) a.slab[(size_t)blockIdx.x * a.slab_stride + o] = v;      // this pixel block's plane (deterministic mode)
+        else atomicAdd(a.dw + o, v);
       }
     }
     __syncthreads();
@@ -1423,6 +1458,10 @@ struct ProfScope {
     if (on && hipEventRecord(r.b, s) == hipSuccess) g_prof.push_back(r);
   }
 };
+
+// cpm_set_deterministic: split reductions of forward / data gradient go through slab planes folded in split order
+// instead of float atomics (the weight gradient always does)
+static int g_deterministic = 0;
 
 // conv arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 3-term split-bf16 MFMA (fp32 accumulate)
 static int g_conv_split = 0;
@@ -1622,7 +1661,7 @@ static size_t splitk_slab_bytes(const cpm_conv_desc* d, bool dgrad) {
     a.ksteps = cpm::cdiv(d->R, st) * cpm::cdiv(d->S, st) * cpm::cdiv(d->K / d->groups, BK);
   }
   const Plan p = plan_igemm(a);
-  if (p.split <= 1 || (a.OCtot & 3)) return 0;
+  if (p.split <= 1) return 0;
   return (size_t)p.split * (((size_t)a.M * a.OCtot + 63) / 64 * 64) * sizeof(float);
 }
 
@@ -1647,7 +1686,7 @@ static float* slab_in(void* workspace, size_t bytes, size_t off, int split, size
   // output in stores and again in loads), so it is the DETERMINISTIC mode's path, not the default one.  (The weight
   // gradient's planes ARE the default: there the atomics cost 23 % of the kernel.)
   static const int on = env_int("CPM_SPLITK_SLAB", env_int("CPM_DETERMINISTIC", 0));
-  if (!on || split <= 1 || !workspace || (oc_tot & 3)) return nullptr;
+  if (!(on || g_deterministic) || split <= 1 || !workspace) return nullptr;
   off = (off + 255) / 256 * 256;
   if (bytes < off + (size_t)split * plane_floats * sizeof(float)) return nullptr;
   return (float*)((char*)workspace + off);
@@ -1698,9 +1737,13 @@ static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void*
   if (rc != CPM_OK) return rc;
   if (a.slab) {
     const int64_t b = ((int64_t)a.M * a.OCtot / 4 + 255) / 256;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, a.slab,
-                       a.split_k, a.slab_stride, y, 0, scale, shift, residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode,
-                       relu, (const float*)nullptr);
+    const dim3 rg((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)));
+    if (a.OCtot & 3)
+      hipLaunchKernelGGL(splitk_reduce_scalar_kernel, rg, dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, y, 0, scale,
+                         shift, residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode, relu, (const float*)nullptr);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, y, 0, scale, shift,
+                         residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode, relu, (const float*)nullptr);
     rc = cpm::check_launch("conv split-K reduce");
   } else if (a.atomic_out && !seeded && (scale || shift || residual || relu)) {
     const int64_t total = (int64_t)a.M * a.OCtot;
@@ -1792,10 +1835,13 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
       if (nr * ns * a.ksteps_per_tap < a.split_k) all_phases = false;   // (such a phase runs unsplit: one plane only)
     }
   const size_t plane = ((size_t)whole.M * a.OCtot + 63) / 64 * 64;
-  a.slab = (a.split_k > 1 && all_phases) ? slab_in(workspace, workspace_bytes, prepared ? 0 : need, a.split_k, plane, a.OCtot)
-                                         : nullptr;
+  a.slab = a.split_k > 1 ? slab_in(workspace, workspace_bytes, prepared ? 0 : need, a.split_k, plane, a.OCtot) : nullptr;
   a.slab_stride = plane;
-  if (a.slab) a.atomic_out = 1;
+  if (a.slab) {
+    a.atomic_out = 1;
+    // a stride phase without taps (or one that runs unsplit) leaves plane rows unwritten: they must read as zero
+    if (!all_phases && hipMemsetAsync(a.slab, 0, (size_t)a.split_k * plane * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
+  }
   if (a.atomic_out && !accumulate && !a.slab) {
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
@@ -1834,9 +1880,15 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   if (rc != CPM_OK) return rc;
   if (a.slab) {
     const int64_t b = ((int64_t)whole.M * a.OCtot / 4 + 255) / 256;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b))), dim3(256), 0, s, a.slab,
-                       a.split_k, a.slab_stride, dx, accumulate ? 1 : 0, out_scale, shift, (const float*)nullptr,
-                       (int64_t)whole.M, a.OCtot, a.OH, a.OW, 0, relu, out_mask);
+    const dim3 rg((unsigned)(b > 4096 ? 4096 : (b < 1 ? 1 : b)));
+    if (a.OCtot & 3)
+      hipLaunchKernelGGL(splitk_reduce_scalar_kernel, rg, dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, dx,
+                         accumulate ? 1 : 0, out_scale, shift, (const float*)nullptr, (int64_t)whole.M, a.OCtot, a.OH,
+                         a.OW, 0, relu, out_mask);
+    else
+      hipLaunchKernelGGL(splitk_reduce_kernel, rg, dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, dx,
+                         accumulate ? 1 : 0, out_scale, shift, (const float*)nullptr, (int64_t)whole.M, a.OCtot, a.OH,
+                         a.OW, 0, relu, out_mask);
     rc = cpm::check_launch("dgrad split-K reduce");
   } else if (a.atomic_out && (shift || relu || out_scale || out_mask)) {
     const int64_t total = (int64_t)whole.M * a.OCtot;
@@ -1970,7 +2022,12 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
 }
 
 static size_t wgrad_slab_bytes(const cpm_conv_desc* d) {
-  if (d->C / d->groups == 1 && d->R * d->S <= 16) return 0;           // wgrad_cg1_kernel: no reduction split
+  if (d->C / d->groups == 1 && d->R * d->S <= 16) {                    // wgrad_cg1_kernel: one plane per pixel block
+    const int64_t M = (int64_t)d->N * d->P * d->Q;
+    int ppb = (int)((M * d->groups / (2 * num_cus()) + 63) / 64 * 64);
+    ppb = ppb < 128 ? 128 : (ppb > 2048 ? 2048 : ppb);
+    return (size_t)cpm::cdiv(M, ppb) * (((size_t)d->K * d->R * d->S + 63) / 64 * 64) * sizeof(float);
+  }
   const WgradArgs a = wgrad_args(d, nullptr, nullptr, nullptr, nullptr);
   const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0);
   const WgradPlan p = plan_wgrad(a, wvec);
@@ -1996,8 +2053,20 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
     int ppb = (int)(((int64_t)a.M * a.groups / (2 * num_cus()) + 63) / 64 * 64);
     ppb = ppb < 128 ? 128 : (ppb > 2048 ? 2048 : ppb);
     dim3 grid((unsigned)cpm::cdiv(a.M, ppb), (unsigned)a.groups);
+    // deterministic mode: every pixel block writes its own plane, folded in block order (instead of float atomics)
+    const size_t dw_n = (size_t)d->K * taps, pl = (dw_n + 63) / 64 * 64;
+    if (g_deterministic && workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)grid.x * pl * sizeof(float)) {
+      a.slab = (float*)workspace;
+      a.slab_stride = pl;
+    }
     hipLaunchKernelGGL((wgrad_cg1_kernel<16>), grid, dim3(256), 0, s, a, ppb);
-    return cpm::check_launch("conv wgrad (one channel per group)");
+    int rc1 = cpm::check_launch("conv wgrad (one channel per group)");
+    if (rc1 == CPM_OK && a.slab) {
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)cpm::cdiv((int64_t)dw_n / 4 + 1, 256)), dim3(256), 0, s, a.slab,
+                         (int)grid.x, a.slab_stride, (int64_t)dw_n, dw);
+      rc1 = cpm::check_launch("conv wgrad reduce (one channel per group)");
+    }
+    return rc1;
   }
   const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) &&
                     (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
@@ -2059,6 +2128,13 @@ CPM_EXPORT int cpm_set_conv_math(int mode) {
 }
 
 CPM_EXPORT int cpm_get_conv_math(void) { return g_conv_split ? CPM_MATH_BF16X3 : CPM_MATH_F32; }
+
+CPM_EXPORT int cpm_set_deterministic(int on) {
+  g_deterministic = on != 0;
+  return CPM_OK;
+}
+
+CPM_EXPORT int cpm_get_deterministic(void) { return g_deterministic; }
 
 CPM_EXPORT int cpm_prof_enable(int on) {
   for (auto& r : g_prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }

@@ -66,6 +66,11 @@ def get_conv_math():
     return [k for k, c in CONV_MATH.items() if c == v][0]
 
 
+def set_deterministic(on):
+    """Split-K partial sums through ordered slab planes instead of float atomics (cpmrcnn_hip.h)."""
+    check(lib().cpm_set_deterministic(int(bool(on))), "set_deterministic")
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().cpm_last_error().decode()))

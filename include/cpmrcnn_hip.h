@@ -138,6 +138,13 @@ typedef struct {
 #define CPM_MATH_BF16X3 1
 int cpm_set_conv_math(int mode);
 int cpm_get_conv_math(void);
+/* Deterministic reductions for the conv family (process-wide, default off; environment CPM_DETERMINISTIC=1 at load):
+ * the split-K partial sums of forward / data gradient go through workspace slab planes folded in split order instead
+ * of float atomics -- two runs then produce bit-identical activations, data gradients and weight gradients (the weight
+ * gradient's split reduction always works that way).  A few percent slower on thin layers.  Per-channel parameter
+ * sums (bias / GroupNorm affine gradients) and the loss scalars still use float atomics. */
+int cpm_set_deterministic(int on);
+int cpm_get_deterministic(void);
 
 size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d);
 int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,

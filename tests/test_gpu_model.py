@@ -213,6 +213,45 @@ def test_backward_big_matches_reference(model, golden_big, conv_math):
         conv_math, worst, ", ".join("%s max %.1e over %d/%d" % (n.split(".", 1)[1], m, o, t) for n, m, o, t in log)))
 
 
+def test_deterministic_mode_gives_bit_identical_weight_gradients(model, golden_big, conv_math):
+    """cpm_set_deterministic(1): split reductions of forward / data gradient fold ordered slab planes instead of adding
+    with float atomics (the weight gradient always does), the RoIAlign backward is the sorted gather: two backward
+    passes over the whole model then give BIT-IDENTICAL gradients for every conv / Linear weight.
+    The per-channel sums (biases, GroupNorm affine) still use float atomics and are held to 1e-5 here."""
+    from pet.lib.ops import _hip
+    from pet.utils.data.structures.bounding_box import BoxList
+    g = golden_big
+    model.train()
+
+    def run():
+        model.zero_grad(set_to_none=True)
+        boxes = [BoxList(torch.from_numpy(g["rois"]).cuda(), (320, 256))]
+        G = model.Grid_Cascade_RCNN
+        p = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(g["img"]).cuda()))
+        xg, _ = G.Head_grid_2(p, boxes)
+        hm, iou = G.Output_grid_2(xg, None)
+        loss = (hm["unfused"] ** 2).mean() + (iou ** 2).mean() + (G.Output_cls(G.Head_cls(p, boxes)) ** 2).mean()
+        lo, br = model.RPN.head(p)
+        (loss + sum((a ** 2).mean() for a in lo) + sum((a ** 2).mean() for a in br)).backward()
+        torch.cuda.synchronize()
+        return {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.grad is not None}
+    _hip.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        _hip.set_deterministic(False)
+    assert set(a) == set(b) and len(a) > 100
+    exact = 0
+    differ = [k for k in a if a[k].dim() >= 2 and not torch.equal(a[k], b[k])]
+    assert not differ, (len(differ), [d.replace('Conv_Body', 'B').replace('.weight', '') for d in differ])
+    for k in a:
+        if a[k].dim() >= 2:
+            exact += 1
+        else:
+            assert float((a[k] - b[k]).abs().max()) <= 1e-5 * float(b[k].abs().max()) + 1e-12, k
+    assert exact >= 60
+
+
 def test_relu_gate_flips_between_arithmetics_are_rare(model, golden_big):
     """The explanation behind check_grad_entries, measured: the ReLU gates of the grid head (8 x conv + GroupNorm +
     ReLU per stage) differ between the exact-f32 and the split-bf16 forward only where a pre-activation is zero to
