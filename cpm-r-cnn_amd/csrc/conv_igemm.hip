@@ -1460,7 +1460,7 @@ struct ProfScope {
 };
 
 // cpm_set_deterministic: split reductions of forward / data gradient go through slab planes folded in split order
-// instead of float atomics (the weight gradient always does)
+// instead of float atomics (and the weight gradient)
 static int g_deterministic = 0;
 
 // conv arithmetic: 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 3-term split-bf16 MFMA (fp32 accumulate)
@@ -2055,7 +2055,8 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
     dim3 grid((unsigned)cpm::cdiv(a.M, ppb), (unsigned)a.groups);
     // deterministic mode: every pixel block writes its own plane, folded in block order (instead of float atomics)
     const size_t dw_n = (size_t)d->K * taps, pl = (dw_n + 63) / 64 * 64;
-    if (g_deterministic && workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)grid.x * pl * sizeof(float)) {
+    static const int det_env = env_int("CPM_DETERMINISTIC", 0);
+    if ((g_deterministic || det_env) && workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (size_t)grid.x * pl * sizeof(float)) {
       a.slab = (float*)workspace;
       a.slab_stride = pl;
     }
@@ -2072,9 +2073,13 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
                     (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
   const WgradPlan p = plan_wgrad(a, wvec);
   a.split_k = p.split;
-  // A split reduction lands in one slab plane per split (plain stores) and is folded into dw in split order; without
-  // a workspace (or with CPM_WGRAD_SLAB=0) the splits add into dw with float atomics as before.
-  static const int use_slab = env_int("CPM_WGRAD_SLAB", 1);
+  // Deterministic mode (cpm_set_deterministic / CPM_DETERMINISTIC / CPM_WGRAD_SLAB=1): a split reduction lands in one
+  // slab plane per split (plain stores) and is folded into dw in split order -- bit-reproducible.  Default: the splits
+  // add into dw with float atomics.  Measured both ways in the training step: in isolation the atomic epilogue costs
+  // 23 % of the kernel (grid-head layer 130 -> 106 us with planes incl. the fold), but inside the step the fold pass
+  // (98 launches, 1.36 ms for R-50; each reads split x dw) gives the gain back: R-50 30.0 vs 30.0 ms/step, R-101
+  // 38.2-40.2 vs 36.8 ms/step (17 more blocks of thin 1x1 layers whose 32-way split planes cost more than their atomics).
+  static const int use_slab = env_int("CPM_WGRAD_SLAB", env_int("CPM_DETERMINISTIC", 0)) || g_deterministic;
   const size_t dw_elems = (size_t)d->K * d->R * d->S * (d->C / d->groups);
   const size_t plane = (dw_elems + 63) / 64 * 64;                     // 256-byte aligned planes
   if (use_slab && a.split_k > 1 && workspace && workspace_bytes >= (size_t)a.split_k * plane * sizeof(float) &&

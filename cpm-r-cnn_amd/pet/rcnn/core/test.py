@@ -118,7 +118,7 @@ def filter_results(boxlist):
     offsets = np.concatenate([[0], np.cumsum(counts)])
     cboxes, cscores = boxes[order].contiguous(), scores[order].contiguous()
     per_class = {}
-    if T.SOFT_NMS.ENABLED and cfg.FAST_RCNN.NMS > 0:
+    if T.SOFT_NMS.ENABLED:                   # whenever enabled, whatever FAST_RCNN.NMS is (reference test.py:468-476)
         method = SOFT_NMS_METHODS[T.SOFT_NMS.METHOD]
         for lo in range(1, num_classes, 64):                          # <= 64 segments per launch
             hi = min(lo + 64, num_classes)

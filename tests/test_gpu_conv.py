@@ -108,10 +108,20 @@ def test_conv_fwd_bwd(case, epi):
                                   (2, 40, 33, 31, 24, 3, 2, 1)],
                          ids=["3x3_split", "grid_ragged_576", "1x1_deep_split", "narrow_tiles"])
 def test_weight_gradient_is_bit_reproducible(case):
-    """The pixel reduction of the weight gradient is split over workgroups; every split writes its own slab plane and
-    wgrad_reduce_kernel folds the planes into dw in split order -- no float atomics, so two runs agree bit for bit
-    (deterministic reductions instead of noise-relative test bounds) and equal torch to 1e-4."""
+    """Deterministic mode: the pixel reduction of the weight gradient is split over workgroups; every split writes its
+    own slab plane and wgrad_reduce_kernel folds the planes into dw in split order -- no float atomics, so two runs
+    agree bit for bit (deterministic reductions instead of noise-relative test bounds) and equal
+    torch to 1e-4."""
+    from pet.lib.ops import _hip
     from pet.lib.ops import conv as ops
+    _hip.set_deterministic(True)
+    try:
+        _check_bit_reproducible_wgrad(ops, case)
+    finally:
+        _hip.set_deterministic(False)
+
+
+def _check_bit_reproducible_wgrad(ops, case):
     N, C, H, W, K, R, stride, pad = case
     x, dy_shape = rnd(N, C, H, W, seed=1), None
     w = rnd(K, C, R, R, seed=2, scale=0.05)

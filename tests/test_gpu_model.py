@@ -215,7 +215,7 @@ def test_backward_big_matches_reference(model, golden_big, conv_math):
 
 def test_deterministic_mode_gives_bit_identical_weight_gradients(model, golden_big, conv_math):
     """cpm_set_deterministic(1): split reductions of forward / data gradient fold ordered slab planes instead of adding
-    with float atomics (the weight gradient always does), the RoIAlign backward is the sorted gather: two backward
+    with float atomics (and the weight gradient), the RoIAlign backward is the sorted gather: two backward
     passes over the whole model then give BIT-IDENTICAL gradients for every conv / Linear weight.
     The per-channel sums (biases, GroupNorm affine) still use float atomics and are held to 1e-5 here."""
     from pet.lib.ops import _hip
