@@ -2079,7 +2079,8 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   // 23 % of the kernel (grid-head layer 130 -> 106 us with planes incl. the fold), but inside the step the fold pass
   // (98 launches, 1.36 ms for R-50; each reads split x dw) gives the gain back: R-50 30.0 vs 30.0 ms/step, R-101
   // 38.2-40.2 vs 36.8 ms/step (17 more blocks of thin 1x1 layers whose 32-way split planes cost more than their atomics).
-  static const int use_slab = env_int("CPM_WGRAD_SLAB", env_int("CPM_DETERMINISTIC", 0)) || g_deterministic;
+  static const int env_slab = env_int("CPM_WGRAD_SLAB", env_int("CPM_DETERMINISTIC", 0));
+  const bool use_slab = env_slab || g_deterministic;
   const size_t dw_elems = (size_t)d->K * d->R * d->S * (d->C / d->groups);
   const size_t plane = (dw_elems + 63) / 64 * 64;                     // 256-byte aligned planes
   if (use_slab && a.split_k > 1 && workspace && workspace_bytes >= (size_t)a.split_k * plane * sizeof(float) &&
