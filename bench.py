@@ -166,6 +166,19 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     dump = os.environ.get("CPM_PROF_DUMP")
     if dump:
         L.cpm_prof_dump(dump.encode())
+    # algorithmic HBM bytes of the average igemm call: input + output + weight, each once (fp32)
+    import csv
+    import tempfile
+    alg_bytes = None
+    with tempfile.NamedTemporaryFile("r", suffix=".csv") as tf:
+        if L.cpm_prof_dump(tf.name.encode()) == 0:
+            nb, nl = 0.0, 0
+            for r in csv.DictReader(open(tf.name)):
+                if r["kind"] in ("0", "1"):
+                    N, Hh, W, C, K, R, g, P, Q = (int(r[k]) for k in ("N", "H", "W", "C", "K", "R", "groups", "P", "Q"))
+                    nb += 4.0 * (N * Hh * W * C + N * P * Q * K + K * R * R * (C // g))
+                    nl += 1
+            alg_bytes = int(nb / nl) if nl else None
     L.cpm_prof_enable(0)
     # dominant kernel = igemm_kernel<...> (forward-gather + data-gradient-gather instantiations of one template)
     ms = kinds["igemm_fwd"]["ms"] + kinds["igemm_dgrad"]["ms"]
@@ -179,7 +192,7 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; they are
     # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this same command) and committed
     traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1_pmc_traffic.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc.json")
     if math == "bf16x3" and os.path.exists(pmc):
         with open(pmc) as f:
             traffic = json.load(f)["kernels"]["igemm_kernel"]["hbm_bytes_per_launch"]
@@ -193,6 +206,7 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     return {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad, 3 x v_mfma_f32_32x32x16_bf16 per product)",
             "achieved": round(achieved, 2), "peak": round(MFMA_BF16_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
             "frac": round(3 * achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "algorithmic_bytes_per_call": alg_bytes,
             "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 MFMA terms per fp32 product; "
                          "achieved counts algorithmic flops (2*N*P*Q*K*R*S*C/g), not the 3x issued",
             "frac_vs_raw_bf16_peak": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -2016,6 +2016,7 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   } else {
     p = {64, 64, 2, 2, 1, false};
   }
+  // (64x64 tiles on the 1x1 layers, to quarter the atomic bytes of their 32-way splits: measured 15 % slower)
   p.split = split_for(blocks(p.bm, p.bn), p.bm * p.bn >= 128 * 128 ? 2 : 4);
   p.bf16 = wvec && g_conv_split && p.bm % 64 == 0 && p.bn % 64 == 0;
   return p;
