@@ -16,7 +16,7 @@ LIB = os.path.join(OUT, "libcpmrcnn_hip.so")
 COMMON = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]
 # translation units whose arithmetic must round exactly like the reference's C++ (no FMA contraction)
-EXACT = {"roi_align.hip", "nms.hip", "detect_glue.hip", "soft_nms.hip", "image_prep.hip"}
+EXACT = {"roi_align.hip", "nms.hip", "detect_glue.hip", "soft_nms.hip", "image_prep.hip", "roi_lists.hip"}
 
 
 def sources():

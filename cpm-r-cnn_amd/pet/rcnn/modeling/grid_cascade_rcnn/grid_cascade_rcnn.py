@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 import pet.lib.ops as ops
+from pet.lib.ops import roi_lists as RL
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
 from pet.rcnn.modeling.grid_cascade_rcnn.inference import post_processor
@@ -56,8 +57,16 @@ class GridCascadeRCNN(nn.Module):
         self.last_counts = {}
         # CPM_FUSED_GLUE=0 runs the per-image formulation (kept as the in-tree cross-check of the fused kernels)
         self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
+        # proposals arrive as a packed device list and every RoI set of the step is built on the device
+        # (_forward_train_lists); CPM_DEVICE_LISTS=0 keeps the BoxList formulation with its host-built index lists
+        self.takes_device_lists = (self.fused_glue and os.environ.get("CPM_DEVICE_LISTS", "1") != "0"
+                                   and not (G.FUSED_ON or G.BETTER_ROI or G.TARGET_REFINE or G.ACROSS_SAMPLE
+                                            or M.RESIZE_ROI or G.RESCORE_OPTION.KEEP_RATIO))
+        self._count_reads = [RL.Counts() for _ in range(M.STAGE_NUM + 2)]
 
     def forward(self, features, proposals, targets=None):
+        if self.training and isinstance(proposals, RL.RoIList):
+            return self._forward_train_lists(features, proposals, targets)
         if self.training:
             loss = {}
             proposals, loss_cls = self._forward_train_cls(features, proposals, targets)
@@ -194,6 +203,93 @@ class GridCascadeRCNN(nn.Module):
             o += counts[i]
         return x, result, losses
 
+    def _forward_train_lists(self, features, props, targets):
+        """The training forward of forward() above with every RoI set built on the device (pet/lib/ops/roi_lists.py):
+        one launch samples the cls RoIs and lists their positives (CLSLossComputation.subsample +
+        keep_only_positive_boxes), one launch per stage transition filters the decoded boxes, appends the gts and
+        re-matches (GridPostProcessor + GridLossComputation.subsample), one gathers the RSM candidates
+        (get_full_sample_boxes) and one samples them.  The host reads back only the per-image counts -- four small
+        copies per step -- and slices views; no index list is built on the host."""
+        G, M = cfg.GRID_RCNN, cfg.GRID_RCNN.CASCADE_MAPPING_OPTION
+        n_img, sizes = props.n_img, props.sizes
+        gt_all, gt_labels, gt_off, off_h = RL.gt_pack(targets)
+        n_gt = off_h[-1]
+        ev = self.cls_loss_evaluator
+        m, sp = ev.proposal_matcher, ev.fg_bg_sampler
+        seeds = torch.randint(0, 2 ** 62, (3,)).tolist()              # CPU generator: torch.manual_seed reproduces
+        with torch.no_grad():
+            sample, pos, counts_all = RL.roi_sample(props, gt_all, gt_labels, gt_off, m.high_threshold,
+                                                    m.low_threshold, sp.batch_size_per_image, sp.positive_fraction,
+                                                    seeds[0], self.max_sample_num_grid, seeds[1],
+                                                    M.FG_IOU_THRESHOLD[0])
+            self._count_reads[0].start(counts_all)
+            c = self._count_reads[0].wait()                           # host round trip 1 of 4
+        if c[-1]:
+            raise RuntimeError("an image holds more than %d proposals; set CPM_DEVICE_LISTS=0" % RL.roi_sample_max_rows())
+        sample.host_counts, pos.host_counts = c[:n_img + 1], c[n_img + 1:2 * (n_img + 1)]
+        # ---- cls head ------------------------------------------------------------------------------------
+        S = sample.total
+        self.last_counts["cls"] = S
+        cls_lists = _views(sample, sizes, ("objectness", "obj"), ("labels", "labels"))
+        ev.set_packed_sample(cls_lists, sample.labels[:S])
+        loss = dict(loss_classifier=ev([self.Output_cls(self.Head_cls(features, cls_lists))]))
+        # ---- CMM cascade ---------------------------------------------------------------------------------
+        cur, R0 = pos, pos.total
+        x = None
+        for s in range(self.stage_num):
+            gev = self.grid_loss_evaluators[s]
+            last = s == self.stage_num - 1
+            R = cur.total
+            self.last_counts["grid_%d" % s] = R
+            rois = cur.boxes[:R]
+            x, _ = getattr(self, "Head_grid_%d" % s)(features, _views(cur, sizes))
+            grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
+            logits = grid_logits["unfused"]
+            ratio = M.STAGE_MAPPING_RATIO[s]
+            loss_grid = ops.grid_bce_loss(logits, rois, cur.gt[:R], gev.whole_map_size, gev.sub_regions, ratio,
+                                          gev.pos_radius, gev.loss_weight)
+            loss["loss_grid_%d" % (s + 1)] = loss_grid * self.stage_loss_weight[s]
+            if G.IOU_HELPER and last:
+                max_iou = cur.iou[:R]
+                iou_target = torch.stack([1 - max_iou, max_iou], dim=1)
+                loss["loss_iou_%d" % (s + 1)] = ops.l2_loss_nosync(iou_logits, iou_target) * G.IOU_LOSS_WEIGHT
+            if last:
+                break
+            with torch.no_grad():
+                img = cur.img[:R]
+                refined, keep = ops.grid_decode(logits, rois, gev.whole_map_size, gev.sub_regions, ratio, img, gt_all,
+                                                gt_off)
+                m2, iou2 = ops.match_rois(refined, img, gt_all, gt_off, M.FG_IOU_THRESHOLD[s + 1],
+                                          M.BG_IOU_THRESHOLD[s + 1])
+                nxt = RL.stage_advance(refined, keep, m2, iou2, img, cur.src[:R] if s else None, n_img, R0, gt_all,
+                                       gt_off, n_gt, sizes)
+                self._count_reads[1 + s].start(nxt.counts)
+                nxt.host_counts = self._count_reads[1 + s].wait()     # the stage's one host round trip
+                cur = nxt
+        if not G.RESCORE_ON:
+            return x, _views(cur, sizes), loss
+        # ---- RSM -----------------------------------------------------------------------------------------
+        rev = self.rescore_loss_evaluator
+        m, sp = rev.proposal_matcher, rev.fg_bg_sampler
+        with torch.no_grad():
+            if cur is pos:                                            # single-stage cascade: rows are their own source
+                cur.src = torch.arange(R0, device=cur.boxes.device)
+            cand = RL.rescore_gather(sample, cur, pos.src, R0, S + cur.total)
+            rs, _, counts_all = RL.roi_sample(cand, gt_all, gt_labels, gt_off, m.high_threshold, m.low_threshold,
+                                              sp.batch_size_per_image, sp.positive_fraction, seeds[2])
+            self._count_reads[-1].start(counts_all)
+            c = self._count_reads[-1].wait()                          # host round trip 4 of 4
+        if c[-1]:
+            raise RuntimeError("an image holds more than %d RSM candidates; set CPM_DEVICE_LISTS=0"
+                               % RL.roi_sample_max_rows())
+        rs.host_counts = c[:n_img + 1]
+        self.last_counts["rescore"] = rs.total
+        rs_lists = _views(rs, sizes, ("objectness", "obj"), ("labels", "labels"))
+        rev.set_packed_sample(rs_lists, rs.labels[:rs.total])
+        logits = self.Output_rescore(self.Head_rescore(features, rs_lists))
+        loss["loss_rescore"] = rev([logits]) * G.RESCORE_LOSS_WEIGHT
+        return x, rs_lists, loss
+
     def _forward_train_rescore(self, features, cls_proposals, grid_proposals, targets):
         with torch.no_grad():
             proposals = get_full_sample_boxes(cls_proposals, grid_proposals)
@@ -222,6 +318,25 @@ class GridCascadeRCNN(nn.Module):
     def _forward_test_rescore(self, features, proposals):
         logits = self.Output_rescore(self.Head_rescore(features, proposals))
         return self.cls_post_processor(logits, proposals, rescore=True)
+
+
+class _PackedBoxLists(list):
+    """per-image BoxLists that are views of one packed device list, plus its [R, 5] RoIAlign rows"""
+    rois5 = None
+
+
+def _views(lst, sizes, *fields):
+    """RoIList -> per-image BoxList views (no device work); fields: (BoxList field, RoIList attribute) pairs"""
+    out, o = _PackedBoxLists(), 0
+    for i in range(lst.n_img):
+        c = lst.host_counts[i]
+        bl = BoxList(lst.boxes[o:o + c], sizes[i], mode="xyxy")
+        for name, attr in fields:
+            bl.add_field(name, getattr(lst, attr)[o:o + c])
+        out.append(bl)
+        o += c
+    out.rois5 = lst.rois5[:o] if lst.rois5 is not None else None
+    return out
 
 
 def get_full_sample_boxes(cls_proposals, grid_proposals):

@@ -28,6 +28,11 @@ class CLSLossComputation(object):
         self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
         # CPM_FUSED_GLUE=0 runs the per-image formulation (the in-tree cross-check of the fused path)
         self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
+        self._packed_labels = None
+
+    def set_packed_sample(self, boxlists, labels):
+        """the sample as produced on the device (pet/lib/ops/roi_lists.py): per-image views + the packed labels"""
+        self._proposals, self._packed_labels = boxlists, labels
 
     def prepare_targets(self, proposals, targets):
         labels = []
@@ -85,6 +90,7 @@ class CLSLossComputation(object):
         return out
 
     def subsample(self, proposals, targets):
+        self._packed_labels = None
         if self.fused_glue and proposals[0].bbox.is_cuda:
             return self._subsample_fused(proposals, targets)
         labels = self.prepare_targets(proposals, targets)
@@ -101,7 +107,9 @@ class CLSLossComputation(object):
         class_logits = cat(class_logits, dim=0)
         if not hasattr(self, "_proposals"):
             raise RuntimeError("subsample needs to be called before")
-        labels = cat([p.get_field("labels") for p in self._proposals], dim=0)
+        labels = self._packed_labels
+        if labels is None:
+            labels = cat([p.get_field("labels") for p in self._proposals], dim=0)
         return F.cross_entropy(class_logits, labels)
 
 

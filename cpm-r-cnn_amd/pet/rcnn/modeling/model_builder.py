@@ -48,6 +48,9 @@ class Generalized_RCNN(nn.Module):
             else:
                 raise ValueError("built RoI heads: MODEL.GRID_ON + GRID_RCNN.CASCADE_MAPPING_ON (CPM R-CNN) and "
                                  "MODEL.FASTER_RCNN + MODEL.CASCADE_ON (Cascade R-CNN)")
+        if not M.RPN_ONLY:
+            # heads that consume the proposals as a packed device list let the RPN skip its host round trips
+            self.RPN.roi_heads_take_lists = bool(getattr(self._roi_heads(), "takes_device_lists", False))
         if cfg.TRAIN.FREEZE_CONV_BODY:
             for p in self.Conv_Body.parameters():
                 p.requires_grad = False

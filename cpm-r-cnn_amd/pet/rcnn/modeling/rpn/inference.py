@@ -11,6 +11,7 @@ import torch
 
 import pet.lib.ops as ops
 from pet.lib.ops import nms_segments
+from pet.lib.ops import roi_lists as RL
 from pet.rcnn.core.config import cfg
 from pet.rcnn.utils.box_coder import BoxCoder
 from pet.rcnn.utils.misc import permute_and_flatten
@@ -29,6 +30,8 @@ class RPNPostProcessor(torch.nn.Module):
         self.fpn_post_nms_per_batch = fpn_post_nms_per_batch
         # CPM_FUSED_GLUE=0 runs the per-level / per-image tensor-op formulation below (the in-tree cross-check)
         self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
+        # CPM_DEVICE_LISTS=0: proposals come back as per-image BoxLists built from host index lists (two round trips)
+        self.device_lists = self.fused_glue and os.environ.get("CPM_DEVICE_LISTS", "1") != "0"
 
     def add_gt_proposals(self, proposals, targets):
         device = proposals[0].bbox.device
@@ -58,7 +61,7 @@ class RPNPostProcessor(torch.nn.Module):
             boxes[n, :, 3].clamp_(min=0, max=h - 1)
         return scores, boxes
 
-    def start_fused(self, anchors, objectness, box_regression):
+    def start_fused(self, anchors, objectness, box_regression, read_counts=True):
         """Same selection as forward() below with the per-level decode in one kernel (cpm_rpn_decode), every
         post-NMS gather done once for the whole batch from host-built index lists, and two host round trips in all
         (NMS counts, cross-level top-k mask) instead of one per image and boolean index."""
@@ -92,12 +95,28 @@ class RPNPostProcessor(torch.nn.Module):
         # host round trip 1, split in two: the kept counts travel to pinned memory behind the NMS kernels and an
         # event marks the copy; the caller may queue unrelated device work (the RPN loss) before finish() waits for
         # that event only -- the device then stays busy while the host builds the index lists below
-        counts_h = torch.empty(counts.shape, dtype=counts.dtype).pin_memory()
-        counts_h.copy_(counts, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
+        counts_h = ev = None
+        if read_counts:
+            counts_h = torch.empty(counts.shape, dtype=counts.dtype).pin_memory()
+            counts_h.copy_(counts, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
         return dict(num_levels=num_levels, N=N, dev=dev, sizes=sizes, offsets=offsets, owner=owner, all_boxes=all_boxes,
-                    all_scores=all_scores, keep=keep, counts_h=counts_h, event=ev)
+                    all_scores=all_scores, keep=keep, counts=counts, counts_h=counts_h, event=ev)
+
+    def can_keep_on_device(self, objectness, targets):
+        """training selection (one top-k over the batch, gts appended) as ONE launch with the result left on the
+        device as a packed list (pet/lib/ops/roi_lists.py) -- no host round trip in the proposal stage at all"""
+        return (self.device_lists and self.training and targets is not None and self.can_fuse(objectness)
+                and (len(objectness) == 1 or self.fpn_post_nms_per_batch)
+                and len(objectness) * objectness[0].shape[0] <= 512)
+
+    def finish_device(self, st, targets):
+        gt_all, _, gt_off, off_h = RL.gt_pack(targets)
+        k = self.fpn_post_nms_top_n if st["num_levels"] > 1 else (1 << 30)
+        return RL.proposals_finalize(st["all_boxes"], st["all_scores"], st["keep"], st["counts"], st["offsets"],
+                                     st["N"], st["num_levels"], self.post_nms_top_n, k, gt_all, gt_off, off_h[-1],
+                                     st["sizes"])
 
     def finish_fused(self, st, targets=None):
         num_levels, N, dev, sizes, offsets, owner = (st[k] for k in ("num_levels", "N", "dev", "sizes", "offsets", "owner"))

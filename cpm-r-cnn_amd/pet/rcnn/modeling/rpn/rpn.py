@@ -55,11 +55,15 @@ class RPNModule(nn.Module):
         elif sel.can_fuse(objectness):
             # proposals up to the NMS, then the (host-sync-free) loss kernels, then the rest of the selection: the
             # loss runs on the device while the host waits for the NMS counts and builds the proposal lists
+            on_device = sel.can_keep_on_device(objectness, targets) and getattr(self, "roi_heads_take_lists", False)
             with torch.no_grad():
-                pending = sel.start_fused(anchors, objectness, rpn_box_regression)
+                pending = sel.start_fused(anchors, objectness, rpn_box_regression, read_counts=not on_device)
+                if on_device:
+                    boxes = sel.finish_device(pending, targets)         # a packed RoIList; nothing is read back
             loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
-            with torch.no_grad():
-                boxes = sel.finish_fused(pending, targets)
+            if not on_device:
+                with torch.no_grad():
+                    boxes = sel.finish_fused(pending, targets)
             return boxes, {"loss_objectness": loss_objectness, "loss_rpn_box_reg": loss_rpn_box_reg}
         else:
             with torch.no_grad():

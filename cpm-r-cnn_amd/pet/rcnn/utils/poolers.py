@@ -47,7 +47,10 @@ class Pooler(nn.Module):
         return torch.cat([ids, concat], dim=1)
 
     def forward(self, x, boxes):
-        rois = self.convert_to_roi_format(boxes)
+        # lists that come packed from the device (pet/lib/ops/roi_lists.py) carry their [R, 5] rows ready-made
+        rois = getattr(boxes, "rois5", None)
+        if rois is None:
+            rois = self.convert_to_roi_format(boxes)
         if len(self.poolers) == 1:
             return self.poolers[0](x[0], rois)
         assert not self.aligned

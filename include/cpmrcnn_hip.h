@@ -382,6 +382,54 @@ int cpm_image_prep(const uint8_t* src, int H, int W, const int32_t* hbounds, con
 int cpm_image_resize_linear(const uint8_t* src, int H, int W, int oh, int ow, float inv_fx, float inv_fy, int flip,
                             int swap_rb, float* dst, void* stream);
 
+/* ---- device-resident RoI lists of the training step -----------------------------------------
+ * Packed lists with a fixed capacity and a per-image count ON THE DEVICE replace the reference's per-image BoxList
+ * surgery (nonzero / boolean index / randperm / cat, each a launch and a device->host round trip).  Every call is one
+ * launch of one workgroup; counts arrays hold [images] per-image rows followed by the total; rois5 outputs are
+ * [capacity][5] = (image, x1, y1, x2, y2), the RoIAlign input format (pet/rcnn/utils/poolers.py:74-85).
+ *
+ * cpm_proposals_finalize: RPNPostProcessor.forward_for_single_feature_map's post-NMS top-n, select_over_all_levels
+ *   (training: ONE top-k over the batch) and add_gt_proposals (pet/rcnn/modeling/rpn/inference.py:101-196).  Inputs
+ *   are cpm_nms_batched's: seg_boxes / seg_scores [S] rows of all (level, image) segments (level-major; h_seg_off HOST
+ *   [levels*images+1]), keep (segment-relative kept rows, best first) and keep_count.  Of the candidates in reference
+ *   order (image, level, rank) the batch_top_k best scores are kept -- ties at the boundary by lowest index, as
+ *   torch.topk does -- in that order, each image followed by its gts (objectness 1).  Rows >= total: img -1.
+ * cpm_roi_sample: CLSLossComputation.subsample (grid_cascade_rcnn/loss.py:29-97): IoU(+1) match against the image's
+ *   gts, Matcher(high, low) labels (gt label / 0 / -1), BalancedPositiveNegativeSampler(batch, max_pos) -- the draw of
+ *   cpm_sample_pos_neg for the same seed -- and the sample compacted in input order.  max_grid > 0 also lists the
+ *   sample's positives, at most max_grid per image (keep_only_positive_boxes, pet/rcnn/utils/misc.py:54-94; a random
+ *   subset drawn from seed_grid), p_src = row in the sample, p_iou = best IoU, p_gt = the box of the best gt if that
+ *   IoU >= grid_high, else of the image's first gt (GridLossComputation.subsample at stage 0, loss.py:144-162:
+ *   t.bbox[matched.clamp(min=0)]).  Images may hold at most cpm_roi_sample_max_rows() rows;
+ *   otherwise *status = 1 and nothing is written.  Padding rows: s_img -1, s_labels -100 (cross_entropy ignore_index).
+ * cpm_stage_advance: GridPostProcessor's training filter + the next stage's subsample
+ *   (grid_cascade_rcnn/inference.py:281-310, loss.py:144-176): rows with keep != 0 and matched >= 0 in order, then the
+ *   image's gts; o_gt = the matched gt box (a gt matches itself, IoU 1), o_src = ride-along row (gt g: gt_src_base+g).
+ * cpm_rescore_gather: get_full_sample_boxes (grid_cascade_rcnn.py:231-245): per image the cls sample's rows with
+ *   label <= 0, then the last stage's rows; a last-stage row's objectness is followed through its ride-along index
+ *   g_src: < n_first -> the cls sample row p_src[g_src], otherwise an appended gt (objectness 1). */
+int cpm_proposals_finalize(const float* seg_boxes, const float* seg_scores, const int64_t* keep,
+                           const int32_t* keep_count, const int32_t* h_seg_off, int n_images, int n_levels,
+                           int post_nms_top_n, int batch_top_k, const float* gts, const int32_t* gt_off, int capacity,
+                           float* out_boxes, float* out_obj, float* out_rois5 /* may be NULL */, int32_t* out_img,
+                           int32_t* out_counts, void* stream);
+int cpm_roi_sample_max_rows(void);
+int cpm_roi_sample(const float* boxes, const float* obj, const int32_t* counts, int n_images, const float* gts,
+                   const int64_t* gt_labels, const int32_t* gt_off, float high, float low, int batch_size_per_image,
+                   int max_pos, uint64_t seed, int max_grid, uint64_t seed_grid, float grid_high, int cap_sample,
+                   float* s_boxes, float* s_obj, int64_t* s_labels, int32_t* s_img, float* s_rois5, int32_t* s_counts,
+                   int cap_grid, float* p_boxes, float* p_gt, float* p_iou, int64_t* p_src, int32_t* p_img,
+                   float* p_rois5, int32_t* p_counts, int32_t* status, void* stream);
+int cpm_stage_advance(const float* refined, const uint8_t* keep, const int64_t* matched, const float* iou,
+                      const int32_t* img, const int64_t* src /* NULL: row index */, int R, int n_images,
+                      int64_t gt_src_base,
+                      const float* gts, const int32_t* gt_off, int capacity, float* o_rois, float* o_gt, float* o_iou,
+                      int64_t* o_src, int32_t* o_img, float* o_rois5, int32_t* o_counts, void* stream);
+int cpm_rescore_gather(const float* s_boxes, const float* s_obj, const int64_t* s_labels, const int32_t* s_counts,
+                       const float* g_boxes, const int64_t* g_src, const int32_t* g_counts, const int64_t* p_src,
+                       int n_first, int n_images, int capacity, float* o_boxes, float* o_obj, int32_t* o_counts,
+                       void* stream);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------
  * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and
  * remembers the launch's ALGORITHMIC flops (2*N*P*Q*K*R*S*C/groups); cpm_prof_enable(0) stops and

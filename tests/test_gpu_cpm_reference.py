@@ -3,8 +3,9 @@
 The fixture holds a training-mode forward of the reference's GridCascadeRCNN (grid_cascade_rcnn.py:57-224) on a
 2-image batch whose proposal sets every sampler keeps whole (no random draw): the RoI set entering each grid stage,
 the cls / RSM samples, the 8 losses and gradient statistics -- and CLSPostProcessor's candidate selection
-(inference.py:59-124).  The batch-fused device path (cpm_match_rois / cpm_grid_bce_loss / cpm_grid_decode) and the
-per-image formulation are BOTH held to it, in both conv arithmetics."""
+(inference.py:59-124).  The packed device-list path the training step runs on (csrc/roi_lists.hip), the batch-fused
+path with host index lists (cpm_match_rois / cpm_grid_bce_loss / cpm_grid_decode) and the per-image formulation are ALL
+held to it, in both conv arithmetics."""
 import json
 import os
 
@@ -79,12 +80,12 @@ def _same_boxes(got, want, what, tol=0.05, flips_allowed=0):
     return int(flipped.sum())
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused_glue", "per_image"])
+@pytest.mark.parametrize("fused", ["lists", True, False], ids=["device_lists", "fused_glue", "per_image"])
 def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fused):
     g = golden
     head = model.Grid_Cascade_RCNN
     saved = (head.fused_glue, head.cls_loss_evaluator.fused_glue, head.rescore_loss_evaluator.fused_glue)
-    head.fused_glue = head.cls_loss_evaluator.fused_glue = head.rescore_loss_evaluator.fused_glue = fused
+    head.fused_glue = head.cls_loss_evaluator.fused_glue = head.rescore_loss_evaluator.fused_glue = bool(fused)
     stage_rois = []
     heads = [getattr(head, "Head_grid_%d" % s) for s in range(3)]
     hooks = [h.register_forward_pre_hook(lambda m, a: stage_rois.append([b.bbox.detach().clone() for b in a[1]]))
@@ -94,6 +95,10 @@ def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fus
         for q in model.parameters():
             q.grad = None
         props, targets = _inputs(g)
+        if fused == "lists":                     # the packed device lists the training step runs on (roi_lists.hip)
+            from pet.lib.ops import roi_lists as RL
+            assert head.takes_device_lists
+            props = RL.from_boxlists(props)
         feats = model.Conv_Body_FPN(model.Conv_Body(torch.from_numpy(g["img"]).cuda()))
         x, result, losses = head(feats, props, targets)
         # --- the samples: cls head, every grid stage, RSM head ------------------------------------------------
