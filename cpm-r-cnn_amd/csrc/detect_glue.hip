@@ -241,6 +241,65 @@ __global__ __launch_bounds__(256) void rpn_decode_kernel(const float4* __restric
   out[i] = o;
 }
 
+// all FPN levels in one launch (blockIdx.y = level), results written straight into the level-major segment layout
+// the batched NMS reads (segment = level * N + image, k_l rows each)
+constexpr int DEC_LEVELS = 8;
+struct DecodeLevels {
+  const float4* reg[DEC_LEVELS];
+  const int64_t* idx[DEC_LEVELS];
+  const float4* anchors[DEC_LEVELS];
+  int A[DEC_LEVELS], k[DEC_LEVELS], out_off[DEC_LEVELS];
+};
+
+__global__ __launch_bounds__(256) void rpn_decode_multi_kernel(DecodeLevels lv, int N, float wx, float wy, float ww,
+                                                               float wh, float clip, ImSizes sz,
+                                                               float4* __restrict__ out) {
+  const int l = blockIdx.y, k = lv.k[l], A = lv.A[l];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * k) return;
+  const int n = i / k;
+  const int64_t j = lv.idx[l][i];
+  const float4 b = lv.anchors[l][j], c = lv.reg[l][(int64_t)n * A + j];
+  const float w = b.z - b.x + 1.f, h = b.w - b.y + 1.f;
+  const float cx = b.x + 0.5f * w, cy = b.y + 0.5f * h;
+  const float dx = c.x / wx, dy = c.y / wy;
+  const float dw = fminf(c.z / ww, clip), dh = fminf(c.w / wh, clip);
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  const float mx = sz.w[n] - 1.f, my = sz.h[n] - 1.f;
+  float4 o;
+  o.x = fminf(fmaxf(pcx - 0.5f * pw, 0.f), mx);
+  o.y = fminf(fmaxf(pcy - 0.5f * ph, 0.f), my);
+  o.z = fminf(fmaxf(pcx + 0.5f * pw - 1.f, 0.f), mx);
+  o.w = fminf(fmaxf(pcy + 0.5f * ph - 1.f, 0.f), my);
+  out[lv.out_off[l] + i] = o;
+}
+
+// objectness logits of every level -> sigmoid, one launch (RPNPostProcessor: objectness.sigmoid(), inference.py:72);
+// the expression torch's sigmoid kernel evaluates, so the scores -- and every tie among them -- are the same bits
+struct SigLevels { const float* in[DEC_LEVELS]; int n[DEC_LEVELS], out_off[DEC_LEVELS]; };
+
+__global__ __launch_bounds__(256) void sigmoid_multi_kernel(SigLevels lv, float* __restrict__ out) {
+  const int l = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= lv.n[l]) return;
+  out[lv.out_off[l] + i] = 1.f / (1.f + expf(-lv.in[l][i]));
+}
+
+// RPN anchor labels from the match (rpn/loss.py:60-79): 1 matched, 0 below the low threshold, -1 between the
+// thresholds or not visible
+__global__ __launch_bounds__(256) void rpn_labels_kernel(const int64_t* __restrict__ matched,
+                                                         const uint8_t* __restrict__ vis, int64_t total,
+                                                         int discard_between, float* __restrict__ lab) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t m = matched[i];
+  float v = m >= 0 ? 1.f : 0.f;
+  if (discard_between && m == -2) v = -1.f;
+  if (vis && !vis[i]) v = -1.f;
+  lab[i] = v;
+}
+
 int fill_geom(GridGeom& G, int points, int map_size, const int* sub_xy, const int64_t* strides) {
   if (points <= 0 || points > MAX_POINTS) return -1;
   int gs = 1;
@@ -410,4 +469,54 @@ CPM_EXPORT int cpm_rpn_decode(const float* reg, const int64_t* topk_idx, const f
                      (const float4*)reg, topk_idx, (const float4*)anchors, N, A, k, weights4[0], weights4[1],
                      weights4[2], weights4[3], clip, sz, (float4*)out_boxes);
   return cpm::check_launch("rpn_decode");
+}
+
+CPM_EXPORT int cpm_rpn_decode_multi(const float* const* reg, const int64_t* const* topk_idx,
+                                    const float* const* anchors, const int* A, const int* k, const int* out_off,
+                                    int levels, int N, const float* weights4, float clip, const float* im_w,
+                                    const float* im_h, float* out_boxes, void* stream) {
+  CPM_REQUIRE(levels >= 1 && levels <= DEC_LEVELS && N >= 1 && N <= 64, "1..8 levels, 1..64 images");
+  CPM_REQUIRE(reg && topk_idx && anchors && A && k && out_off && weights4 && im_w && im_h && out_boxes, "null pointer");
+  DecodeLevels lv = {};
+  int kmax = 0;
+  for (int l = 0; l < levels; ++l) {
+    CPM_REQUIRE(reg[l] && topk_idx[l] && anchors[l] && A[l] >= 1 && k[l] >= 1 && out_off[l] >= 0, "bad level");
+    CPM_REQUIRE((((uintptr_t)reg[l] | (uintptr_t)anchors[l]) & 15) == 0, "boxes must be 16-byte aligned");
+    lv.reg[l] = (const float4*)reg[l]; lv.idx[l] = topk_idx[l]; lv.anchors[l] = (const float4*)anchors[l];
+    lv.A[l] = A[l]; lv.k[l] = k[l]; lv.out_off[l] = out_off[l];
+    if (k[l] > kmax) kmax = k[l];
+  }
+  CPM_REQUIRE(((uintptr_t)out_boxes & 15) == 0, "boxes must be 16-byte aligned");
+  ImSizes sz;
+  for (int n = 0; n < N; ++n) { sz.w[n] = im_w[n]; sz.h[n] = im_h[n]; }
+  hipLaunchKernelGGL(rpn_decode_multi_kernel, dim3((unsigned)((N * kmax + 255) / 256), levels), dim3(256), 0,
+                     (hipStream_t)stream, lv, N, weights4[0], weights4[1], weights4[2], weights4[3], clip, sz,
+                     (float4*)out_boxes);
+  return cpm::check_launch("rpn_decode_multi");
+}
+
+CPM_EXPORT int cpm_sigmoid_multi(const float* const* in, const int* n, const int* out_off, int levels, float* out,
+                                 void* stream) {
+  CPM_REQUIRE(levels >= 1 && levels <= DEC_LEVELS && in && n && out_off && out, "1..8 levels, non-null pointers");
+  SigLevels lv = {};
+  int nmax = 0;
+  for (int l = 0; l < levels; ++l) {
+    CPM_REQUIRE(in[l] && n[l] >= 0 && out_off[l] >= 0, "bad level");
+    lv.in[l] = in[l]; lv.n[l] = n[l]; lv.out_off[l] = out_off[l];
+    if (n[l] > nmax) nmax = n[l];
+  }
+  if (nmax == 0) return CPM_OK;
+  hipLaunchKernelGGL(sigmoid_multi_kernel, dim3((unsigned)((nmax + 255) / 256), levels), dim3(256), 0,
+                     (hipStream_t)stream, lv, out);
+  return cpm::check_launch("sigmoid_multi");
+}
+
+CPM_EXPORT int cpm_rpn_labels(const int64_t* matched, const uint8_t* visible, int64_t total, int discard_between,
+                              float* labels, void* stream) {
+  CPM_REQUIRE(total >= 0, "total >= 0");
+  if (total == 0) return CPM_OK;
+  CPM_REQUIRE(matched && labels, "null pointer");
+  hipLaunchKernelGGL(rpn_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     matched, visible, total, discard_between, labels);
+  return cpm::check_launch("rpn_labels");
 }

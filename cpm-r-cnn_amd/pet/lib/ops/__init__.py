@@ -11,5 +11,6 @@ from .pool_points_interp import pool_points_interp, PoolPointsInterp
 from .boxes import box_iou, box_voting, box_ml_voting
 from .deform_conv import deform_conv, cols_conv, DeformConv, DeformConvPack
 from .detect_glue import match_rois, grid_bce_loss, grid_decode, rpn_decode, topk_rows, topk_rows_multi, rpn_loss, sample_pos_neg
+from .detect_glue import sigmoid_multi, rpn_decode_multi, rpn_labels
 from .image_prep import image_prep, resample_tables, value_table, resize_linear
 from .offpath import *  # noqa: F401,F403  (every remaining name of the reference's ops package imports)

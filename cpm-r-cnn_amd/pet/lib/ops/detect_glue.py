@@ -133,6 +133,57 @@ def rpn_decode(reg, topk_idx, anchors, weights, clip, image_sizes):
     return out
 
 
+def sigmoid_multi(logit_list):
+    """sigmoid of several fp32 tensors in one launch (cpm_sigmoid_multi); returns views of one flat buffer, shaped
+    like the inputs (which must be dense in memory; the values follow the inputs' memory order)."""
+    H.require_gpu(*logit_list)
+    L = len(logit_list)
+    ns = [t.numel() for t in logit_list]
+    offs = [0]
+    for n in ns:
+        offs.append(offs[-1] + n)
+    flat = torch.empty((offs[-1],), dtype=torch.float32, device=logit_list[0].device)
+    vp, ip = ctypes.c_void_p * L, ctypes.c_int * L
+    with H.guard(flat.device):
+        rc = H.lib().cpm_sigmoid_multi(vp(*[t.data_ptr() for t in logit_list]), ip(*ns), ip(*offs[:-1]), L,
+                                       H.ptr(flat), H.stream())
+    H.check(rc, "sigmoid_multi")
+    return [flat[offs[i]:offs[i + 1]] for i in range(L)]
+
+
+def rpn_decode_multi(regs, idxs, anchors, out_offs, out_boxes, weights, clip, image_sizes):
+    """rpn_decode for all levels in one launch: regs[l] [N, A_l, 4], idxs[l] [N, k_l] int64, anchors[l] [A_l, 4];
+    level l's boxes are written to out_boxes[out_offs[l] : out_offs[l] + N * k_l]."""
+    L, N = len(regs), regs[0].shape[0]
+    vp, ip = ctypes.c_void_p * L, ctypes.c_int * L
+    w4 = (ctypes.c_float * 4)(*[float(v) for v in weights])
+    iw = (ctypes.c_float * N)(*[float(s[0]) for s in image_sizes])
+    ih = (ctypes.c_float * N)(*[float(s[1]) for s in image_sizes])
+    for r, i in zip(regs, idxs):
+        if not (r.is_contiguous() and i.is_contiguous()):
+            raise RuntimeError("rpn_decode_multi: contiguous inputs")
+    with H.guard(out_boxes.device):
+        rc = H.lib().cpm_rpn_decode_multi(vp(*[r.data_ptr() for r in regs]), vp(*[i.data_ptr() for i in idxs]),
+                                          vp(*[a.data_ptr() for a in anchors]), ip(*[r.shape[1] for r in regs]),
+                                          ip(*[i.shape[1] for i in idxs]), ip(*[int(o) for o in out_offs]), L, N, w4,
+                                          H.f(clip), iw, ih, H.ptr(out_boxes), H.stream())
+    H.check(rc, "rpn_decode_multi")
+    return out_boxes
+
+
+def rpn_labels(matched, visible, discard_between=True):
+    """anchor labels (1 / 0 / -1, fp32) from the match and the visibility mask (cpm_rpn_labels)"""
+    lab = torch.empty(matched.shape, dtype=torch.float32, device=matched.device)
+    vis = None
+    if visible is not None:
+        vis = visible.contiguous().view(torch.uint8)
+    with H.guard(matched.device):
+        rc = H.lib().cpm_rpn_labels(H.ptr(matched), H.ptr(vis), ctypes.c_int64(matched.numel()),
+                                    int(bool(discard_between)), H.ptr(lab), H.stream())
+    H.check(rc, "rpn_labels")
+    return lab
+
+
 TOPK_MAX = 2048
 
 
@@ -155,9 +206,9 @@ def topk_rows(scores, k):
     return vals, idx
 
 
-def topk_rows_multi(score_list, ks):
+def topk_rows_multi(score_list, ks, out=None):
     """topk_rows for several [rows, n_l] matrices (same rows) in one launch (cpm_topk_rows_multi): the RPN's FPN levels.
-    Returns a list of (values, indices)."""
+    Returns a list of (values, indices); `out` may supply that list ([rows, k_l] fp32 / int64, contiguous)."""
     if not score_list or len(score_list) != len(ks) or len(ks) > 8:
         raise RuntimeError("topk_rows_multi: 1..8 matrices with one k each")
     H.require_gpu(*score_list)
@@ -170,6 +221,13 @@ def topk_rows_multi(score_list, ks):
             raise RuntimeError("topk_rows_multi: k must be in [1, min(n, %d)], got %d (n = %d)" % (TOPK_MAX, k, s.shape[1]))
         s = s if s.is_contiguous() else s.contiguous()
         ss.append(s)
+        if out is not None:
+            v, i = out[len(outs)]
+            if (v.shape != (rows, k) or i.shape != (rows, k) or v.dtype != torch.float32 or i.dtype != torch.int64
+                    or not v.is_contiguous() or not i.is_contiguous()):
+                raise RuntimeError("topk_rows_multi: out must hold contiguous [rows, k] fp32 / int64 pairs")
+            outs.append((v, i))
+            continue
         outs.append((torch.empty((rows, k), dtype=torch.float32, device=s.device),
                      torch.empty((rows, k), dtype=torch.int64, device=s.device)))
     L = len(ss)

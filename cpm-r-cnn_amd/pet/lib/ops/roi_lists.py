@@ -30,6 +30,22 @@ class RoIList(object):
             raise RuntimeError("RoIList counts have not been read back (Counts.read)")
         return self.host_counts[-1]
 
+    def to_boxlists(self):
+        """per-image BoxLists (bbox + "objectness"), reading the counts back if needed -- for consumers outside the
+        packed training path (tests, tools)"""
+        from pet.utils.data.structures.bounding_box import BoxList
+        if self.host_counts is None:
+            self.host_counts = self.counts.cpu().tolist()
+        out, o = [], 0
+        for i in range(self.n_img):
+            c = self.host_counts[i]
+            bl = BoxList(self.boxes[o:o + c], self.sizes[i], mode="xyxy")
+            if self.obj is not None:
+                bl.add_field("objectness", self.obj[o:o + c])
+            out.append(bl)
+            o += c
+        return out
+
     def live(self, name):
         """the live rows of a field (a view); needs the counts on the host"""
         return getattr(self, name)[:self.total]

@@ -65,6 +65,7 @@ class AnchorGenerator(nn.Module):
         self.cell_anchors = BufferList(cells)
         self.straddle_thresh = straddle_thresh
         self._cache = {}
+        self._image_cache, self._batch_cache = {}, {}
 
     def num_anchors_per_location(self):
         return [len(c) for c in self.cell_anchors]
@@ -95,16 +96,52 @@ class AnchorGenerator(nn.Module):
         boxlist.add_field("visibility", self.visibility(boxlist.bbox, w, h))
 
     def forward(self, image_list, feature_maps):
-        per_level = self.grid_anchors([f.shape[-2:] for f in feature_maps])
-        anchors = []
+        """list (image) of list (level) of BoxLists with a "visibility" field.  Pure functions of the feature-map and
+        image sizes: built once per distinct size and handed out again (read-only) on later steps -- a training step
+        otherwise spends ~70 small launches per batch on the visibility masks alone."""
+        grid_sizes = tuple((int(f.shape[-2]), int(f.shape[-1])) for f in feature_maps)
+        dev = str(feature_maps[0].device)
+        per_level = None
+        anchors = AnchorBatch()
         for (ih, iw) in image_list.image_sizes:
-            in_image = []
-            for a in per_level:
-                bl = BoxList(a, (iw, ih), mode="xyxy")
-                self.add_visibility_to(bl)
-                in_image.append(bl)
+            key = (grid_sizes, int(ih), int(iw), dev)
+            in_image = self._image_cache.get(key)
+            if in_image is None:
+                if per_level is None:
+                    per_level = self.grid_anchors(grid_sizes)
+                in_image = []
+                for a in per_level:
+                    bl = BoxList(a, (iw, ih), mode="xyxy")
+                    self.add_visibility_to(bl)
+                    in_image.append(bl)
+                if len(self._image_cache) >= 256:
+                    self._image_cache.clear()
+                self._image_cache[key] = in_image
             anchors.append(in_image)
+        anchors.key = (grid_sizes, tuple((int(h), int(w)) for h, w in image_list.image_sizes), dev)
+        anchors.owner = self
         return anchors
+
+    def batch_pack(self, anchors):
+        """(boxes [T, 4], visibility [T], image index int32 [T], anchors per image) of all anchors of the batch,
+        image-major then level -- what the batch-fused RPN loss consumes; remembered per (feature, image) sizes."""
+        pack = self._batch_cache.get(anchors.key)
+        if pack is None:
+            n_img = len(anchors)
+            abox = torch.cat([a.bbox for per_img in anchors for a in per_img], dim=0)
+            vis = torch.cat([a.get_field("visibility") for per_img in anchors for a in per_img], dim=0)
+            per = abox.shape[0] // n_img
+            img = torch.arange(n_img, device=abox.device).repeat_interleave(per).to(torch.int32)
+            if len(self._batch_cache) >= 64:
+                self._batch_cache.clear()
+            pack = self._batch_cache[anchors.key] = (abox, vis, img, per)
+        return pack
+
+
+class AnchorBatch(list):
+    """the anchors of a batch + the key of their cached concatenation (AnchorGenerator.batch_pack)"""
+    key = None
+    owner = None
 
 
 def make_anchor_generator():

@@ -68,29 +68,39 @@ class RPNPostProcessor(torch.nn.Module):
         num_levels, N = len(objectness), objectness[0].shape[0]
         dev = objectness[0].device
         sizes = [per_img[0].size for per_img in anchors]
-        seg_boxes, seg_scores, offsets, owner = [], [], [0], []
-        lvl_scores, lvl_k = [], []
+        lvl_k, lvl_n, offsets, owner = [], [], [0], []
         for o in objectness:
             _, A, H, W = o.shape
-            lvl_scores.append(permute_and_flatten(o, N, A, 1, H, W).view(N, -1).sigmoid())
+            lvl_n.append(A * H * W)
             lvl_k.append(min(self.pre_nms_top_n, A * H * W))
-        if max(lvl_k) <= ops.detect_glue.TOPK_MAX and num_levels <= 8:
-            picked = ops.topk_rows_multi(lvl_scores, lvl_k)  # all images of all levels in one launch
-        else:
-            picked = [s.topk(k, dim=1, sorted=True) for s, k in zip(lvl_scores, lvl_k)]
-        for lvl, b in enumerate(box_regression):
-            _, A4, H, W = b.shape
-            reg = permute_and_flatten(b, N, A4 // 4, 4, H, W)
-            k = lvl_k[lvl]
-            scores, idx = picked[lvl]
-            boxes = ops.rpn_decode(reg, idx, anchors[0][lvl].bbox, self.box_coder.weights,
-                                   self.box_coder.bbox_xform_clip, sizes)
-            seg_boxes.append(boxes.view(N * k, 4))
-            seg_scores.append(scores.reshape(N * k))
-            for n in range(N):
-                offsets.append(offsets[-1] + k)
+            for n in range(N):                                # segments: level-major, then image
+                offsets.append(offsets[-1] + lvl_k[-1])
                 owner.append(n)
-        all_boxes, all_scores = torch.cat(seg_boxes, 0), torch.cat(seg_scores, 0)
+        lvl_off = offsets[0::N]
+        regs = [permute_and_flatten(b, N, b.shape[1] // 4, 4, b.shape[2], b.shape[3]) for b in box_regression]
+        dense = all(o.permute(0, 2, 3, 1).is_contiguous() for o in objectness) and all(r.is_contiguous() for r in regs)
+        if max(lvl_k) <= ops.detect_glue.TOPK_MAX and num_levels <= 8 and dense:
+            # three launches for all levels and images: sigmoid, row-wise top-k, decode -- the last two writing
+            # straight into the segment layout the batched NMS reads (no per-level tensors, no cat)
+            lvl_scores = [s.view(N, n) for s, n in zip(ops.sigmoid_multi(objectness), lvl_n)]
+            all_scores = torch.empty((offsets[-1],), dtype=torch.float32, device=dev)
+            all_idx = torch.empty((offsets[-1],), dtype=torch.int64, device=dev)
+            all_boxes = torch.empty((offsets[-1], 4), dtype=torch.float32, device=dev)
+            out = [(all_scores[lvl_off[l]:lvl_off[l + 1]].view(N, lvl_k[l]), all_idx[lvl_off[l]:lvl_off[l + 1]].view(N, lvl_k[l]))
+                   for l in range(num_levels)]
+            ops.topk_rows_multi(lvl_scores, lvl_k, out=out)
+            ops.rpn_decode_multi(regs, [o[1] for o in out], [a.bbox for a in anchors[0]], lvl_off[:-1], all_boxes,
+                                 self.box_coder.weights, self.box_coder.bbox_xform_clip, sizes)
+        else:
+            seg_boxes, seg_scores = [], []
+            for lvl, o in enumerate(objectness):
+                scores, idx = permute_and_flatten(o, N, o.shape[1], 1, o.shape[2], o.shape[3]).view(N, -1).sigmoid() \
+                    .topk(lvl_k[lvl], dim=1, sorted=True)
+                boxes = ops.rpn_decode(regs[lvl], idx, anchors[0][lvl].bbox, self.box_coder.weights,
+                                       self.box_coder.bbox_xform_clip, sizes)
+                seg_boxes.append(boxes.view(N * lvl_k[lvl], 4))
+                seg_scores.append(scores.reshape(N * lvl_k[lvl]))
+            all_boxes, all_scores = torch.cat(seg_boxes, 0), torch.cat(seg_scores, 0)
         keep, counts = nms_segments(all_boxes, all_scores, None, offsets, self.nms_thresh, 0)
         # host round trip 1, split in two: the kept counts travel to pinned memory behind the NMS kernels and an
         # event marks the copy; the caller may queue unrelated device work (the RPN loss) before finish() waits for

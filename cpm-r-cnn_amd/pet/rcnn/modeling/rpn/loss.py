@@ -8,6 +8,7 @@ from torch.nn import functional as F
 
 import pet.lib.ops as ops
 from pet.lib.ops import smooth_l1_loss
+from pet.lib.ops.roi_lists import gt_pack
 from pet.rcnn.core.config import cfg
 from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from pet.rcnn.utils.matcher import Matcher
@@ -47,23 +48,27 @@ class RPNLossComputation(object):
         targets, both losses and both gradients over all anchors under the sample masks (identical values and gradients
         to the nonzero()-gathered subsets: a gather's backward scatters into zeros exactly where the mask is zero)."""
         n_img = len(anchors)
-        abox = torch.cat([a.bbox for per_img in anchors for a in per_img], dim=0)
-        vis = torch.cat([a.get_field("visibility") for per_img in anchors for a in per_img], dim=0)
-        per = abox.shape[0] // n_img
+        if getattr(anchors, "owner", None) is not None:
+            abox, vis, img, per = anchors.owner.batch_pack(anchors)       # cached per (feature, image) sizes
+        else:
+            abox = torch.cat([a.bbox for per_img in anchors for a in per_img], dim=0)
+            vis = torch.cat([a.get_field("visibility") for per_img in anchors for a in per_img], dim=0)
+            per = abox.shape[0] // n_img
+            img = torch.arange(n_img, device=abox.device).repeat_interleave(per).to(torch.int32)
         assert all(sum(len(a) for a in per_img) == per for per_img in anchors)
-        dev = abox.device
-        img = torch.arange(n_img, device=dev).repeat_interleave(per)
-        gt_all = torch.cat([t.bbox for t in targets], dim=0)
-        gt_off = torch.tensor([0] + [len(t) for t in targets]).cumsum(0).to(torch.int32).pin_memory().to(
-            dev, non_blocking=True)
+        gt_all, _, gt_off, _ = gt_pack(targets)
         m = self.proposal_matcher
-        matched, _ = ops.match_rois(abox, img.to(torch.int32), gt_all, gt_off, m.high_threshold, m.low_threshold,
+        matched, _ = ops.match_rois(abox, img, gt_all, gt_off, m.high_threshold, m.low_threshold,
                                     m.allow_low_quality_matches)
-        lab = self.generate_labels_func(matched).to(dtype=torch.float32)
-        if "between_thresholds" in self.discard_cases:
-            lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1.0, lab)
-        if "not_visibility" in self.discard_cases:
-            lab = torch.where(vis, lab, -1.0)
+        if self.generate_labels_func is generate_rpn_labels:
+            lab = ops.rpn_labels(matched, vis if "not_visibility" in self.discard_cases else None,
+                                 "between_thresholds" in self.discard_cases)
+        else:
+            lab = self.generate_labels_func(matched).to(dtype=torch.float32)
+            if "between_thresholds" in self.discard_cases:
+                lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1.0, lab)
+            if "not_visibility" in self.discard_cases:
+                lab = torch.where(vis, lab, -1.0)
         pos, neg, quota = batch_pos_neg_sample(lab, [per] * n_img, self.fg_bg_sampler.batch_size_per_image,
                                                self.fg_bg_sampler.positive_fraction)
         n_sampled = quota.sum()

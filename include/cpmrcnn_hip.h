@@ -382,6 +382,20 @@ int cpm_image_prep(const uint8_t* src, int H, int W, const int32_t* hbounds, con
 int cpm_image_resize_linear(const uint8_t* src, int H, int W, int oh, int ow, float inv_fx, float inv_fy, int flip,
                             int swap_rb, float* dst, void* stream);
 
+/* ---- RPN proposal stage, all FPN levels per launch --------------------------------------------
+ * cpm_sigmoid_multi: objectness.sigmoid() (pet/rcnn/modeling/rpn/inference.py:72) of `levels` (<= 8) logit arrays of
+ *   n[l] elements into out + out_off[l]; evaluates 1 / (1 + expf(-x)) like the framework kernel (same bits, same ties).
+ * cpm_rpn_decode_multi: cpm_rpn_decode for every level at once; level l's N x k[l] boxes land at out_boxes + out_off[l]
+ *   rows (the level-major segment layout cpm_nms_batched reads).
+ * cpm_rpn_labels: anchor labels of RPNLossComputation.prepare_targets (rpn/loss.py:60-79) from the match: 1 matched,
+ *   0 below the low threshold, -1 between thresholds (if discard_between) or not visible (visible may be NULL). */
+int cpm_sigmoid_multi(const float* const* in, const int* n, const int* out_off, int levels, float* out, void* stream);
+int cpm_rpn_decode_multi(const float* const* reg, const int64_t* const* topk_idx, const float* const* anchors,
+                         const int* A, const int* k, const int* out_off, int levels, int N, const float* weights4,
+                         float clip, const float* im_w, const float* im_h, float* out_boxes, void* stream);
+int cpm_rpn_labels(const int64_t* matched, const uint8_t* visible, int64_t total, int discard_between, float* labels,
+                   void* stream);
+
 /* ---- device-resident RoI lists of the training step -----------------------------------------
  * Packed lists with a fixed capacity and a per-image count ON THE DEVICE replace the reference's per-image BoxList
  * surgery (nonzero / boolean index / randperm / cat, each a launch and a device->host round trip).  Every call is one

@@ -134,7 +134,7 @@ def test_fused_cascade_equals_per_image_path():
         torch.manual_seed(0)
         with torch.no_grad():
             props, _ = m.RPN(to_image_list(images.cuda()), feats, targets)
-            props, _ = head._forward_train_cls(feats, props, targets)
+            props, _ = head._forward_train_cls(feats, props.to_boxlists(), targets)
         outs = []
         for fused in (True, True, False):                           # the fused path twice: its run-to-run noise
             head.fused_glue = fused
@@ -254,6 +254,7 @@ def test_fused_cls_subsample_properties():
         with torch.no_grad():
             feats = m.Conv_Body_FPN(m.Conv_Body(il.tensors.contiguous(memory_format=torch.channels_last)))
             props, _ = m.RPN(il, feats, targets)
+            props = props.to_boxlists()
         ev = m.Grid_Cascade_RCNN.cls_loss_evaluator
         want_labels = ev.prepare_targets(props, targets)
         ev.fused_glue = True

@@ -291,3 +291,42 @@ def test_device_list_head_equals_boxlist_head():
             assert float((a - b).abs().max()) <= 3 * noise + 2e-3 * scale + 1e-9, lvl
     finally:
         config.reset_cfg()
+
+
+def test_sigmoid_multi_is_bitwise_torch_sigmoid():
+    """The RPN scores must be the framework's sigmoid bit for bit: ties among saturated scores decide the top-k order."""
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(2, 3, 50, 84, generator=g).mul(6).cuda().contiguous(memory_format=torch.channels_last),
+          torch.cat([torch.linspace(-110, 110, 70001), torch.tensor([0.0, -0.0, 88.7, -88.7, 1e-30, 17.3, -17.3])]).cuda(),
+          torch.randn(5, generator=g).cuda()]
+    outs = ops.sigmoid_multi(xs)
+    for x, o in zip(xs, outs):
+        want = torch.sigmoid(x)
+        want = want.permute(0, 2, 3, 1).reshape(-1) if x.dim() == 4 else want.reshape(-1)
+        assert torch.equal(o, want)
+
+
+def test_rpn_decode_multi_and_labels_equal_single_level_ops():
+    import pet.lib.ops as ops
+    rng = np.random.default_rng(8)
+    N, sizes = 2, [(640, 480), (600, 400)]
+    As, ks = [5000, 1200, 300], [700, 700, 300]
+    regs, idxs, ancs, offs = [], [], [], [0]
+    for A, k in zip(As, ks):
+        regs.append(torch.from_numpy(rng.normal(0, 0.5, (N, A, 4)).astype(np.float32)).cuda())
+        idxs.append(torch.from_numpy(np.stack([rng.permutation(A)[:k] for _ in range(N)]).astype(np.int64)).cuda())
+        ancs.append(torch.from_numpy(_rand_boxes(rng, A, 640, 480, 8, 300)).cuda())
+        offs.append(offs[-1] + N * k)
+    out = torch.empty((offs[-1], 4), dtype=torch.float32, device="cuda")
+    ops.rpn_decode_multi(regs, idxs, ancs, offs[:-1], out, (1.0, 1.0, 1.0, 1.0), float(np.log(1000. / 16)), sizes)
+    for l in range(3):
+        want = ops.rpn_decode(regs[l], idxs[l], ancs[l], (1.0, 1.0, 1.0, 1.0), float(np.log(1000. / 16)), sizes)
+        assert torch.equal(out[offs[l]:offs[l + 1]], want.view(-1, 4))
+    matched = torch.from_numpy(rng.integers(-2, 5, 100000)).cuda()
+    vis = torch.from_numpy(rng.uniform(0, 1, 100000) < 0.7).cuda()
+    lab = (matched >= 0).float()
+    lab = torch.where(matched == -2, -1.0, lab)
+    assert torch.equal(ops.rpn_labels(matched, None, True), lab)
+    assert torch.equal(ops.rpn_labels(matched, vis, True), torch.where(vis, lab, -1.0))
+    assert torch.equal(ops.rpn_labels(matched, vis, False), torch.where(vis, (matched >= 0).float(), -1.0))
