@@ -300,6 +300,54 @@ __global__ __launch_bounds__(256) void rpn_labels_kernel(const int64_t* __restri
   lab[i] = v;
 }
 
+// ISM loss: l2_loss (pet/lib/ops/l2_loss.py:4-11) of [R, 2] predictions against targets (1 - iou, iou).  The reference
+// indexes x[pos_inds] with the [P, 2] (row, column) pairs of the positive targets, i.e. every positive entry (r, c)
+// gathers rows r AND c; with E[i] = 0.5 * sum_j (x[i,j] - t[i,j])^2 that is
+//   (sum_r cnt[r] * E[r] + n_col0 * E[0] + n_col1 * E[1]) / P,   cnt[r] = #positive targets of row r.
+// Value and gradient in one launch of one workgroup (R is a few hundred).
+__global__ __launch_bounds__(256) void l2_pairs_kernel(const float2* __restrict__ x, const float* __restrict__ iou,
+                                                       const float2* __restrict__ target, int R,
+                                                       float* __restrict__ loss, float2* __restrict__ grad) {
+  __shared__ float s_red[256];
+  __shared__ float s_col[2];
+  auto tgt = [&](int r) { return target ? target[r] : make_float2(1.f - iou[r], iou[r]); };
+  float c0 = 0.f, c1 = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float2 t = tgt(r);
+    c0 += t.x > 0.f ? 1.f : 0.f;
+    c1 += t.y > 0.f ? 1.f : 0.f;
+  }
+  for (int pass = 0; pass < 2; ++pass) {
+    s_red[threadIdx.x] = pass ? c1 : c0;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) s_col[pass] = s_red[0];
+    __syncthreads();
+  }
+  const float col0 = s_col[0], col1 = s_col[1];
+  const float P = col0 + col1, inv = 1.f / fmaxf(P, 1.f);
+  float part = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float2 t = tgt(r), v = x[r];
+    float w = (t.x > 0.f ? 1.f : 0.f) + (t.y > 0.f ? 1.f : 0.f);
+    if (r == 0) w += col0;
+    if (r == 1) w += col1;
+    const float dx = v.x - t.x, dy = v.y - t.y;
+    part += w * 0.5f * (dx * dx + dy * dy);
+    grad[r] = make_float2(w * dx * inv, w * dy * inv);
+  }
+  s_red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) s_red[threadIdx.x] += s_red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = s_red[0] * inv;
+}
+
 int fill_geom(GridGeom& G, int points, int map_size, const int* sub_xy, const int64_t* strides) {
   if (points <= 0 || points > MAX_POINTS) return -1;
   int gs = 1;
@@ -519,4 +567,14 @@ CPM_EXPORT int cpm_rpn_labels(const int64_t* matched, const uint8_t* visible, in
   hipLaunchKernelGGL(rpn_labels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      matched, visible, total, discard_between, labels);
   return cpm::check_launch("rpn_labels");
+}
+
+CPM_EXPORT int cpm_l2_loss_pairs(const float* x, const float* iou, const float* target, int R, float* loss,
+                                 float* grad, void* stream) {
+  CPM_REQUIRE(R >= 2, "at least two rows (a positive target's column index is used as a row)");
+  CPM_REQUIRE(x && (iou || target) && loss && grad, "null pointer");
+  CPM_REQUIRE((((uintptr_t)x | (uintptr_t)grad | (uintptr_t)target) & 7) == 0, "rows must be 8-byte aligned");
+  hipLaunchKernelGGL(l2_pairs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float2*)x, iou,
+                     (const float2*)target, R, loss, (float2*)grad);
+  return cpm::check_launch("l2_loss_pairs");
 }

@@ -36,3 +36,36 @@ def l2_loss_nosync(x, target):
     col = m.sum(dim=0)
     total = (m.sum(dim=1) * e).sum() + col[0] * e[0] + col[1] * e[1]
     return total / p.clamp(min=1.0)
+
+
+class _L2PairsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, iou, target):
+        from . import _hip as H
+        H.require_gpu(x, iou, target)
+        xc = x.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(xc)
+        with H.guard(x.device):
+            rc = H.lib().cpm_l2_loss_pairs(H.ptr(xc), H.ptr(iou), H.ptr(target), xc.shape[0], H.ptr(loss), H.ptr(grad),
+                                           H.stream())
+        H.check(rc, "l2_loss_pairs")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        return grad * g, None, None
+
+
+def l2_loss_fused(x, target=None, iou=None):
+    """l2_loss_nosync as ONE launch for value and gradient (cpm_l2_loss_pairs): x [R, 2] fp32 against target [R, 2],
+    or against (1 - iou, iou) when `iou` [R] is given instead."""
+    if x.dim() != 2 or x.shape[1] != 2 or x.shape[0] < 2 or x.dtype != torch.float32:
+        return l2_loss_nosync(x, target if target is not None else torch.stack([1 - iou, iou], dim=1))
+    if target is not None:
+        target = target.detach().contiguous()
+    if iou is not None:
+        iou = iou.detach().contiguous()
+    return _L2PairsFn.apply(x, iou, target)

@@ -54,7 +54,7 @@ class GridCascadeRCNN(nn.Module):
             self.Head_rescore = registry.ROI_CLS_HEADS[G.ROI_CLS_HEAD](dim_in, spatial_scale)
             self.Output_rescore = registry.ROI_CLS_OUTPUTS[G.ROI_CLS_OUTPUT](self.Head_rescore.dim_out)
             self.rescore_loss_evaluator = loss_evaluator(type="cls")
-        self.last_counts = {}
+        self._last_counts, self._pending = {}, None
         # CPM_FUSED_GLUE=0 runs the per-image formulation (kept as the in-tree cross-check of the fused kernels)
         self.fused_glue = os.environ.get("CPM_FUSED_GLUE", "1") != "0"
         # proposals arrive as a packed device list and every RoI set of the step is built on the device
@@ -208,9 +208,12 @@ class GridCascadeRCNN(nn.Module):
         one launch samples the cls RoIs and lists their positives (CLSLossComputation.subsample +
         keep_only_positive_boxes), one launch per stage transition filters the decoded boxes, appends the gts and
         re-matches (GridPostProcessor + GridLossComputation.subsample), one gathers the RSM candidates
-        (get_full_sample_boxes) and one samples them.  The host reads back only the per-image counts -- four small
-        copies per step -- and slices views; no index list is built on the host."""
+        (get_full_sample_boxes) and one samples them.  The cls and RSM heads run on the whole capacity of their
+        sample (images x BATCH_SIZE_PER_IMAGE rows; the rows beyond the count carry cross_entropy's ignore_index
+        and contribute exactly nothing), so only the grid stages need their RoI counts on the host: three small
+        copies per step, the first hidden behind the cls head.  No index list is built on the host."""
         G, M = cfg.GRID_RCNN, cfg.GRID_RCNN.CASCADE_MAPPING_OPTION
+        self._resolve_pending()
         n_img, sizes = props.n_img, props.sizes
         gt_all, gt_labels, gt_off, off_h = RL.gt_pack(targets)
         n_gt = off_h[-1]
@@ -223,16 +226,16 @@ class GridCascadeRCNN(nn.Module):
                                                     seeds[0], self.max_sample_num_grid, seeds[1],
                                                     M.FG_IOU_THRESHOLD[0])
             self._count_reads[0].start(counts_all)
-            c = self._count_reads[0].wait()                           # host round trip 1 of 4
+        # ---- cls head on the sample's capacity, queued before the host waits for the counts -----------------
+        ev.set_packed_sample(None, sample.labels)
+        loss = dict(loss_classifier=ev([self.Output_cls(self.Head_cls(features, _capacity_rows(sample)))]))
+        c = self._count_reads[0].wait()                               # host round trip 1 of 3
         if c[-1]:
             raise RuntimeError("an image holds more than %d proposals; set CPM_DEVICE_LISTS=0" % RL.roi_sample_max_rows())
         sample.host_counts, pos.host_counts = c[:n_img + 1], c[n_img + 1:2 * (n_img + 1)]
-        # ---- cls head ------------------------------------------------------------------------------------
         S = sample.total
-        self.last_counts["cls"] = S
-        cls_lists = _views(sample, sizes, ("objectness", "obj"), ("labels", "labels"))
-        ev.set_packed_sample(cls_lists, sample.labels[:S])
-        loss = dict(loss_classifier=ev([self.Output_cls(self.Head_cls(features, cls_lists))]))
+        self._last_counts["cls"] = S
+        ev.set_packed_sample(_views(sample, sizes, ("objectness", "obj"), ("labels", "labels")), sample.labels)
         # ---- CMM cascade ---------------------------------------------------------------------------------
         cur, R0 = pos, pos.total
         x = None
@@ -240,7 +243,7 @@ class GridCascadeRCNN(nn.Module):
             gev = self.grid_loss_evaluators[s]
             last = s == self.stage_num - 1
             R = cur.total
-            self.last_counts["grid_%d" % s] = R
+            self._last_counts["grid_%d" % s] = R
             rois = cur.boxes[:R]
             x, _ = getattr(self, "Head_grid_%d" % s)(features, _views(cur, sizes))
             grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
@@ -250,9 +253,7 @@ class GridCascadeRCNN(nn.Module):
                                           gev.pos_radius, gev.loss_weight)
             loss["loss_grid_%d" % (s + 1)] = loss_grid * self.stage_loss_weight[s]
             if G.IOU_HELPER and last:
-                max_iou = cur.iou[:R]
-                iou_target = torch.stack([1 - max_iou, max_iou], dim=1)
-                loss["loss_iou_%d" % (s + 1)] = ops.l2_loss_nosync(iou_logits, iou_target) * G.IOU_LOSS_WEIGHT
+                loss["loss_iou_%d" % (s + 1)] = ops.l2_loss_fused(iou_logits, iou=cur.iou[:R]) * G.IOU_LOSS_WEIGHT
             if last:
                 break
             with torch.no_grad():
@@ -268,7 +269,7 @@ class GridCascadeRCNN(nn.Module):
                 cur = nxt
         if not G.RESCORE_ON:
             return x, _views(cur, sizes), loss
-        # ---- RSM -----------------------------------------------------------------------------------------
+        # ---- RSM, again on the sample's capacity: its count is read back lazily -----------------------------
         rev = self.rescore_loss_evaluator
         m, sp = rev.proposal_matcher, rev.fg_bg_sampler
         with torch.no_grad():
@@ -278,17 +279,22 @@ class GridCascadeRCNN(nn.Module):
             rs, _, counts_all = RL.roi_sample(cand, gt_all, gt_labels, gt_off, m.high_threshold, m.low_threshold,
                                               sp.batch_size_per_image, sp.positive_fraction, seeds[2])
             self._count_reads[-1].start(counts_all)
-            c = self._count_reads[-1].wait()                          # host round trip 4 of 4
-        if c[-1]:
-            raise RuntimeError("an image holds more than %d RSM candidates; set CPM_DEVICE_LISTS=0"
-                               % RL.roi_sample_max_rows())
-        rs.host_counts = c[:n_img + 1]
-        self.last_counts["rescore"] = rs.total
-        rs_lists = _views(rs, sizes, ("objectness", "obj"), ("labels", "labels"))
-        rev.set_packed_sample(rs_lists, rs.labels[:rs.total])
-        logits = self.Output_rescore(self.Head_rescore(features, rs_lists))
+        result = _LazyViews(self, rs, sizes)
+        self._pending = result
+        rev.set_packed_sample(result, rs.labels)
+        logits = self.Output_rescore(self.Head_rescore(features, _capacity_rows(rs)))
         loss["loss_rescore"] = rev([logits]) * G.RESCORE_LOSS_WEIGHT
-        return x, rs_lists, loss
+        return x, result, loss
+
+    def _resolve_pending(self):
+        """read the RSM sample's counts of the previous step (and its status) if nobody asked for them yet"""
+        if self._pending is not None:
+            self._pending.resolve()
+
+    @property
+    def last_counts(self):
+        self._resolve_pending()
+        return self._last_counts
 
     def _forward_train_rescore(self, features, cls_proposals, grid_proposals, targets):
         with torch.no_grad():
@@ -323,6 +329,44 @@ class GridCascadeRCNN(nn.Module):
 class _PackedBoxLists(list):
     """per-image BoxLists that are views of one packed device list, plus its [R, 5] RoIAlign rows"""
     rois5 = None
+
+
+def _capacity_rows(lst):
+    """all `capacity` rows of a sampled list as the RoIAlign input of a head that runs without knowing the count"""
+    out = _PackedBoxLists()
+    out.rois5 = lst.rois5
+    return out
+
+
+class _LazyViews(object):
+    """the RSM sample as per-image BoxLists, materialised (one small device->host copy, queued long before) only when
+    somebody looks at it: the training loop never does"""
+
+    def __init__(self, head, lst, sizes):
+        self._head, self._lst, self._sizes, self._lists = head, lst, sizes, None
+
+    def resolve(self):
+        if self._lists is None:
+            head, n = self._head, self._lst.n_img
+            c = head._count_reads[-1].wait()
+            if head._pending is self:
+                head._pending = None
+            if c[-1]:
+                raise RuntimeError("an image holds more than %d RSM candidates; set CPM_DEVICE_LISTS=0"
+                                   % RL.roi_sample_max_rows())
+            self._lst.host_counts = c[:n + 1]
+            head._last_counts["rescore"] = self._lst.total
+            self._lists = _views(self._lst, self._sizes, ("objectness", "obj"), ("labels", "labels"))
+        return self._lists
+
+    def __len__(self):
+        return len(self.resolve())
+
+    def __iter__(self):
+        return iter(self.resolve())
+
+    def __getitem__(self, i):
+        return self.resolve()[i]
 
 
 def _views(lst, sizes, *fields):

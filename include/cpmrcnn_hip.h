@@ -396,6 +396,14 @@ int cpm_rpn_decode_multi(const float* const* reg, const int64_t* const* topk_idx
 int cpm_rpn_labels(const int64_t* matched, const uint8_t* visible, int64_t total, int discard_between, float* labels,
                    void* stream);
 
+/* ISM loss: l2_loss (pet/lib/ops/l2_loss.py:4-11) of x [R, 2] against target [R, 2] -- or, with target NULL, against
+ * (1 - iou[r], iou[r]) (GridLossComputation.prepare_iou_target, grid_cascade_rcnn/loss.py:164-176).  The reference's
+ * x[pos_inds] gathers, for every positive target entry (r, c), rows r AND c:
+ *   loss = (sum_r cnt[r] E[r] + n_col0 E[0] + n_col1 E[1]) / P,  E[i] = 0.5 sum_j (x[i,j] - t[i,j])^2.
+ * *loss and grad [R, 2] (d loss / d x) from one launch; R >= 2. */
+int cpm_l2_loss_pairs(const float* x, const float* iou, const float* target, int R, float* loss, float* grad,
+                      void* stream);
+
 /* ---- device-resident RoI lists of the training step -----------------------------------------
  * Packed lists with a fixed capacity and a per-image count ON THE DEVICE replace the reference's per-image BoxList
  * surgery (nonzero / boolean index / randperm / cat, each a launch and a device->host round trip).  Every call is one

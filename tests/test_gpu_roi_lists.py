@@ -330,3 +330,26 @@ def test_rpn_decode_multi_and_labels_equal_single_level_ops():
     assert torch.equal(ops.rpn_labels(matched, None, True), lab)
     assert torch.equal(ops.rpn_labels(matched, vis, True), torch.where(vis, lab, -1.0))
     assert torch.equal(ops.rpn_labels(matched, vis, False), torch.where(vis, (matched >= 0).float(), -1.0))
+
+
+@pytest.mark.parametrize("R", [2, 3, 37, 700])
+def test_l2_loss_fused_equals_reference_formulation(R):
+    """cpm_l2_loss_pairs (value + gradient in one launch) against l2_loss -- the reference's nonzero() + x[pos_inds]
+    formulation (pet/lib/ops/l2_loss.py:4-11) -- and its autograd gradient."""
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(R)
+    iou = torch.rand(R, generator=g).cuda()
+    iou[::5] = 1.0                                   # 1 - iou == 0: not a positive target
+    iou[1::7] = 0.0
+    x = torch.randn(R, 2, generator=g).cuda()
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    target = torch.stack([1 - iou, iou], dim=1)
+    want = ops.l2_loss(xa, target)
+    got = ops.l2_loss_fused(xb, iou=iou)
+    got2 = ops.l2_loss_fused(x.clone(), target=target)
+    assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want)) + 1e-7
+    assert abs(float(got2) - float(want)) <= 1e-5 * abs(float(want)) + 1e-7
+    (want * 3).backward()
+    (got * 3).backward()
+    np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
