@@ -366,15 +366,16 @@ __global__ void __launch_bounds__(THREADS) roi_sample_kernel(SampleArgs a) {
     a.s_counts[a.n_img] = out_s;
     if (a.max_grid > 0) a.p_counts[a.n_img] = out_p;
   }
-  // padding rows: a head may run on the whole capacity without knowing the count -- a valid dummy RoI (image 0,
-  // empty box) and cross_entropy's ignore_index as the label keep such rows out of the loss and its gradients
+  // padding rows: a head may run on the whole capacity without knowing the count -- image -1 (RoIAlign pools zeros
+  // and scatters nothing back for it) and cross_entropy's ignore_index as the label keep such rows out of the loss
+  // and of every gradient
   for (int p = out_s + threadIdx.x; p < a.cap_sample; p += THREADS) {
     a.s_img[p] = -1;
     a.s_labels[p] = -100;
     a.s_boxes[p] = make_float4(0.f, 0.f, 0.f, 0.f);
     a.s_obj[p] = 0.f;
     float* r5 = a.s_rois5 + (size_t)p * 5;
-    r5[0] = 0.f; r5[1] = 0.f; r5[2] = 0.f; r5[3] = 0.f; r5[4] = 0.f;
+    r5[0] = -1.f; r5[1] = 0.f; r5[2] = 0.f; r5[3] = 0.f; r5[4] = 0.f;
   }
   if (a.max_grid > 0)
     for (int p = out_p + threadIdx.x; p < a.cap_grid; p += THREADS) a.p_img[p] = -1;
