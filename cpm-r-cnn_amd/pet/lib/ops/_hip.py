@@ -83,9 +83,40 @@ _raw_stream = torch._C._cuda_getCurrentRawStream
 _cur_device = torch._C._cuda_getDevice
 
 
+_override = None        # raw hipStream_t the ops launch on instead of torch's current stream (see use_stream)
+
+
+def stream_raw():
+    return _override if _override is not None else _raw_stream(_cur_device())
+
+
 def stream():
-    """The current stream of the current device as a raw hipStream_t."""
-    return c_void_p(_raw_stream(_cur_device()))
+    """The stream the ops launch on, as a raw hipStream_t: torch's current stream of the current device, or the one
+    set by use_stream()."""
+    return c_void_p(stream_raw())
+
+
+class use_stream(object):
+    """`with use_stream(raw):` -- every op launched inside goes to that raw stream (cheaper than torch.cuda.stream,
+    and invisible to torch: tensors allocated inside still belong to torch's current stream)."""
+    __slots__ = ("raw", "prev")
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    def __enter__(self):
+        global _override
+        self.prev, _override = _override, self.raw
+
+    def __exit__(self, *exc):
+        global _override
+        _override = self.prev
+        return False
+
+
+def fork(raw_from, raw_to):
+    """stream `raw_to` waits for everything queued on `raw_from` so far (cpm_stream_fork)"""
+    check(lib().cpm_stream_fork(c_void_p(raw_from), c_void_p(raw_to)), "stream_fork")
 
 
 class _NoGuard(object):
@@ -134,7 +165,7 @@ _ws = {}
 def workspace(nbytes, device):
     """A grow-only scratch buffer per (device, stream); callers never hold it across ops."""
     idx = device.index if device.index is not None else _cur_device()
-    key = (idx, _raw_stream(idx))
+    key = (idx, _override if _override is not None else _raw_stream(idx))
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

@@ -271,6 +271,54 @@ def _wmem(w):
     return w if w.is_contiguous(memory_format=CL) else w.contiguous(memory_format=CL)
 
 
+# ---- weight gradients beside the data-gradient chain --------------------------------------------------------------
+# The backward pass is one dependent chain of data gradients; a layer's weight gradient hangs off it as a leaf that
+# nothing waits for until the optimizer step.  Most layers of this model fill less than the 256 CUs on their own
+# (M = 2..8 k pixels in layer3 / layer4 / the RoI heads), so the weight-gradient kernels go to a second stream and
+# run in the gaps: forked after the layer's data gradient is queued, joined once at the end of the backward pass.
+_SIDE_WGRAD = os.environ.get("CPM_WGRAD_STREAM", "1") != "0"
+_side = {}              # device index -> (torch stream, raw handle)
+_side_armed = set()     # device indices with side work that the running backward pass still has to join
+
+
+def wgrad_stream(device):
+    """the second stream weight gradients run on (None when disabled): whoever consumes gradients on a stream other
+    than the compute stream (pet.utils.parallel) must wait for it too"""
+    if not _SIDE_WGRAD:
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side.get(idx)
+    if st is None:
+        t = torch.cuda.Stream(device=device)
+        st = _side[idx] = (t, t.cuda_stream)
+    return st[0]
+
+
+def _join_side():
+    """end of the backward pass: the compute stream waits for the weight gradients"""
+    for idx in list(_side_armed):
+        H.fork(_side[idx][1], H._raw_stream(idx))
+    _side_armed.clear()
+
+
+def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):
+    dev = x.device
+    idx = dev.index
+    st = _side.get(idx)
+    if st is None:
+        wgrad_stream(dev)
+        st = _side[idx]
+    H.fork(H._raw_stream(idx), st[1])               # everything queued so far: dy, the gate pass, this layer's dgrad
+    with H.use_stream(st[1]):
+        conv2d_backward_weight(x, dy, w, stride, pad, dil, groups, out=out, dbias=dbias)
+    # the caching allocator must not hand these blocks to the compute stream while the side stream still reads them
+    x.record_stream(st[0])
+    dy.record_stream(st[0])
+    if idx not in _side_armed:
+        _side_armed.add(idx)
+        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+
+
 class _ConvFn(Function):
     """y = relu?( conv(x, w) * scale + shift + residual )   (scale/shift/residual optional).
     scale is a frozen per-channel factor (AffineChannel2d) and never receives a gradient; shift receives one
@@ -349,6 +397,30 @@ class _ConvFn(Function):
                     gres = None
                 else:
                     h["acc"] = gres
+        # the weight gradient first: forked onto the second stream it starts together with the data gradient below
+        dw = None
+        if need_w:
+            wp = ctx.wparam
+            dbias = None
+            if fuse_bias:
+                bp = ctx.bparam
+                dbias = bp._cpm_grad_sink if bp is not None else torch.zeros(w.shape[0], dtype=torch.float32,
+                                                                             device=dy.device)
+                if bp is None:
+                    dshift = dbias
+            if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
+                if _SIDE_WGRAD and x.numel() and dpre.numel() and not (fuse_bias and ctx.bparam is None):
+                    _wgrad_on_side(x, dpre, w, stride, pad, dil, groups, wp._cpm_grad_sink, dbias)
+                else:
+                    conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias)
+                _sink_done(getattr(wp, "_cpm_owner", wp))
+            else:
+                dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, dbias=dbias)
+                if wp is not None:                      # this use reaches the parameter through autograd's accumulation
+                    own = getattr(wp, "_cpm_owner", wp)
+                    own._cpm_uses -= 1
+            if fuse_bias and ctx.bparam is not None:
+                _sink_done(ctx.bparam)                  # accumulated in place
         dx = None
         if need_x:
             h = ctx.x_holder
@@ -365,26 +437,6 @@ class _ConvFn(Function):
                     dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, wparam=ctx.wsrc)
                 if h is not None:
                     h["acc"] = dx
-        dw = None
-        if need_w:
-            wp = ctx.wparam
-            dbias = None
-            if fuse_bias:
-                bp = ctx.bparam
-                dbias = bp._cpm_grad_sink if bp is not None else torch.zeros(w.shape[0], dtype=torch.float32,
-                                                                             device=dy.device)
-                if bp is None:
-                    dshift = dbias
-            if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
-                conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias)
-                _sink_done(getattr(wp, "_cpm_owner", wp))
-            else:
-                dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, dbias=dbias)
-                if wp is not None:                      # this use reaches the parameter through autograd's accumulation
-                    own = getattr(wp, "_cpm_owner", wp)
-                    own._cpm_uses -= 1
-            if fuse_bias and ctx.bparam is not None:
-                _sink_done(ctx.bparam)                  # accumulated in place
         return dx, dw, None, dshift, gres, None, None, None, None, None, None, None
 
 

@@ -12,6 +12,8 @@ Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` in the 
 import torch
 import torch.distributed as dist
 
+from pet.lib.ops.conv import wgrad_stream
+
 
 def world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
@@ -87,6 +89,9 @@ class FlatGradReducer(object):
     def _launch(self, ci):
         b, e, _ = self.chunks[ci]
         self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+        side = wgrad_stream(self.flat.device)       # weight gradients are queued on a second stream (pet.lib.ops.conv)
+        if side is not None:
+            self.stream.wait_stream(side)
         with torch.cuda.stream(self.stream):
             dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
 

@@ -452,6 +452,11 @@ int cpm_rescore_gather(const float* s_boxes, const float* s_obj, const int64_t* 
                        int n_first, int n_images, int capacity, float* o_boxes, float* o_obj, int32_t* o_counts,
                        void* stream);
 
+/* Stream ordering for work the host side forks onto a second stream (the weight-gradient kernels of the backward
+ * pass run beside the data-gradient chain): stream `to` waits for everything queued on `from` so far.  Not thread safe
+ * (one backward pass per process). */
+int cpm_stream_fork(void* from, void* to);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------
  * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and
  * remembers the launch's ALGORITHMIC flops (2*N*P*Q*K*R*S*C/groups); cpm_prof_enable(0) stops and
