@@ -152,12 +152,19 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     """HIP-event time of every conv launch (events recorded on the launch stream inside the library) over
     `steps` extra iterations; algorithmic flops = 2*N*P*Q*K*R*S*C/g per launch."""
     from pet.lib.ops import _hip as H
+    from pet.lib.ops import conv as conv_ops
     L = H.lib()
     torch.cuda.synchronize()
+    # kernel durations are measured one kernel at a time: in the timed steps the weight-gradient kernels share the
+    # device with the data-gradient chain (second stream), which stretches every overlapped kernel's own duration
+    side, conv_ops._SIDE_WGRAD = conv_ops._SIDE_WGRAD, False
     L.cpm_prof_enable(1)
-    for _ in range(steps):
-        trainer.step(images, targets)
-    torch.cuda.synchronize()
+    try:
+        for _ in range(steps):
+            trainer.step(images, targets)
+        torch.cuda.synchronize()
+    finally:
+        conv_ops._SIDE_WGRAD = side
     kinds = {}
     for kind, name in ((0, "igemm_fwd"), (1, "igemm_dgrad"), (2, "wgrad")):
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_int64()
