@@ -176,16 +176,22 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     # algorithmic HBM bytes of the average igemm call: input + output + weight, each once (fp32)
     import csv
     import tempfile
-    alg_bytes = None
+    alg_bytes = per_call_frac = None
     with tempfile.NamedTemporaryFile("r", suffix=".csv") as tf:
         if L.cpm_prof_dump(tf.name.encode()) == 0:
-            nb, nl = 0.0, 0
+            nb, nl, bound_ms, meas_ms = 0.0, 0, 0.0, 0.0
             for r in csv.DictReader(open(tf.name)):
                 if r["kind"] in ("0", "1"):
                     N, Hh, W, C, K, R, g, P, Q = (int(r[k]) for k in ("N", "H", "W", "C", "K", "R", "groups", "P", "Q"))
-                    nb += 4.0 * (N * Hh * W * C + N * P * Q * K + K * R * R * (C // g))
+                    by = 4.0 * (N * Hh * W * C + N * P * Q * K + K * R * R * (C // g))
+                    nb += by
                     nl += 1
+                    # the launch's own roofline: MFMA peak of the arithmetic or 8 TB/s on its algorithmic bytes
+                    peak = MFMA_BF16_PEAK_TFLOPS / 3 if math == "bf16x3" else MFMA_F32_PEAK_TFLOPS
+                    bound_ms += max(float(r["gflop"]) / peak, by / 8e9)
+                    meas_ms += float(r["ms"])
             alg_bytes = int(nb / nl) if nl else None
+            per_call_frac = round(bound_ms / meas_ms, 4) if meas_ms else None
     L.cpm_prof_enable(0)
     # dominant kernel = igemm_kernel<...> (forward-gather + data-gradient-gather instantiations of one template)
     ms = kinds["igemm_fwd"]["ms"] + kinds["igemm_dgrad"]["ms"]
@@ -214,6 +220,9 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
             "achieved": round(achieved, 2), "peak": round(MFMA_BF16_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
             "frac": round(3 * achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
             "algorithmic_bytes_per_call": alg_bytes,
+            "frac_vs_per_call_bound": per_call_frac,
+            "per_call_bound_note": "sum over the family's launches of max(flops / MFMA peak, algorithmic bytes / 8 TB/s) "
+                                   "divided by their measured time: many of the step's 1x1 layers are HBM-bound by shape",
             "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3 MFMA terms per fp32 product; "
                          "achieved counts algorithmic flops (2*N*P*Q*K*R*S*C/g), not the 3x issued",
             "frac_vs_raw_bf16_peak": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
