@@ -207,34 +207,44 @@ __global__ __launch_bounds__(64) void sweep_segments(const uint64_t* __restrict_
   if (lane == 0) keep_count[p] = nkeep;
 }
 
-// ---- 3b. the same sweep for segments of at most 2048 boxes (every RPN / RoI-head call) ------------------------------
-// The general kernel above pays one dependent global round trip per 64-row block (the kept rows' remaining words) plus
-// 64 lanes OR-ing into the same LDS word.  Here a lane keeps its WHOLE mask row (<= 32 words) in registers, the rows of
-// block b+1 are fetched while block b is resolved (two register sets, the block loop unrolled by two), and the
-// "removed" words are produced by wave OR-reductions (shuffles) of the kept lanes' registers: no LDS atomics, and
-// the only wait per block is on loads issued a block earlier.
+// ---- 3b. segments of at most 2048 boxes (every RPN / RoI-head call): transposed tiles, no cross-lane reductions ------
+// The sweep above asks "which later boxes does kept row r remove" and has to OR 64-bit words ACROSS the lanes that hold
+// the kept rows: ~500 wave OR-reductions (DPP chains, ~0.2 us each) per 2000-box segment, 137-150 us on one
+// wavefront.  The transposed question -- "is box c removed by an earlier kept box" -- needs no reduction at all: lane
+// c holds, per earlier 64-box block rb, the word T[c][rb] of the boxes of rb that would suppress c (IoU is symmetric,
+// so mask_tiles_t computes the same predicate calls as mask_tiles, stored the other way round), and
+//     removed(c) = OR over rb of (T[c][rb] & kept[rb]) != 0
+// is per-lane ANDs against the wave-uniform kept words.  Inside a block the rounds of the greedy resolution turn into
+// two ballots each.  The rows of block b+1 are fetched while block b is resolved.
 constexpr int SMALL_NB = 32;
 
-// OR of a 32-bit value over the wavefront, result wave-uniform: four DPP row shifts leave each 16-lane row's OR in its
-// last lane, four readlanes fetch those (ds_bpermute-based shuffles cost ~10x as much and there are 31 of these per
-// 64-row block)
-__device__ __forceinline__ uint32_t wave_or32(uint32_t v) {
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
-  v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 15) | (uint32_t)__builtin_amdgcn_readlane((int)v, 31) |
-         (uint32_t)__builtin_amdgcn_readlane((int)v, 47) | (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-__device__ __forceinline__ uint64_t wave_or64(uint64_t v) {
-  return ((uint64_t)wave_or32((uint32_t)(v >> 32)) << 32) | wave_or32((uint32_t)v);
-}
-
-__device__ __forceinline__ void load_row(const uint64_t* __restrict__ m, int nblk, int row, int n,
-                                         uint64_t (&w)[SMALL_NB]) {
-#pragma unroll
-  for (int j = 0; j < SMALL_NB; ++j) w[j] = (row < n && j < nblk) ? m[(int64_t)row * nblk + j] : 0ull;
+__global__ __launch_bounds__(64) void mask_tiles_t(const float4* __restrict__ sboxes,
+                                                   const int32_t* __restrict__ slabels, SegTable T, float thr,
+                                                   uint64_t* __restrict__ mask) {
+  const int p = blockIdx.z;
+  const int base = T.off[p], n = T.off[p + 1] - base;
+  const int nblk = (n + 63) >> 6;
+  const int rb = blockIdx.y, cb = blockIdx.x;                  // earlier block rb, this box's block cb
+  if (rb >= nblk || cb >= nblk || rb > cb) return;
+  __shared__ float4 rbox[64];
+  __shared__ int32_t rlab[64];
+  const int lane = threadIdx.x;
+  const int r_size = min(n - rb * 64, 64), c_size = min(n - cb * 64, 64);
+  if (lane < r_size) {
+    rbox[lane] = sboxes[base + rb * 64 + lane];
+    rlab[lane] = slabels[base + rb * 64 + lane];
+  }
+  __syncthreads();
+  if (lane < c_size) {
+    const int c = cb * 64 + lane;
+    const float4 b = sboxes[base + c];
+    const int32_t bl = slabels[base + c];
+    uint64_t t = 0;
+    const int limit = (rb == cb) ? lane : r_size;              // only EARLIER boxes can suppress
+    for (int i = 0; i < limit; ++i)
+      if (bl == rlab[i] && iou_gt(rbox[i], b, thr)) t |= 1ull << i;     // the call mask_tiles makes for (row i, col c)
+    mask[T.mask_off[p] + (int64_t)rb * (nblk * 64) + c] = t;   // [rb][box]: a block's 64 words are contiguous
+  }
 }
 
 __global__ __launch_bounds__(64) void sweep_segments_small(const uint64_t* __restrict__ mask,
@@ -246,62 +256,67 @@ __global__ __launch_bounds__(64) void sweep_segments_small(const uint64_t* __res
   const int nblk = (n + 63) >> 6;
   const int lane = threadIdx.x;
   const uint64_t* m = mask + T.mask_off[p];
-  __shared__ uint64_t remv[SMALL_NB];                   // words of the boxes removed so far (one wave: no barriers)
-  if (lane < SMALL_NB) remv[lane] = 0;
+  uint64_t kw[SMALL_NB];                                       // kept words of the finished blocks (wave-uniform)
+#pragma unroll
+  for (int j = 0; j < SMALL_NB; ++j) kw[j] = 0ull;
+  // words rb <= blk of this lane's box in block blk (the others are never written by mask_tiles_t)
+  // (the box's original index travels with its row: fetched a block ahead, not between the resolution and the store)
+  auto load_row = [&](int blk, uint64_t (&w)[SMALL_NB], int32_t& ord) {
+    const int row = blk * 64 + lane;
+#pragma unroll
+    for (int j = 0; j < SMALL_NB; ++j) {
+      // unconditional loads (the mask is padded to whole blocks; words never written are discarded below): a per-lane
+      // predicate here puts every load under its own exec-masked branch and the loads stop overlapping
+      uint64_t v = 0ull;
+      if (j <= blk) v = m[(int64_t)j * (nblk * 64) + row];       // wave-uniform condition (blk < nblk)
+      w[j] = (row < n && j <= blk) ? v : 0ull;
+    }
+    ord = order[base + (row < n ? row : n - 1)];
+  };
   uint64_t wa[SMALL_NB], wb[SMALL_NB];
-  load_row(m, nblk, lane, n, wa);
+  int32_t oa = 0, ob = 0;
+  load_row(0, wa, oa);
   int nkeep = 0;
   bool done = false;
-  // one block of 64 rows; `w` holds this block's rows, the caller has already issued the next block's loads
-  auto process = [&](int blk, uint64_t (&w)[SMALL_NB]) {
+  auto process = [&](int blk, const uint64_t (&w)[SMALL_NB], int32_t ord) {
     const int row_l = blk * 64 + lane;
-    const int rows_here = min(n - blk * 64, 64);
-    uint64_t diag = 0;
+    bool dead = false;
+    uint64_t dt = 0;                                           // same-block boxes (earlier lanes) that suppress this one
 #pragma unroll
-    for (int j = 0; j < SMALL_NB; ++j)
-      if (j == blk) diag = w[j];
-    const uint64_t cur = remv[blk];
+    for (int j = 0; j < SMALL_NB; ++j) {
+      if (j < blk) dead |= (w[j] & kw[j]) != 0ull;
+      if (j == blk) dt = w[j];
+    }
+    uint64_t alive = __ballot(row_l < n && !dead);
     uint64_t kept = 0;
-    uint64_t alive = (rows_here == 64 ? ~0ull : ((1ull << rows_here) - 1ull)) & ~cur;
-    // Greedy resolution of the block in ROUNDS instead of one dependent step per kept box: a row that no still-alive
-    // earlier row suppresses is kept whatever happens to the others (its earlier suppressors are all dead, and a kept
-    // one would already have removed it); the rows those suppress are dead; drop both sets and repeat.  The lowest
-    // alive row always qualifies, so the loop ends; with few overlaps it takes 2-3 rounds of two wave OR-reductions
-    // where the sequential form took ~58 find-first-set / readlane steps.  diag holds bits of LATER rows only.
+    // rounds: an alive box that no alive earlier box suppresses is kept; what the kept ones suppress is dead; repeat
+    // (the lowest alive box always qualifies).  Two ballots per round.
     while (alive) {
-      const bool live = (alive >> lane) & 1ull;
-      const uint64_t hit = wave_or64(live ? diag : 0ull);          // rows some alive row suppresses
-      const uint64_t k = alive & ~hit;                              // ... the others are kept
-      const bool kl = (k >> lane) & 1ull;
-      const uint64_t dead = wave_or64(kl ? diag : 0ull);           // rows a kept row suppresses
+      const uint64_t k = alive & ~__ballot((dt & alive) != 0ull);
+      const uint64_t dead_now = __ballot((dt & k) != 0ull);
       kept |= k;
-      alive &= ~(k | dead);
+      alive &= ~(k | dead_now);
     }
     if (topk > 0 && nkeep + __popcll(kept) >= topk) {               // keep the first (topk - nkeep) of them
       int extra = nkeep + __popcll(kept) - topk;
       while (extra-- > 0) kept &= ~(1ull << (63 - __builtin_clzll(kept)));
       done = true;
     }
-    const bool mine = (kept >> lane) & 1ull;
-    if (mine) {
+    if ((kept >> lane) & 1ull) {
       const int pos = nkeep + __popcll(kept & ((1ull << lane) - 1ull));
-      keep[base + pos] = (int64_t)order[base + row_l];
+      keep[base + pos] = (int64_t)ord;
     }
     nkeep += __popcll(kept);
-    if (done) return;
 #pragma unroll
     for (int j = 0; j < SMALL_NB; ++j)
-      if (j > blk && j < nblk) {
-        const uint64_t r = wave_or64(mine ? w[j] : 0ull);
-        if (lane == 0) remv[j] |= r;
-      }
+      if (j == blk) kw[j] = kept;
   };
   for (int blk = 0; blk < nblk && !done; blk += 2) {
-    if (blk + 1 < nblk) load_row(m, nblk, (blk + 1) * 64 + lane, n, wb);
-    process(blk, wa);
+    if (blk + 1 < nblk) load_row(blk + 1, wb, ob);
+    process(blk, wa, oa);
     if (done || blk + 1 >= nblk) break;
-    if (blk + 2 < nblk) load_row(m, nblk, (blk + 2) * 64 + lane, n, wa);
-    process(blk + 1, wb);
+    if (blk + 2 < nblk) load_row(blk + 2, wa, oa);
+    process(blk + 1, wb, ob);
   }
   if (lane == 0) keep_count[p] = nkeep;
 }
@@ -334,7 +349,7 @@ WsLayout ws_layout(const int32_t* off, int P) {
   size_t mask_words = 0, bigmax = 0;
   for (int p = 0; p < P; ++p) {
     const size_t n = (size_t)(off[p + 1] - off[p]);
-    mask_words += n * ((n + 63) / 64);
+    mask_words += ((n + 63) / 64) * 64 * ((n + 63) / 64);       // rows padded to whole 64-box blocks
     if (n > (size_t)LDS_SORT_MAX) {
       size_t np2 = 1;
       while (np2 < n) np2 <<= 1;
@@ -398,7 +413,7 @@ CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const in
     for (int i = 0; i < np; ++i) {
       const int64_t n = T.off[i + 1] - T.off[i];
       T.mask_off[i] = mask_base;
-      mask_base += n * ((n + 63) / 64);
+      mask_base += ((n + 63) / 64) * 64 * ((n + 63) / 64);
       if (n > maxn) maxn = (int)n;
     }
     T.mask_off[np] = mask_base;
@@ -431,14 +446,15 @@ CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const in
     }
     hipLaunchKernelGGL(gather_sorted, dim3(cpm::cdiv(maxn, 256) > 64 ? 64 : cpm::cdiv(maxn, 256), np), dim3(256), 0,
                        s, boxes, labels, T, order, sboxes, slabels);
-    // 2. tiles
+    // 2. tiles + 3. sweep
     const int nblk = (maxn + 63) / 64;
-    hipLaunchKernelGGL(mask_tiles, dim3(nblk, nblk, np), dim3(64), 0, s, sboxes, slabels, T, iou_threshold, mask);
-    // 3. sweep
-    if (maxn <= SMALL_NB * 64)
+    if (maxn <= SMALL_NB * 64) {
+      hipLaunchKernelGGL(mask_tiles_t, dim3(nblk, nblk, np), dim3(64), 0, s, sboxes, slabels, T, iou_threshold, mask);
       hipLaunchKernelGGL(sweep_segments_small, dim3(np), dim3(64), 0, s, mask, order, T, topk, keep, keep_count + p0);
-    else
+    } else {
+      hipLaunchKernelGGL(mask_tiles, dim3(nblk, nblk, np), dim3(64), 0, s, sboxes, slabels, T, iou_threshold, mask);
       hipLaunchKernelGGL(sweep_segments, dim3(np), dim3(64), 0, s, mask, order, T, topk, keep, keep_count + p0);
+    }
   }
   return cpm::check_launch("nms_batched");
 }

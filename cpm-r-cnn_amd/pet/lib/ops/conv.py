@@ -278,7 +278,7 @@ def _wmem(w):
 # run in the gaps: forked after the layer's data gradient is queued, joined once at the end of the backward pass.
 _SIDE_WGRAD = os.environ.get("CPM_WGRAD_STREAM", "1") != "0"
 _side = {}              # device index -> (torch stream, raw handle)
-_side_armed = set()     # device indices with side work that the running backward pass still has to join
+_side_armed = {}        # device index -> raw compute stream that has to wait for the side work of the running backward
 
 
 def wgrad_stream(device):
@@ -296,8 +296,8 @@ def wgrad_stream(device):
 
 def _join_side():
     """end of the backward pass: the compute stream waits for the weight gradients"""
-    for idx in list(_side_armed):
-        H.fork(_side[idx][1], H._raw_stream(idx))
+    for idx, main_raw in list(_side_armed.items()):
+        H.fork(_side[idx][1], main_raw)
     _side_armed.clear()
 
 
@@ -308,14 +308,15 @@ def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):
     if st is None:
         wgrad_stream(dev)
         st = _side[idx]
-    H.fork(H._raw_stream(idx), st[1])               # everything queued so far: dy, the gate pass, this layer's dgrad
+    main_raw = H._raw_stream(idx)                   # the stream this op's forward ran on (autograd made it current)
+    H.fork(main_raw, st[1])                         # everything queued so far: dy, the gate pass
     with H.use_stream(st[1]):
         conv2d_backward_weight(x, dy, w, stride, pad, dil, groups, out=out, dbias=dbias)
     # the caching allocator must not hand these blocks to the compute stream while the side stream still reads them
     x.record_stream(st[0])
     dy.record_stream(st[0])
     if idx not in _side_armed:
-        _side_armed.add(idx)
+        _side_armed[idx] = main_raw
         torch.autograd.Variable._execution_engine.queue_callback(_join_side)
 
 

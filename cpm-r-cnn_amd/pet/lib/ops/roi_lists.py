@@ -77,8 +77,9 @@ def gt_pack(targets):
     """(gt boxes [G,4], gt labels int64 [G], gt_off int32 [images+1] device, host offsets) of a batch, built once per
     step and remembered on the first target."""
     first = targets[0]
+    key = tuple((id(t), t.bbox.data_ptr(), t.bbox._version, len(t)) for t in targets)
     pack = getattr(first, "_cpm_gt_pack", None)
-    if pack is not None and pack[4] == tuple(id(t) for t in targets):
+    if pack is not None and pack[4] == key:
         return pack[:4]
     dev = first.bbox.device
     off_h = [0]
@@ -88,7 +89,7 @@ def gt_pack(targets):
     labels = torch.cat([t.get_field("labels") for t in targets], dim=0).to(torch.int64) \
         if first.has_field("labels") else None
     gt_off = torch.tensor(off_h, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
-    first._cpm_gt_pack = (gt_all, labels, gt_off, off_h, tuple(id(t) for t in targets))
+    first._cpm_gt_pack = (gt_all, labels, gt_off, off_h, key)
     return gt_all, labels, gt_off, off_h
 
 
