@@ -9,8 +9,9 @@
 One "step" = the reference's training iteration (tools/rcnn/train_net.py:62-78): scheduler.step, zero_grad,
 forward (backbone, FPN, RPN + proposal NMS, cls head, 3 CPM grid stages + ISM, RSM), loss sum, backward,
 gradient all-reduce (N > 1), SGD step.  Inputs are resident in HBM before the timed region.  Prints ONE JSON line
-with the throughput, the roofline of the dominant kernel (fp32-MFMA implicit-GEMM conv, HIP-event timed) and, on
-one GPU, the CPU baseline (oracle/cpu_model.py: torch-CPU convs + C-oracle RoIAlign on the host cores).
+with the throughput, the roofline of the dominant kernel (implicit-GEMM conv on MFMA, HIP-event timed, one kernel at
+a time), the same step in the other conv arithmetic and with every grid stage at its RoI cap, and, on one GPU, the CPU
+baseline (oracle/cpu_pipeline.py: the whole training step with torch-CPU convs + the C oracle on the host cores).
 """
 import argparse
 import ctypes

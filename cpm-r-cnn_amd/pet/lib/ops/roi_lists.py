@@ -5,7 +5,7 @@ A list is a set of capacity-sized tensors whose first `total` rows are live, ima
 counts held on the DEVICE ([images] counts followed by the total).  The reference's BoxList surgery between the
 proposal NMS and the heads (pet/rcnn/modeling/rpn/inference.py:101-196, grid_cascade_rcnn/loss.py:29-97,
 pet/rcnn/utils/misc.py:54-94, grid_cascade_rcnn.py:231-245) becomes one launch per list; the host only reads the
-counts back (`Counts.read`) when it must size the next head launch."""
+counts back (`Counts.start` / `Counts.wait`) when it must size the next head launch."""
 import ctypes
 
 import torch
@@ -27,7 +27,7 @@ class RoIList(object):
     @property
     def total(self):
         if self.host_counts is None:
-            raise RuntimeError("RoIList counts have not been read back (Counts.read)")
+            raise RuntimeError("RoIList counts have not been read back (Counts.start / Counts.wait)")
         return self.host_counts[-1]
 
     def to_boxlists(self):
