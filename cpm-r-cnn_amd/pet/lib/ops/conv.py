@@ -315,9 +315,10 @@ def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):
     # the caching allocator must not hand these blocks to the compute stream while the side stream still reads them
     x.record_stream(st[0])
     dy.record_stream(st[0])
-    if idx not in _side_armed:
-        _side_armed[idx] = main_raw
-        torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+    # one join per fork is queued (the first one to run does the work, the rest find nothing armed): a backward pass
+    # that died half-way must not leave a stale "already armed" mark behind that would skip the join of the next one
+    _side_armed[idx] = main_raw
+    torch.autograd.Variable._execution_engine.queue_callback(_join_side)
 
 
 class _ConvFn(Function):

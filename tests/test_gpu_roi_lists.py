@@ -348,8 +348,8 @@ def test_l2_loss_fused_equals_reference_formulation(R):
     want = ops.l2_loss(xa, target)
     got = ops.l2_loss_fused(xb, iou=iou)
     got2 = ops.l2_loss_fused(x.clone(), target=target)
-    assert abs(float(got) - float(want)) <= 1e-5 * abs(float(want)) + 1e-7
-    assert abs(float(got2) - float(want)) <= 1e-5 * abs(float(want)) + 1e-7
+    assert abs(float(got.detach()) - float(want.detach())) <= 1e-5 * abs(float(want.detach())) + 1e-7
+    assert abs(float(got2) - float(want.detach())) <= 1e-5 * abs(float(want.detach())) + 1e-7
     (want * 3).backward()
     (got * 3).backward()
     np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
