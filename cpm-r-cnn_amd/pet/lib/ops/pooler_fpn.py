@@ -97,11 +97,24 @@ class _RoIAlignFPN(Function):
         return (None, None, None, None, None, None, None) + tuple(t if f else None for t, f in zip(grads, fresh))
 
 
+_LEVEL_RANGE = {}
+
+
+def _level_range(s_first, s_last):
+    """-log2 of the first / last scale in fp32 (poolers.py:84-88), computed once per pair of scales: the two tensor
+    ops cost ~30 us of host time per call, right behind each of the step's host round trips"""
+    key = (s_first, s_last)
+    r = _LEVEL_RANGE.get(key)
+    if r is None:
+        r = _LEVEL_RANGE[key] = (-float(torch.log2(torch.tensor(s_first, dtype=torch.float32))),
+                                 -float(torch.log2(torch.tensor(s_last, dtype=torch.float32))))
+    return r
+
+
 def roi_align_fpn(feats, rois, output_size, scales, sampling_ratio, canonical_scale=224, canonical_level=4,
                   eps=1e-6, return_levels=False):
     """feats: list of [B,C,H_l,W_l]; rois [K,5].  Level range follows poolers.py:84-88 (-log2 of the scales)."""
-    lvl_min = -float(torch.log2(torch.tensor(float(scales[0]), dtype=torch.float32)))
-    lvl_max = -float(torch.log2(torch.tensor(float(scales[len(feats) - 1]), dtype=torch.float32)))
+    lvl_min, lvl_max = _level_range(float(scales[0]), float(scales[len(feats) - 1]))
     out, levels = _RoIAlignFPN.apply(rois, tuple(output_size), tuple(scales), sampling_ratio, lvl_min, lvl_max,
                                      (float(canonical_scale), float(canonical_level), float(eps)), *feats)
     return (out, levels) if return_levels else out
