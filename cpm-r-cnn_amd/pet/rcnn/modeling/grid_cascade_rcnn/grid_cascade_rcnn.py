@@ -235,7 +235,7 @@ class GridCascadeRCNN(nn.Module):
         sample.host_counts, pos.host_counts = c[:n_img + 1], c[n_img + 1:2 * (n_img + 1)]
         S = sample.total
         self._last_counts["cls"] = S
-        ev.set_packed_sample(_views(sample, sizes, ("objectness", "obj"), ("labels", "labels")), sample.labels)
+        ev.set_packed_sample(_RowsNow(sample, sizes, (("objectness", "obj"), ("labels", "labels"))), sample.labels)
         # ---- CMM cascade ---------------------------------------------------------------------------------
         cur, R0 = pos, pos.total
         x = None
@@ -245,7 +245,7 @@ class GridCascadeRCNN(nn.Module):
             R = cur.total
             self._last_counts["grid_%d" % s] = R
             rois = cur.boxes[:R]
-            x, _ = getattr(self, "Head_grid_%d" % s)(features, _views(cur, sizes))
+            x, _ = getattr(self, "Head_grid_%d" % s)(features, _RowsNow(cur, sizes))
             grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
             logits = grid_logits["unfused"]
             ratio = M.STAGE_MAPPING_RATIO[s]
@@ -329,6 +329,29 @@ class GridCascadeRCNN(nn.Module):
 class _PackedBoxLists(list):
     """per-image BoxLists that are views of one packed device list, plus its [R, 5] RoIAlign rows"""
     rois5 = None
+
+
+class _RowsNow(object):
+    """the live rows of a packed list for a head: the [R, 5] RoIAlign rows at once, the per-image BoxList views only
+    if somebody iterates (hooks, tests) -- building them costs host time right behind a host round trip"""
+
+    def __init__(self, lst, sizes, fields=()):
+        self._lst, self._sizes, self._fields, self._lists = lst, sizes, fields, None
+        self.rois5 = lst.rois5[:lst.total] if lst.rois5 is not None else None
+
+    def _get(self):
+        if self._lists is None:
+            self._lists = _views(self._lst, self._sizes, *self._fields)
+        return self._lists
+
+    def __len__(self):
+        return self._lst.n_img
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, i):
+        return self._get()[i]
 
 
 def _capacity_rows(lst):
