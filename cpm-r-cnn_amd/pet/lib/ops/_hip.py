@@ -23,6 +23,13 @@ class ConvDesc(ctypes.Structure):
                                      "Q")]
 
 
+class ConvGNLayer(ctypes.Structure):
+    """cpm_conv_gn_layer (include/cpmrcnn_hip.h)"""
+    _fields_ = [("conv", ConvDesc)] + \
+               [(n, c_void_p) for n in ("w", "wt", "bias", "gamma", "beta", "dw", "dbias", "dgamma", "dbeta")] + \
+               [("gn_groups", c_int), ("eps", c_float)]
+
+
 def lib():
     """Load (once) and return the C-ABI library; raises if it was not built."""
     global _lib

@@ -608,6 +608,165 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
     return _GroupNormFn.apply(x, gamma, beta, groups, eps, relu)
 
 
+# ---- a stack of [conv + bias -> GroupNorm -> ReLU] layers as ONE autograd node (cpm_conv_gn_stack_*) -------------
+_STACK = os.environ.get("CPM_CONV_GN_STACK", "1") != "0"
+
+
+class _StackPlan(object):
+    """What does not change from call to call about a [conv -> GroupNorm -> ReLU] stack on a given per-sample input
+    shape: the native layer table (cpm_conv_gn_layer[]: per-sample geometry, parameter and gradient-sink pointers).
+    Built once; the number of samples (RoIs) varies from step to step and only sizes the two buffers of a call
+    (cpm_conv_gn_stack_sizes, remembered per N).  The stages this exists for run ~0.3 ms of kernels: dozens of small
+    allocations or ~150 ctypes field stores in front of the first launch would cost what the native loop saves."""
+
+    def __init__(self, chw, cfgs, params):
+        self.cfgs, self.params, self.n = cfgs, params, len(cfgs)
+        self.table = (H.ConvGNLayer * self.n)()
+        c, h, wd = chw
+        for i, (stride, pad, gn_groups, eps) in enumerate(cfgs):
+            w, bias, gamma, beta = params[4 * i:4 * i + 4]
+            k, _, r, s = w.shape
+            L = self.table[i]
+            L.conv = make_desc(1, c, h, wd, k, r, s, stride, pad, 1, 1)
+            L.w, L.bias, L.gamma, L.beta = w.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+            L.dw, L.dbias = w._cpm_grad_sink.data_ptr(), bias._cpm_grad_sink.data_ptr()
+            L.dgamma, L.dbeta = gamma._cpm_grad_sink.data_ptr(), beta._cpm_grad_sink.data_ptr()
+            L.gn_groups, L.eps = int(gn_groups), float(eps)
+            c, h, wd = k, L.conv.P, L.conv.Q
+        self.out_chw = (c, h, wd)
+        self.ptrs = self._pointers()
+        self.wt_ptrs = None
+        self.sizes = {}
+
+    def _pointers(self):
+        return tuple(p.data_ptr() for p in self.params) + tuple(p._cpm_grad_sink.data_ptr() for p in self.params)
+
+    def stale(self):
+        """a parameter or its gradient sink moved (load_state_dict into new storage, a rebuilt optimizer)"""
+        return self.ptrs != self._pointers()
+
+    def sizes_for(self, n):
+        r = self.sizes.get(n)
+        if r is None:
+            f, b, w = H.c_size_t(), H.c_size_t(), H.c_size_t()
+            H.check(H.lib().cpm_conv_gn_stack_sizes(self.table, self.n, int(n), H.ctypes.byref(f), H.ctypes.byref(b),
+                                                   H.ctypes.byref(w)), "conv_gn_stack_sizes")
+            if len(self.sizes) > 1024:
+                self.sizes.clear()
+            r = self.sizes[n] = (int(f.value), int(b.value), int(w.value))
+        return r
+
+    def refresh_weight_images(self):
+        """data-gradient weight images (FlatSGD._refresh_dgrad_weights): registered on first use, present from the
+        first optimizer step on; their addresses then stay put"""
+        wts = []
+        for i in range(self.n):
+            w = self.params[4 * i]
+            k, cin, r, s = w.shape
+            wt = _prepared_wt(w, 1, k, r * s, cin)
+            wts.append(wt.data_ptr() if wt is not None else None)
+        wts = tuple(wts)
+        if wts != self.wt_ptrs:
+            for i, v in enumerate(wts):
+                self.table[i].wt = v
+            self.wt_ptrs = wts
+
+
+class _ConvGNStackFn(Function):
+    """x -> L x [conv(w, b, stride, pad) -> GroupNorm(gamma, beta) -> ReLU]: the calls of _ConvFn + _GroupNormFn layer by
+    layer, issued by one C loop per direction (cpm_conv_gn_stack_*).  The parameters are not inputs of the node: each
+    owns a slice of the flat gradient buffer that the kernels accumulate into, and the reducer is told directly."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        H.require_gpu(x)
+        x = nhwc(x)
+        n = x.shape[0]
+        fwd_floats, _, ws_bytes = plan.sizes_for(n)
+        fbuf = torch.empty((fwd_floats,), dtype=torch.float32, device=x.device)
+        y = empty_nhwc((n,) + plan.out_chw, x)
+        for p_ in plan.params:
+            p_._cpm_uses = getattr(p_, "_cpm_uses", 0) + 1
+        ws = H.workspace(ws_bytes, x.device)
+        with H.guard(x.device):
+            rc = H.lib().cpm_conv_gn_stack_forward(plan.table, plan.n, n, H.ptr(x), H.ptr(fbuf), H.ptr(y), H.ptr(ws),
+                                                   H.c_size_t(ws.numel()), H.stream())
+        H.check(rc, "conv_gn_stack_forward")
+        ctx.plan = plan
+        ctx.save_for_backward(x, fbuf, y)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        x, fbuf, y = ctx.saved_tensors
+        plan = ctx.plan
+        dy = nhwc(dy)
+        dev = x.device
+        n = x.shape[0]
+        _, bwd_floats, ws_bytes = plan.sizes_for(n)
+        bbuf = torch.empty((bwd_floats,), dtype=torch.float32, device=dev)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        plan.refresh_weight_images()
+        ws = H.workspace(ws_bytes, dev)
+        side_raw, side_ws, st = None, None, None
+        if _SIDE_WGRAD:
+            wgrad_stream(dev)
+            st = _side[dev.index]
+            side_raw = st[1]
+            with H.use_stream(side_raw):
+                side_ws = H.workspace(ws_bytes, dev)
+        main_raw = H._raw_stream(dev.index)
+        with H.guard(dev):
+            rc = H.lib().cpm_conv_gn_stack_backward(plan.table, plan.n, n, H.ptr(x), H.ptr(dy), H.ptr(fbuf), H.ptr(y),
+                                                    H.ptr(bbuf), H.ptr(dx), H.ptr(ws), H.c_size_t(ws.numel()),
+                                                    H.ptr(side_ws),
+                                                    H.c_size_t(side_ws.numel() if side_ws is not None else 0),
+                                                    H.c_void_p(main_raw), H.c_void_p(side_raw))
+        H.check(rc, "conv_gn_stack_backward")
+        if side_raw is not None:
+            # the weight gradients read the layer inputs (x, the gn_outs inside fbuf) and d_conv (bbuf) on that stream
+            for t in (x, fbuf, bbuf):
+                t.record_stream(st[0])
+            _side_armed[dev.index] = main_raw
+            torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+        for p_ in plan.params:
+            _sink_done(p_)
+        return dx, None
+
+
+def conv_gn_stack(x, convs, norms):
+    """[conv(x) -> GroupNorm -> ReLU] over lists of ops.Conv2d / ops.GroupNorm modules; one autograd node when every
+    parameter accumulates into the flat gradient buffer (training under pet.utils.optimizer), the per-op path else."""
+    ok = _STACK and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and x.shape[0] > 0
+    plan = None
+    if ok:
+        cache = convs[0].__dict__.setdefault("_cpm_stack_plans", {})
+        chw = tuple(x.shape[1:])
+        plan = cache.get(chw)
+        if plan is not None and plan.stale():
+            plan = None
+        if plan is None:
+            params = []
+            for cv, gn in zip(convs, norms):
+                ps = (cv.weight, cv.bias, gn.weight, gn.bias)
+                ok = ok and all(p is not None and p.requires_grad and getattr(p, "_cpm_grad_sink", None) is not None
+                                and p._cpm_grad_sink.data_ptr() != 0 for p in ps) \
+                    and cv.groups == 1 and cv.dilation[0] == 1 and cv.in_channels > 1 \
+                    and cv.weight.is_contiguous(memory_format=CL) and cv.padding_mode == "zeros"
+                params += list(ps)
+            if ok:
+                cfgs = tuple((cv.stride[0], cv.padding[0], gn.num_groups, gn.eps) for cv, gn in zip(convs, norms))
+                if len(cache) > 16:
+                    cache.clear()
+                plan = cache[chw] = _StackPlan(chw, cfgs, tuple(params))
+    if plan is None:
+        for cv, gn in zip(convs, norms):
+            x = gn(cv(x), relu=True)
+        return x
+    return _ConvGNStackFn.apply(x, plan)
+
+
 def stem_forward(x, w_pad, scale, shift, r=7, s=7, stride=2, pad=3):
     """ResNet stem (backbone/ResNet.py:123-136): 7x7/s2 conv on 3 channels as im2col + 1x1 MFMA GEMM with the
     frozen affine + ReLU fused, then the 3x3/s2 max-pool.  Frozen stage: forward only.

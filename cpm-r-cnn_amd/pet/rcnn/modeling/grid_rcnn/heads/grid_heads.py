@@ -5,6 +5,7 @@ import numpy as np
 from torch import nn
 
 import pet.lib.ops as ops
+from pet.lib.ops import conv as conv_ops
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
 from pet.rcnn.utils.poolers import Pooler
@@ -46,6 +47,7 @@ class roi_grid_head(nn.Module):
     def forward(self, features, proposals):
         x = self.pooler(features, proposals)
         assert x.shape[-1] == x.shape[-2] == self.roi_feat_size
-        for blk in self.convs:
-            x = blk[1](blk[0](x), relu=True)          # conv -> GroupNorm+ReLU (one kernel)
+        # conv -> GroupNorm+ReLU x 8: one autograd node / one native call per direction when training on the flat
+        # gradient buffer (pet/lib/ops/conv.py: conv_gn_stack), layer by layer otherwise
+        x = conv_ops.conv_gn_stack(x, [blk[0] for blk in self.convs], [blk[1] for blk in self.convs])
         return x, None

@@ -457,6 +457,45 @@ int cpm_rescore_gather(const float* s_boxes, const float* s_obj, const int64_t* 
  * (one backward pass per process). */
 int cpm_stream_fork(void* from, void* to);
 
+/* ---- a stack of [conv + bias -> GroupNorm -> ReLU] layers from one call ------------------------------------------
+ * The CMM grid head (pet/rcnn/modeling/grid_rcnn/heads/grid_heads.py:41-57,146-152: 8 layers per cascade stage) on a
+ * few dozen RoIs is launch bound; these entry points run the per-layer C-ABI calls above (cpm_conv2d_forward,
+ * cpm_groupnorm_forward / cpm_groupnorm_backward, cpm_conv2d_backward_weight_bias, cpm_conv2d_backward_data[_prepared])
+ * in a loop, same order and arguments as a caller going layer by layer.  The layer table holds what does not change
+ * from call to call (geometry per sample: conv.N is ignored; parameter and gradient-sink pointers), so a caller builds
+ * it ONCE; the number of samples N (RoIs) comes with every call.  All per-call tensors live in two caller-owned
+ * buffers whose sizes cpm_conv_gn_stack_sizes reports for a given N (pieces laid out back to back, 256-byte aligned):
+ *   fwd_base: conv_out / gn_out [N,P,Q,K], mean / rstd [N, gn_groups] of every layer (written by forward, read by
+ *             backward); the LAST layer's gn_out is the separate tensor y;
+ *   bwd_base: d_conv [N,P,Q,K] and d_in [N,H,W,C] (gradient at the layer's input) of every layer; layer 0's d_in is the
+ *             separate tensor dx (NULL skips that data gradient);
+ *   dw / dbias / dgamma / dbeta: gradient sinks, ACCUMULATED into (dbias may be NULL); wt: the weight's data-gradient
+ *             image or NULL (then w is used).
+ * backward: `side_stream` (NULL = none) receives the weight-gradient launches, forked after each layer's GroupNorm
+ * backward; the caller joins it.  workspace (and side_workspace) >= the workspace_bytes reported for N. */
+typedef struct {
+  cpm_conv_desc conv;
+  const float* w;
+  const float* wt;
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  float* dw;
+  float* dbias;
+  float* dgamma;
+  float* dbeta;
+  int gn_groups;
+  float eps;
+} cpm_conv_gn_layer;
+int cpm_conv_gn_stack_sizes(const cpm_conv_gn_layer* layers, int n_layers, int N, size_t* fwd_floats,
+                            size_t* bwd_floats, size_t* workspace_bytes);
+int cpm_conv_gn_stack_forward(const cpm_conv_gn_layer* layers, int n_layers, int N, const float* x, float* fwd_base,
+                              float* y, void* workspace, size_t workspace_bytes, void* stream);
+int cpm_conv_gn_stack_backward(const cpm_conv_gn_layer* layers, int n_layers, int N, const float* x, const float* dy,
+                               float* fwd_base, float* y, float* bwd_base, float* dx, void* workspace,
+                               size_t workspace_bytes, void* side_workspace, size_t side_workspace_bytes, void* stream,
+                               void* side_stream);
+
 /* ---- measurement hooks (bench.py) ----------------------------------------------
  * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and
  * remembers the launch's ALGORITHMIC flops (2*N*P*Q*K*R*S*C/groups); cpm_prof_enable(0) stops and

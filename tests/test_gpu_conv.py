@@ -341,3 +341,67 @@ def test_filter_row_weight_gradient(case, deterministic, monkeypatch):
     finally:
         _hip.set_deterministic(False)
         _hip.set_conv_math(prev)
+
+
+def test_conv_gn_stack_equals_layer_by_layer():
+    """cpm_conv_gn_stack_forward / _backward (one native call per direction for a stack of conv + bias -> GroupNorm ->
+    ReLU layers, the grid head's shape) against the same layers run op by op: the same C-ABI calls in the same order,
+    so outputs, the input gradient and (in deterministic mode) the weight gradients agree bit for bit, the bias and
+    GroupNorm-parameter gradients to the order of their float atomics -- with the weight gradients on the second
+    stream as in training."""
+    import torch.nn as nn
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    from pet.rcnn.core import config
+    from pet.utils.optimizer import Optimizer
+
+    class Stack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            chans = [(48, 72, 2), (72, 72, 1), (72, 72, 1)]
+            self.convs = nn.ModuleList([ops.Conv2d(ci, co, 3, st, 1) for ci, co, st in chans])
+            self.norms = nn.ModuleList([ops.GroupNorm(12, co) for _, co, _ in chans])
+
+        def forward(self, x):
+            return C.conv_gn_stack(x, list(self.convs), list(self.norms))
+
+    config.reset_cfg()
+    prev_math, prev_stack = _hip.get_conv_math(), C._STACK
+    _hip.set_deterministic(True)
+    try:
+        torch.manual_seed(5)
+        m = Stack().cuda().to(memory_format=CL)
+        with torch.no_grad():
+            for gn in m.norms:
+                gn.weight.uniform_(0.5, 1.5)
+                gn.bias.uniform_(-0.5, 0.5)
+        opt = Optimizer(m, config.cfg.SOLVER).build()
+        x0 = rnd(37, 48, 14, 14, seed=21).cuda().contiguous(memory_format=CL)
+        dy = rnd(37, 72, 7, 7, seed=22).cuda().contiguous(memory_format=CL)
+        res = {}
+        for stack in (True, False):
+            C._STACK = stack
+            opt.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = m(x)
+            assert (y.grad_fn.__class__.__name__ == "_ConvGNStackFnBackward") == stack
+            y.backward(dy)
+            torch.cuda.synchronize()
+            res[stack] = (y.detach().clone(), x.grad.clone(), opt.flat_grad.clone())
+        ya, xa, ga = res[True]
+        yb, xb, gb = res[False]
+        live = torch.zeros(ga.numel(), dtype=torch.bool, device="cuda")
+        for b, e in zip(opt.seg_begin.tolist(), opt.seg_end.tolist()):
+            live[b:e] = True
+        assert torch.equal(ya, yb) and torch.equal(xa, xb)
+        assert float(gb[live].abs().max()) > 0
+        for cv in m.convs:                               # weight gradients: ordered slab sums, bit-reproducible
+            o = (cv.weight.grad.data_ptr() - opt.flat_grad.data_ptr()) // 4
+            assert torch.equal(ga[o:o + cv.weight.numel()], gb[o:o + cv.weight.numel()])
+        assert relerr(ga[live], gb[live]) < 1e-6         # bias / GroupNorm sums still fold with float atomics
+    finally:
+        C._STACK = prev_stack
+        _hip.set_deterministic(False)
+        _hip.set_conv_math(prev_math)
+        config.reset_cfg()
