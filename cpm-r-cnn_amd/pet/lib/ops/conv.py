@@ -122,6 +122,7 @@ def _prepared_wt(wparam, groups, kg, rs, cg):
     since the last refresh (`_version` moved: load_state_dict, manual edits)."""
     if wparam is None or not _WT_CACHE:
         return None
+    wparam = getattr(wparam, "_cpm_owner", wparam)      # a Linear's per-call [K,C,1,1] view stands for its parameter
     key = (groups, kg, rs, cg)
     reg = getattr(wparam, "_cpm_wt_desc", None)
     if reg is None:

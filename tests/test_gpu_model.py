@@ -450,7 +450,9 @@ def test_dgrad_weight_images_follow_the_optimizer():
         for k, p in reg:
             groups, kg, rs, cg = p._cpm_wt_desc
             w = p.detach()
-            if rs == 1 and w.shape[2] * w.shape[3] > 1:          # full-window conv registered as a [K, R*S*C] matrix
+            if w.dim() == 2:                                     # nn.Linear used as a 1x1 conv on a 1x1 image
+                want = w.t().reshape(-1)
+            elif rs == 1 and w.shape[2] * w.shape[3] > 1:        # full-window conv registered as a [K, R*S*C] matrix
                 want = w.permute(2, 3, 1, 0).reshape(-1)
             else:
                 K, Cg, R, S = w.shape
