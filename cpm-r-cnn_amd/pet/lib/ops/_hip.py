@@ -23,11 +23,11 @@ class ConvDesc(ctypes.Structure):
                                      "Q")]
 
 
-class ConvGNLayer(ctypes.Structure):
-    """cpm_conv_gn_layer (include/cpmrcnn_hip.h)"""
+class ChainLayer(ctypes.Structure):
+    """cpm_chain_layer (include/cpmrcnn_hip.h)"""
     _fields_ = [("conv", ConvDesc)] + \
                [(n, c_void_p) for n in ("w", "wt", "bias", "gamma", "beta", "dw", "dbias", "dgamma", "dbeta")] + \
-               [("gn_groups", c_int), ("eps", c_float)]
+               [("has_gn", c_int), ("relu", c_int), ("gn_groups", c_int), ("eps", c_float), ("dgrad_flat", c_int)]
 
 
 def lib():

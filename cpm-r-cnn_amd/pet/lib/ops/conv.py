@@ -613,28 +613,45 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
 _STACK = os.environ.get("CPM_CONV_GN_STACK", "1") != "0"
 
 
-class _StackPlan(object):
-    """What does not change from call to call about a [conv -> GroupNorm -> ReLU] stack on a given per-sample input
-    shape: the native layer table (cpm_conv_gn_layer[]: per-sample geometry, parameter and gradient-sink pointers).
-    Built once; the number of samples (RoIs) varies from step to step and only sizes the two buffers of a call
-    (cpm_conv_gn_stack_sizes, remembered per N).  The stages this exists for run ~0.3 ms of kernels: dozens of small
-    allocations or ~150 ctypes field stores in front of the first launch would cost what the native loop saves."""
+class _ChainPlan(object):
+    """What does not change from call to call about a chain of [conv + bias -> (GroupNorm) -> (ReLU)] layers on a
+    given per-sample input shape: the native layer table (cpm_chain_layer[]: per-sample geometry, parameter and
+    gradient-sink pointers).  Built once; the number of samples (RoIs) varies from step to step and only sizes the two
+    buffers of a call (cpm_layer_chain_sizes, remembered per N).  The chains this exists for run ~0.3 ms of kernels:
+    dozens of small allocations or ~150 ctypes field stores in front of the first launch would cost what the native
+    loop saves."""
 
-    def __init__(self, chw, cfgs, params):
-        self.cfgs, self.params, self.n = cfgs, params, len(cfgs)
-        self.table = (H.ConvGNLayer * self.n)()
+    def __init__(self, chw, specs):
+        """specs: per layer (weight [K,C,R,S] or [K,C], bias, gamma or None, beta or None, stride, pad, gn_groups, eps,
+        relu)"""
+        self.n = len(specs)
+        self.table = (H.ChainLayer * self.n)()
+        params, self.dgrad_keys = [], []
         c, h, wd = chw
-        for i, (stride, pad, gn_groups, eps) in enumerate(cfgs):
-            w, bias, gamma, beta = params[4 * i:4 * i + 4]
-            k, _, r, s = w.shape
+        for i, (w, bias, gamma, beta, stride, pad, gn_groups, eps, relu) in enumerate(specs):
+            k = w.shape[0]
+            r, s = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
             L = self.table[i]
             L.conv = make_desc(1, c, h, wd, k, r, s, stride, pad, 1, 1)
-            L.w, L.bias, L.gamma, L.beta = w.data_ptr(), bias.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+            L.w, L.bias = w.data_ptr(), bias.data_ptr()
             L.dw, L.dbias = w._cpm_grad_sink.data_ptr(), bias._cpm_grad_sink.data_ptr()
-            L.dgamma, L.dbeta = gamma._cpm_grad_sink.data_ptr(), beta._cpm_grad_sink.data_ptr()
-            L.gn_groups, L.eps = int(gn_groups), float(eps)
+            L.has_gn, L.relu = int(gamma is not None), int(bool(relu))
+            layer_params = [w, bias]
+            if gamma is not None:
+                L.gamma, L.beta = gamma.data_ptr(), beta.data_ptr()
+                L.dgamma, L.dbeta = gamma._cpm_grad_sink.data_ptr(), beta._cpm_grad_sink.data_ptr()
+                L.gn_groups, L.eps = int(gn_groups), float(eps)
+                layer_params += [gamma, beta]
+            params += layer_params
+            # conv2d_backward_data's rule: a full-window layer (fc6, iou_fc1) runs its data gradient as the 1x1 problem
+            # over R*S*C channels it is, with the weight registered as that [K, R*S*C] matrix
+            full_window = (r, s) == (h, wd) and pad == 0 and stride == 1 and (r > 1 or s > 1)
+            L.dgrad_flat = int(full_window)
+            self.dgrad_keys.append((w, 1, k, 1, r * s * c) if full_window else (w, 1, k, r * s, c))
             c, h, wd = k, L.conv.P, L.conv.Q
         self.out_chw = (c, h, wd)
+        self.flat_out = specs[-1][0].dim() == 2                  # a Linear ends the chain: [N, K] output
+        self.params = tuple(params)
         self.ptrs = self._pointers()
         self.wt_ptrs = None
         self.sizes = {}
@@ -650,8 +667,8 @@ class _StackPlan(object):
         r = self.sizes.get(n)
         if r is None:
             f, b, w = H.c_size_t(), H.c_size_t(), H.c_size_t()
-            H.check(H.lib().cpm_conv_gn_stack_sizes(self.table, self.n, int(n), H.ctypes.byref(f), H.ctypes.byref(b),
-                                                   H.ctypes.byref(w)), "conv_gn_stack_sizes")
+            H.check(H.lib().cpm_layer_chain_sizes(self.table, self.n, int(n), H.ctypes.byref(f), H.ctypes.byref(b),
+                                                 H.ctypes.byref(w)), "layer_chain_sizes")
             if len(self.sizes) > 1024:
                 self.sizes.clear()
             r = self.sizes[n] = (int(f.value), int(b.value), int(w.value))
@@ -661,10 +678,8 @@ class _StackPlan(object):
         """data-gradient weight images (FlatSGD._refresh_dgrad_weights): registered on first use, present from the
         first optimizer step on; their addresses then stay put"""
         wts = []
-        for i in range(self.n):
-            w = self.params[4 * i]
-            k, cin, r, s = w.shape
-            wt = _prepared_wt(w, 1, k, r * s, cin)
+        for key in self.dgrad_keys:
+            wt = _prepared_wt(*key)
             wts.append(wt.data_ptr() if wt is not None else None)
         wts = tuple(wts)
         if wts != self.wt_ptrs:
@@ -673,26 +688,29 @@ class _StackPlan(object):
             self.wt_ptrs = wts
 
 
-class _ConvGNStackFn(Function):
-    """x -> L x [conv(w, b, stride, pad) -> GroupNorm(gamma, beta) -> ReLU]: the calls of _ConvFn + _GroupNormFn layer by
-    layer, issued by one C loop per direction (cpm_conv_gn_stack_*).  The parameters are not inputs of the node: each
-    owns a slice of the flat gradient buffer that the kernels accumulate into, and the reducer is told directly."""
+class _LayerChainFn(Function):
+    """x -> L x [conv(w, b) -> (GroupNorm) -> (ReLU)]: the calls of _ConvFn / _GroupNormFn layer by layer, issued by one
+    C loop per direction (cpm_layer_chain_*).  The parameters are not inputs of the node: each owns a slice of the flat
+    gradient buffer that the kernels accumulate into, and the reducer is told directly."""
 
     @staticmethod
     def forward(ctx, x, plan):
         H.require_gpu(x)
-        x = nhwc(x)
+        x = nhwc(x) if x.dim() == 4 else x.contiguous()
         n = x.shape[0]
         fwd_floats, _, ws_bytes = plan.sizes_for(n)
         fbuf = torch.empty((fwd_floats,), dtype=torch.float32, device=x.device)
-        y = empty_nhwc((n,) + plan.out_chw, x)
+        if plan.flat_out:
+            y = torch.empty((n, plan.out_chw[0]), dtype=torch.float32, device=x.device)
+        else:
+            y = torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device, memory_format=CL)
         for p_ in plan.params:
             p_._cpm_uses = getattr(p_, "_cpm_uses", 0) + 1
         ws = H.workspace(ws_bytes, x.device)
         with H.guard(x.device):
-            rc = H.lib().cpm_conv_gn_stack_forward(plan.table, plan.n, n, H.ptr(x), H.ptr(fbuf), H.ptr(y), H.ptr(ws),
-                                                   H.c_size_t(ws.numel()), H.stream())
-        H.check(rc, "conv_gn_stack_forward")
+            rc = H.lib().cpm_layer_chain_forward(plan.table, plan.n, n, H.ptr(x), H.ptr(fbuf), H.ptr(y), H.ptr(ws),
+                                                 H.c_size_t(ws.numel()), H.stream())
+        H.check(rc, "layer_chain_forward")
         ctx.plan = plan
         ctx.save_for_backward(x, fbuf, y)
         return y
@@ -702,7 +720,7 @@ class _ConvGNStackFn(Function):
     def backward(ctx, dy):
         x, fbuf, y = ctx.saved_tensors
         plan = ctx.plan
-        dy = nhwc(dy)
+        dy = nhwc(dy) if dy.dim() == 4 else dy.contiguous()
         dev = x.device
         n = x.shape[0]
         _, bwd_floats, ws_bytes = plan.sizes_for(n)
@@ -719,15 +737,15 @@ class _ConvGNStackFn(Function):
                 side_ws = H.workspace(ws_bytes, dev)
         main_raw = H._raw_stream(dev.index)
         with H.guard(dev):
-            rc = H.lib().cpm_conv_gn_stack_backward(plan.table, plan.n, n, H.ptr(x), H.ptr(dy), H.ptr(fbuf), H.ptr(y),
-                                                    H.ptr(bbuf), H.ptr(dx), H.ptr(ws), H.c_size_t(ws.numel()),
-                                                    H.ptr(side_ws),
-                                                    H.c_size_t(side_ws.numel() if side_ws is not None else 0),
-                                                    H.c_void_p(main_raw), H.c_void_p(side_raw))
-        H.check(rc, "conv_gn_stack_backward")
+            rc = H.lib().cpm_layer_chain_backward(plan.table, plan.n, n, H.ptr(x), H.ptr(dy), H.ptr(fbuf), H.ptr(y),
+                                                  H.ptr(bbuf), H.ptr(dx), H.ptr(ws), H.c_size_t(ws.numel()),
+                                                  H.ptr(side_ws),
+                                                  H.c_size_t(side_ws.numel() if side_ws is not None else 0),
+                                                  H.c_void_p(main_raw), H.c_void_p(side_raw))
+        H.check(rc, "layer_chain_backward")
         if side_raw is not None:
-            # the weight gradients read the layer inputs (x, the gn_outs inside fbuf) and d_conv (bbuf) on that stream
-            for t in (x, fbuf, bbuf):
+            # the weight gradients read the layer inputs (x, the outputs inside fbuf), dy and d_conv (bbuf) over there
+            for t in (x, fbuf, bbuf, dy):
                 t.record_stream(st[0])
             _side_armed[dev.index] = main_raw
             torch.autograd.Variable._execution_engine.queue_callback(_join_side)
@@ -736,36 +754,72 @@ class _ConvGNStackFn(Function):
         return dx, None
 
 
-def conv_gn_stack(x, convs, norms):
-    """[conv(x) -> GroupNorm -> ReLU] over lists of ops.Conv2d / ops.GroupNorm modules; one autograd node when every
-    parameter accumulates into the flat gradient buffer (training under pet.utils.optimizer), the per-op path else."""
-    ok = _STACK and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and x.dim() == 4 and x.shape[0] > 0
-    plan = None
-    if ok:
-        cache = convs[0].__dict__.setdefault("_cpm_stack_plans", {})
-        chw = tuple(x.shape[1:])
-        plan = cache.get(chw)
-        if plan is not None and plan.stale():
-            plan = None
-        if plan is None:
-            params = []
-            for cv, gn in zip(convs, norms):
-                ps = (cv.weight, cv.bias, gn.weight, gn.bias)
-                ok = ok and all(p is not None and p.requires_grad and getattr(p, "_cpm_grad_sink", None) is not None
-                                and p._cpm_grad_sink.data_ptr() != 0 for p in ps) \
-                    and cv.groups == 1 and cv.dilation[0] == 1 and cv.in_channels > 1 \
-                    and cv.weight.is_contiguous(memory_format=CL) and cv.padding_mode == "zeros"
-                params += list(ps)
-            if ok:
-                cfgs = tuple((cv.stride[0], cv.padding[0], gn.num_groups, gn.eps) for cv, gn in zip(convs, norms))
-                if len(cache) > 16:
-                    cache.clear()
-                plan = cache[chw] = _StackPlan(chw, cfgs, tuple(params))
+def _sunk(p):
+    return p is not None and p.requires_grad and getattr(p, "_cpm_grad_sink", None) is not None \
+        and p._cpm_grad_sink.data_ptr() != 0
+
+
+def layer_chain(x, layers, owner):
+    """Run `layers` = [(conv_or_linear_module, GroupNorm_module_or_None, relu), ...] on x as ONE autograd node with one
+    native call per direction (cpm_layer_chain_*) when training on the flat gradient buffer; returns None when the
+    chain does not qualify (the caller then goes layer by layer).  `owner`: the module the plans are cached on."""
+    if not (_STACK and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and x.shape[0] > 0):
+        return None
+    cache = owner.__dict__.setdefault("_cpm_chain_plans", {})
+    chw = tuple(x.shape[1:]) if x.dim() == 4 else (x.shape[1], 1, 1)
+    key = (chw, len(layers))
+    plan = cache.get(key)
+    if plan is not None and plan.stale():
+        plan = None
     if plan is None:
-        for cv, gn in zip(convs, norms):
-            x = gn(cv(x), relu=True)
-        return x
-    return _ConvGNStackFn.apply(x, plan)
+        specs = []
+        for i, (m, gn, relu) in enumerate(layers):
+            w, b = m.weight, m.bias
+            if not (_sunk(w) and _sunk(b)) or (gn is not None and not (_sunk(gn.weight) and _sunk(gn.bias))):
+                return None
+            if w.dim() == 4:
+                conv_like = hasattr(m, "stride")
+                stride, pad = (m.stride[0], m.padding[0]) if conv_like else (1, 0)
+                if conv_like and (m.groups != 1 or m.dilation[0] != 1 or m.in_channels <= 1 or m.padding_mode != "zeros"):
+                    return None
+                if not w.is_contiguous(memory_format=CL):
+                    return None
+            else:
+                stride, pad = 1, 0
+                if not (w.dim() == 2 and w.is_contiguous()):
+                    return None
+            if gn is None and relu and i == len(layers) - 1:
+                return None                                  # a bare ReLU at the end needs its consumer's gate
+            specs.append((w, b, gn.weight if gn is not None else None, gn.bias if gn is not None else None, stride, pad,
+                          gn.num_groups if gn is not None else 0, gn.eps if gn is not None else 0.0, relu))
+        if len(cache) > 16:
+            cache.clear()
+        plan = cache[key] = _ChainPlan(chw, specs)
+    return _LayerChainFn.apply(x, plan)
+
+
+def conv_gn_stack(x, convs, norms):
+    """[conv(x) -> GroupNorm -> ReLU] over lists of ops.Conv2d / ops.GroupNorm modules (the grid head): one autograd
+    node when it qualifies (layer_chain), layer by layer otherwise."""
+    y = layer_chain(x, [(cv, gn, True) for cv, gn in zip(convs, norms)], convs[0]) if x.dim() == 4 else None
+    if y is not None:
+        return y
+    for cv, gn in zip(convs, norms):
+        x = gn(cv(x), relu=True)
+    return x
+
+
+def mlp_chain(x, linears, owner):
+    """Linear -> ReLU -> ... -> Linear (no ReLU after the last one) over ops.Linear modules -- fc6 / fc7 / cls_score,
+    iou_fc1 / iou_fc2 / iou_pred: one autograd node when it qualifies, the per-module calls (with the consumer-side
+    ReLU gates of conv2d / linear) otherwise."""
+    last = len(linears) - 1
+    y = layer_chain(x, [(m, None, i != last) for i, m in enumerate(linears)], owner)
+    if y is not None:
+        return y
+    for i, m in enumerate(linears):
+        x = m(x, relu=True, sole_consumer=True) if i != last else m(x)
+    return x
 
 
 def stem_forward(x, w_pad, scale, shift, r=7, s=7, stride=2, pad=3):

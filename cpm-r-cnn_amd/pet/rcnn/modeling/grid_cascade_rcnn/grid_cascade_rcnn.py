@@ -13,6 +13,7 @@ import torch
 from torch import nn
 
 import pet.lib.ops as ops
+from pet.lib.ops import conv as conv_ops
 from pet.lib.ops import roi_lists as RL
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
@@ -228,7 +229,7 @@ class GridCascadeRCNN(nn.Module):
             self._count_reads[0].start(counts_all)
         # ---- cls head on the sample's capacity, queued before the host waits for the counts -----------------
         ev.set_packed_sample(None, sample.labels)
-        loss = dict(loss_classifier=ev([self.Output_cls(self.Head_cls(features, _capacity_rows(sample)))]))
+        loss = dict(loss_classifier=ev([_head_logits(self.Head_cls, self.Output_cls, features, _capacity_rows(sample))]))
         c = self._count_reads[0].wait()                               # host round trip 1 of 3
         if c[-1]:
             raise RuntimeError("an image holds more than %d proposals; set CPM_DEVICE_LISTS=0" % RL.roi_sample_max_rows())
@@ -282,7 +283,7 @@ class GridCascadeRCNN(nn.Module):
         result = _LazyViews(self, rs, sizes)
         self._pending = result
         rev.set_packed_sample(result, rs.labels)
-        logits = self.Output_rescore(self.Head_rescore(features, _capacity_rows(rs)))
+        logits = _head_logits(self.Head_rescore, self.Output_rescore, features, _capacity_rows(rs))
         loss["loss_rescore"] = rev([logits]) * G.RESCORE_LOSS_WEIGHT
         return x, result, loss
 
@@ -324,6 +325,13 @@ class GridCascadeRCNN(nn.Module):
     def _forward_test_rescore(self, features, proposals):
         logits = self.Output_rescore(self.Head_rescore(features, proposals))
         return self.cls_post_processor(logits, proposals, rescore=True)
+
+
+def _head_logits(head, output, features, rows):
+    """RoIAlign -> fc6 -> ReLU -> fc7 -> ReLU -> cls_score of a cls / RSM head: the three Linears as one autograd node
+    (pet/lib/ops/conv.py: mlp_chain); the backward pass starts with these, and op by op its first kernels are the
+    smallest of the step"""
+    return conv_ops.mlp_chain(head.pooler(features, rows), [head.fc6, head.fc7, output.cls_score], head)
 
 
 class _PackedBoxLists(list):

@@ -7,6 +7,7 @@ import torch.nn.init as init
 from torch import nn
 
 import pet.lib.ops as ops
+from pet.lib.ops import conv as conv_ops
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling import registry
 from pet.utils.net import make_fc
@@ -45,9 +46,8 @@ class Grid_output(nn.Module):
         heat = self.deconv_2(x1)
         iou_logits = None
         if self.has_iou:
-            t = self.iou_fc1(x, relu=True, sole_consumer=True)
-            t = self.iou_fc2(t, relu=True, sole_consumer=True)
-            iou_logits = self.iou_pred(t)
+            # iou_fc1 -> ReLU -> iou_fc2 -> ReLU -> iou_pred: one native call per direction in training
+            iou_logits = conv_ops.mlp_chain(x, [self.iou_fc1, self.iou_fc2, self.iou_pred], self)
         return dict(fused=None, unfused=heat), iou_logits
 
 

@@ -457,22 +457,26 @@ int cpm_rescore_gather(const float* s_boxes, const float* s_obj, const int64_t* 
  * (one backward pass per process). */
 int cpm_stream_fork(void* from, void* to);
 
-/* ---- a stack of [conv + bias -> GroupNorm -> ReLU] layers from one call ------------------------------------------
- * The CMM grid head (pet/rcnn/modeling/grid_rcnn/heads/grid_heads.py:41-57,146-152: 8 layers per cascade stage) on a
- * few dozen RoIs is launch bound; these entry points run the per-layer C-ABI calls above (cpm_conv2d_forward,
- * cpm_groupnorm_forward / cpm_groupnorm_backward, cpm_conv2d_backward_weight_bias, cpm_conv2d_backward_data[_prepared])
- * in a loop, same order and arguments as a caller going layer by layer.  The layer table holds what does not change
- * from call to call (geometry per sample: conv.N is ignored; parameter and gradient-sink pointers), so a caller builds
- * it ONCE; the number of samples N (RoIs) comes with every call.  All per-call tensors live in two caller-owned
- * buffers whose sizes cpm_conv_gn_stack_sizes reports for a given N (pieces laid out back to back, 256-byte aligned):
- *   fwd_base: conv_out / gn_out [N,P,Q,K], mean / rstd [N, gn_groups] of every layer (written by forward, read by
- *             backward); the LAST layer's gn_out is the separate tensor y;
- *   bwd_base: d_conv [N,P,Q,K] and d_in [N,H,W,C] (gradient at the layer's input) of every layer; layer 0's d_in is the
- *             separate tensor dx (NULL skips that data gradient);
+/* ---- a chain of RoI-head layers (conv + bias -> [GroupNorm] -> [ReLU]) from one call --------------------------------
+ * The CMM grid head (8 x conv3x3 -> GroupNorm -> ReLU, pet/rcnn/modeling/grid_rcnn/heads/grid_heads.py:41-57,146-152),
+ * the cls / RSM head (fc6 -> ReLU -> fc7 -> ReLU -> cls_score, heads/cls_heads.py:13-48 + outputs.py:87-104) and the
+ * ISM branch (outputs.py:38-45,76-83) on a few dozen RoIs are launch bound; these entry points run the per-layer C-ABI
+ * calls above (cpm_conv2d_forward, cpm_groupnorm_forward / _backward, cpm_conv2d_backward_weight[_bias],
+ * cpm_conv2d_backward_data[_gated / _prepared]) in a loop, same order and arguments as a caller going layer by layer.
+ * A Linear is a 1x1 conv on a 1x1 image, fc6 / iou_fc1 a full-window conv.  The layer table holds what does not
+ * change from call to call (geometry per sample: conv.N is ignored; parameter and gradient-sink pointers), so a caller
+ * builds it ONCE; the number of samples N (RoIs) comes with every call.  relu: with has_gn the GroupNorm kernel applies
+ * it; without, the conv epilogue does and the NEXT layer's data gradient undoes it (gate on its input), so the last
+ * layer of a chain must not end in a bare ReLU.  All per-call tensors live in two caller-owned buffers whose sizes
+ * cpm_layer_chain_sizes reports for a given N (pieces back to back, 256-byte aligned):
+ *   fwd_base: conv_out [N,P,Q,K] (+ gn_out, mean / rstd [N, gn_groups] with has_gn) of every layer (written by
+ *             forward, read by backward); the LAST layer's output is the separate tensor y;
+ *   bwd_base: d_conv [N,P,Q,K] (has_gn only) and d_in [N,H,W,C] (gradient at the layer's input) of every layer; layer
+ *             0's d_in is the separate tensor dx (NULL skips that data gradient);
  *   dw / dbias / dgamma / dbeta: gradient sinks, ACCUMULATED into (dbias may be NULL); wt: the weight's data-gradient
  *             image or NULL (then w is used).
- * backward: `side_stream` (NULL = none) receives the weight-gradient launches, forked after each layer's GroupNorm
- * backward; the caller joins it.  workspace (and side_workspace) >= the workspace_bytes reported for N. */
+ * backward: `side_stream` (NULL = none) receives the weight-gradient launches, forked per layer; the caller joins it.
+ * workspace (and side_workspace) >= the workspace_bytes reported for N. */
 typedef struct {
   cpm_conv_desc conv;
   const float* w;
@@ -484,17 +488,20 @@ typedef struct {
   float* dbias;
   float* dgamma;
   float* dbeta;
+  int has_gn;
+  int relu;
   int gn_groups;
   float eps;
-} cpm_conv_gn_layer;
-int cpm_conv_gn_stack_sizes(const cpm_conv_gn_layer* layers, int n_layers, int N, size_t* fwd_floats,
-                            size_t* bwd_floats, size_t* workspace_bytes);
-int cpm_conv_gn_stack_forward(const cpm_conv_gn_layer* layers, int n_layers, int N, const float* x, float* fwd_base,
-                              float* y, void* workspace, size_t workspace_bytes, void* stream);
-int cpm_conv_gn_stack_backward(const cpm_conv_gn_layer* layers, int n_layers, int N, const float* x, const float* dy,
-                               float* fwd_base, float* y, float* bwd_base, float* dx, void* workspace,
-                               size_t workspace_bytes, void* side_workspace, size_t side_workspace_bytes, void* stream,
-                               void* side_stream);
+  int dgrad_flat;   /* full-window layer: data gradient as the [N,K] x [K, R*S*C] GEMM it is (wt = that matrix's image) */
+} cpm_chain_layer;
+int cpm_layer_chain_sizes(const cpm_chain_layer* layers, int n_layers, int N, size_t* fwd_floats, size_t* bwd_floats,
+                          size_t* workspace_bytes);
+int cpm_layer_chain_forward(const cpm_chain_layer* layers, int n_layers, int N, const float* x, float* fwd_base,
+                            float* y, void* workspace, size_t workspace_bytes, void* stream);
+int cpm_layer_chain_backward(const cpm_chain_layer* layers, int n_layers, int N, const float* x, const float* dy,
+                             float* fwd_base, float* y, float* bwd_base, float* dx, void* workspace,
+                             size_t workspace_bytes, void* side_workspace, size_t side_workspace_bytes, void* stream,
+                             void* side_stream);
 
 /* ---- measurement hooks (bench.py) ----------------------------------------------
  * cpm_prof_enable(1) brackets every conv kernel launch with HIP events on its own stream and

@@ -385,7 +385,7 @@ def test_conv_gn_stack_equals_layer_by_layer():
             opt.zero_grad()
             x = x0.clone().requires_grad_(True)
             y = m(x)
-            assert (y.grad_fn.__class__.__name__ == "_ConvGNStackFnBackward") == stack
+            assert (y.grad_fn.__class__.__name__ == "_LayerChainFnBackward") == stack
             y.backward(dy)
             torch.cuda.synchronize()
             res[stack] = (y.detach().clone(), x.grad.clone(), opt.flat_grad.clone())
@@ -400,6 +400,63 @@ def test_conv_gn_stack_equals_layer_by_layer():
             o = (cv.weight.grad.data_ptr() - opt.flat_grad.data_ptr()) // 4
             assert torch.equal(ga[o:o + cv.weight.numel()], gb[o:o + cv.weight.numel()])
         assert relerr(ga[live], gb[live]) < 1e-6         # bias / GroupNorm sums still fold with float atomics
+    finally:
+        C._STACK = prev_stack
+        _hip.set_deterministic(False)
+        _hip.set_conv_math(prev_math)
+        config.reset_cfg()
+
+
+def test_mlp_chain_equals_layer_by_layer():
+    """cpm_layer_chain_* on a Linear chain (full-window fc6-like layer -> ReLU -> Linear -> ReLU -> Linear: the cls /
+    RSM / ISM heads) against the per-module calls with their consumer-side ReLU gates: outputs and input gradient bit
+    for bit, weight gradients bit for bit in deterministic mode."""
+    import torch.nn as nn
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    from pet.rcnn.core import config
+    from pet.utils.optimizer import Optimizer
+
+    class Head(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc6 = ops.Linear(40 * 7 * 7, 96, window=(40, 7, 7))
+            self.fc7 = ops.Linear(96, 64)
+            self.out = ops.Linear(64, 11)
+
+        def forward(self, x):
+            return C.mlp_chain(x, [self.fc6, self.fc7, self.out], self)
+
+    config.reset_cfg()
+    prev_math, prev_stack = _hip.get_conv_math(), C._STACK
+    _hip.set_deterministic(True)
+    try:
+        torch.manual_seed(9)
+        m = Head().cuda()
+        m.fc6.weight.data = m.fc6.weight.data.contiguous(memory_format=CL)
+        opt = Optimizer(m, config.cfg.SOLVER).build()
+        x0 = rnd(53, 40, 7, 7, seed=31).cuda().contiguous(memory_format=CL)
+        dy = rnd(53, 11, seed=32).cuda()
+        res = {}
+        for chain in (True, False):
+            C._STACK = chain
+            opt.zero_grad()
+            x = x0.clone().requires_grad_(True)
+            y = m(x)
+            assert (y.grad_fn.__class__.__name__ == "_LayerChainFnBackward") == chain
+            y.backward(dy)
+            torch.cuda.synchronize()
+            res[chain] = (y.detach().clone(), x.grad.clone(), opt.flat_grad.clone())
+        ya, xa, ga = res[True]
+        yb, xb, gb = res[False]
+        assert tuple(ya.shape) == (53, 11) and torch.equal(ya, yb) and torch.equal(xa, xb)
+        for lin in (m.fc6, m.fc7, m.out):
+            o = (lin.weight.grad.data_ptr() - opt.flat_grad.data_ptr()) // 4
+            assert float(gb[o:o + lin.weight.numel()].abs().max()) > 0
+            assert torch.equal(ga[o:o + lin.weight.numel()], gb[o:o + lin.weight.numel()])
+            ob = (lin.bias.grad.data_ptr() - opt.flat_grad.data_ptr()) // 4
+            assert relerr(ga[ob:ob + lin.bias.numel()], gb[ob:ob + lin.bias.numel()]) < 1e-6
     finally:
         C._STACK = prev_stack
         _hip.set_deterministic(False)
