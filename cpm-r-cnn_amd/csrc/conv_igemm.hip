@@ -111,14 +111,31 @@ __global__ __launch_bounds__(64 * WM * WN)
   float4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
   const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
 
-  auto load_tile = [&](int kt, float4 (&ra)[AP], float4 (&rb)[BP]) {
-    const int tap = kt / a.ksteps_per_tap;
-    const int cb = (kt - tap * a.ksteps_per_tap) * BK;      // first reduction channel of this k-step (uniform)
-    const int tr = tap / a.ns, ts = tap - tr * a.ns;
-    const int dh = tr * a.hstep, dw = ts * a.wstep;
-    const unsigned wtap = (unsigned)(((a.r0 + tr * a.rstep) * a.S + a.s0 + ts * a.sstep) * a.CgR + cb) * 4u;
+  // position (tap row, tap column, channel block) of the NEXT tile to load, advanced without divisions: the loads of
+  // a k-step are then a handful of scalar instructions and sit in the same straight-line block as its MFMAs
+  int l_tr, l_ts, l_cb;
+  {
+    const int tap = k_begin / a.ksteps_per_tap;
+    l_cb = (k_begin - tap * a.ksteps_per_tap) * BK;
+    l_tr = tap / a.ns;
+    l_ts = tap - l_tr * a.ns;
+  }
+  const int cb_end = a.ksteps_per_tap * BK;
+  auto load_tile = [&](bool live, float4 (&ra)[AP], float4 (&rb)[BP]) {     // live == false: every lane masked
+    const int cb = l_cb;                                    // first reduction channel of this k-step (uniform)
+    const int dh = l_tr * a.hstep, dw = l_ts * a.wstep;
+    const unsigned wtap = (unsigned)(((a.r0 + l_tr * a.rstep) * a.S + a.s0 + l_ts * a.sstep) * a.CgR + cb) * 4u;
     const unsigned aoff = (unsigned)((dh * a.IW + dw) * a.Ctot + cb) * 4u;
-    const bool c_ok = cb + lcol < a.CgR;
+    {
+      const int ncb = l_cb + BK;
+      const bool wrap_c = ncb >= cb_end;
+      const int nts = l_ts + (wrap_c ? 1 : 0);
+      const bool wrap_s = nts == a.ns;
+      l_cb = wrap_c ? 0 : ncb;
+      l_ts = wrap_s ? 0 : nts;
+      l_tr += wrap_s ? 1 : 0;
+    }
+    const bool c_ok = live & (cb + lcol < a.CgR);
     if (VEC) {
       // branch-free: all the step's loads issue back to back; a masked lane gets an out-of-range offset
 #pragma unroll
@@ -253,7 +270,7 @@ __global__ __launch_bounds__(64 * WM * WN)
   // co-resident waves' MFMAs and the step ends with the barrier alone.
   auto step = [&](int it, int cur, float4 (&la)[AP], float4 (&lb)[BP], const float4 (&sa)[AP],
                   const float4 (&sb)[BP]) {
-    if (it + 2 < nk) load_tile(k_begin + it + 2, la, lb);
+    load_tile(it + 2 < nk, la, lb);
     if (SPLIT) {
       Frag f0, f1;
       fetch(cur, 0, f0);
@@ -263,13 +280,15 @@ __global__ __launch_bounds__(64 * WM * WN)
       store_tile(cur ^ 1, sa, sb);
       mfma3(f1);
       constexpr int NM = TM * TN * 3 * 2;                      // MFMAs of the step
-      constexpr int VPM = (AP + BP) * 12 / NM > 0 ? (AP + BP) * 12 / NM : 1;   // split VALU ops per MFMA gap
+      // VALU ops per MFMA gap: 12 per float4 for the split + ~4 per load for its offset and mask
+      constexpr int VPM = ((AP + BP) * 16 + NM - 1) / NM;
       constexpr int WEVERY = NM / (AP + BP) > 0 ? NM / (AP + BP) : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
 #pragma unroll
       for (int m = 0; m < NM; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+        if (m >= 1 && m <= AP + BP) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // the loads early in the step
         if (m % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
       }
     } else {
@@ -281,9 +300,9 @@ __global__ __launch_bounds__(64 * WM * WN)
   };
 
   if (nk > 0) {
-    load_tile(k_begin, ra0, rb0);
+    load_tile(true, ra0, rb0);
     store_tile(0, ra0, rb0);
-    if (nk > 1) load_tile(k_begin + 1, ra1, rb1);
+    load_tile(nk > 1, ra1, rb1);
   }
   __syncthreads();
   for (int it = 0; it < nk; it += 2) {

@@ -609,7 +609,7 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, relu=False):
     return _GroupNormFn.apply(x, gamma, beta, groups, eps, relu)
 
 
-# ---- a stack of [conv + bias -> GroupNorm -> ReLU] layers as ONE autograd node (cpm_conv_gn_stack_*) -------------
+# ---- a stack of [conv + bias -> GroupNorm -> ReLU] layers as ONE autograd node (cpm_layer_chain_*) -------------
 _STACK = os.environ.get("CPM_CONV_GN_STACK", "1") != "0"
 
 

@@ -344,7 +344,7 @@ def test_filter_row_weight_gradient(case, deterministic, monkeypatch):
 
 
 def test_conv_gn_stack_equals_layer_by_layer():
-    """cpm_conv_gn_stack_forward / _backward (one native call per direction for a stack of conv + bias -> GroupNorm ->
+    """cpm_layer_chain_forward / _backward (one native call per direction for a stack of conv + bias -> GroupNorm ->
     ReLU layers, the grid head's shape) against the same layers run op by op: the same C-ABI calls in the same order,
     so outputs, the input gradient and (in deterministic mode) the weight gradients agree bit for bit, the bias and
     GroupNorm-parameter gradients to the order of their float atomics -- with the weight gradients on the second
