@@ -31,6 +31,7 @@
 // Reference call sites replaced: see include/cpmrcnn_hip.h (conv section).
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -1148,7 +1149,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // row/column-permuted accordingly; it is un-permuted through LDS at the end so that the float atomics into dw
 // are 256-byte contiguous per wave instruction.
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_split_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256)
+    __attribute__((amdgpu_waves_per_eu(2, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))) void wgrad_split_kernel(
+        WgradArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int QA = BM / 4, QB = BN / 4;              // channel vectors per tile
@@ -1189,50 +1192,65 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const unsigned b_chan = (unsigned)(g * a.Cg + c0 + 4 * qb) * 4u;
   asm volatile("" : "+v"(a_off));
 
-  // (n, oh, ow) of the thread's 4 pixels, stepped by 32 pixels per chunk without divisions
+  // The thread's 4 pixels, stepped by 32 pixels per chunk without divisions AND without multiplications: per pixel
+  // (oh, ow) and the byte offset of its input element for this tap; a row / image carry adds a constant to the
+  // offset (v_mul_lo_u32 runs at quarter rate: the three of ((n*IH + ih)*IW + iw)*C cost more than the whole walk).
   const int hw = a.OH * a.OW;
   const int dn = 32 / hw, rem = 32 % hw;
   const int dh = rem / a.OW, dwid = rem % a.OW;
-  int b_n[4], b_oh[4], b_ow[4];
+  const int tap_h = r * a.dil - a.pad, tap_w = s * a.dil - a.pad;
+  const unsigned pixb = (unsigned)a.Ctot * 4u;                                  // bytes per input pixel
+  const unsigned off_step = (unsigned)((dn * a.IH + dh * a.stride) * a.IW + dwid * a.stride) * pixb;
+  const unsigned off_cw = (unsigned)((a.IW - a.OW) * a.stride) * pixb;          // ow wrapped: next output row
+  const unsigned off_ch = (unsigned)((a.IH - a.OH * a.stride) * a.IW) * pixb;   // oh wrapped: next image
+  int b_m = ch_begin * 32 + 4 * prb;                                            // first pixel of the run
+  int b_oh[4], b_ow[4];
+  unsigned b_off[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int m = ch_begin * 32 + 4 * prb + i;
+    const int m = b_m + i;
     b_ow[i] = m % a.OW;
     const int t = m / a.OW;
     b_oh[i] = t % a.OH;
-    b_n[i] = t / a.OH;
+    const int n = t / a.OH;
+    b_off[i] = (unsigned)((n * a.IH + b_oh[i] * a.stride + tap_h) * a.IW + b_ow[i] * a.stride + tap_w) * pixb + b_chan;
   }
 
-  float4 ra[4], rb[4];
-  auto load_chunk = [&]() {
+  // two register sets: the loads of chunk t+2 are in flight while chunk t is multiplied and chunk t+1 (loaded a whole
+  // step ago) is split and moved to the other LDS buffer.  Everything of a step is ONE straight-line block (dead
+  // loads are masked by their offset, the last step re-stores a chunk of zeros into the idle buffer), so that the
+  // address arithmetic, the loads, the bf16 split and the LDS stores all sit in the issue gaps of the step's 24 MFMAs
+  // instead of in front of and behind them.
+  float4 ra0[4], rb0[4], ra1[4], rb1[4];
+  constexpr bool ALL_A = QA == 32, ALL_B = QB == 32;     // 256 threads = QA/16 x 8 runs: every thread has a slot
+  auto load_chunk = [&](bool live, float4 (&ra)[4], float4 (&rb)[4]) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, a_act ? a_off + i * a_pix : OOB_OFF);   // rows >= M: beyond dy
+    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, (live & a_act) ? a_off + i * a_pix : OOB_OFF);   // rows >= M: beyond dy
     a_off += a_step;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int ih = b_oh[i] * a.stride - a.pad + r * a.dil, iw = b_ow[i] * a.stride - a.pad + s * a.dil;
-      const bool ok = b_act & (b_n[i] < a.N) & ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
-      rb[i] = bload4(rs_x, ok ? (unsigned)(((b_n[i] * a.IH + ih) * a.IW + iw) * a.Ctot) * 4u + b_chan : OOB_OFF);
-      b_n[i] += dn; b_oh[i] += dh; b_ow[i] += dwid;
-      if (b_ow[i] >= a.OW) { b_ow[i] -= a.OW; ++b_oh[i]; }
-      if (b_oh[i] >= a.OH) { b_oh[i] -= a.OH; ++b_n[i]; }
+      const int ih = __mul24(b_oh[i], a.stride) + tap_h, iw = __mul24(b_ow[i], a.stride) + tap_w;
+      const bool ok = live & b_act & (b_m + i < a.M) & ((unsigned)ih < (unsigned)a.IH) & ((unsigned)iw < (unsigned)a.IW);
+      unsigned off = ok ? b_off[i] : OOB_OFF;
+      asm volatile("" : "+v"(off));                         // a select, not a branch around the load
+      rb[i] = bload4(rs_x, off);
+      b_ow[i] += dwid;
+      const bool cw = b_ow[i] >= a.OW;
+      b_ow[i] -= cw ? a.OW : 0;
+      b_oh[i] += dh + (cw ? 1 : 0);
+      const bool chh = b_oh[i] >= a.OH;
+      b_oh[i] -= chh ? a.OH : 0;
+      b_off[i] += off_step + (cw ? off_cw : 0u) + (chh ? off_ch : 0u);
     }
+    b_m += 32;
   };
   // the 4 pixels of one channel -> one 8-byte hi store and one 8-byte lo store in the channel's row
   const int wa_sw = (((pra >> 1) ^ ((qa >> 2) & 3)) << 2) | ((pra & 1) << 1);
   const int wb_sw = (((prb >> 1) ^ ((qb >> 2) & 3)) << 2) | ((prb & 1) << 1);
-  const bool do_bias = a.dshift != nullptr && tap == 0 && tile_n == 0;      // block-uniform
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);        // channels oc0 + 4*qa .. +3 over this thread's pixel runs
-  auto store_chunk = [&](int buf) {
-    if (pra < 8) {
+  auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
+    if (ALL_A || pra < 8) {
       const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
                             make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
-      if (do_bias) {
-        bsum.x += (ch[0].x + ch[0].y) + (ch[0].z + ch[0].w);
-        bsum.y += (ch[1].x + ch[1].y) + (ch[1].z + ch[1].w);
-        bsum.z += (ch[2].x + ch[2].y) + (ch[2].z + ch[2].w);
-        bsum.w += (ch[3].x + ch[3].y) + (ch[3].z + ch[3].w);
-      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         uint2 hi, lo;
@@ -1242,7 +1260,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *(uint2*)(sm + PA_LO + o) = lo;
       }
     }
-    if (prb < 8) {
+    if (ALL_B || prb < 8) {
       const float4 ch[4] = {make_float4(rb[0].x, rb[1].x, rb[2].x, rb[3].x), make_float4(rb[0].y, rb[1].y, rb[2].y, rb[3].y),
                             make_float4(rb[0].z, rb[1].z, rb[2].z, rb[3].z), make_float4(rb[0].w, rb[1].w, rb[2].w, rb[3].w)};
 #pragma unroll
@@ -1265,48 +1283,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   const int frow = lane & 31;
-  auto mma_half = [&](int cur, int sub) {
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto fetch = [&](int cur, int sub, Frag& f) {
     const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
-    bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
-      ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
-      al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
-      bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
-      bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
     }
+  };
+  auto mfma3 = [&](const Frag& f) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
       }
   };
-
-  if (nk > 0) {
-    load_chunk();
-    store_chunk(0);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) load_chunk();
-    mma_half(cur, 0);
-    mma_half(cur, 1);
-    if (it + 1 < nk) store_chunk(cur ^ 1);
+  auto step = [&](int it, int cur, float4 (&la)[4], float4 (&lb)[4], const float4 (&sa)[4], const float4 (&sb)[4]) {
+    load_chunk(it + 2 < nk, la, lb);
+    Frag f0, f1;
+    fetch(cur, 0, f0);
+    mfma3(f0);
+    store_chunk(cur ^ 1, sa, sb);
+    fetch(cur, 1, f1);
+    mfma3(f1);
+    // issue order: the first half's operand reads, then one MFMA per gap with its share of the VALU work (pixel walk,
+    // offsets, bf16 split), the loads in the first gaps, the LDS stores spread evenly, and the second half's operand
+    // reads two per gap from the last third of the first half on (their registers free up as the first half drains:
+    // both halves resident at once cost 32 VGPRs more and spilled)
+    constexpr int NM = TM * TN * 6, NH = NM / 2;           // MFMAs of the step / of a half
+    constexpr int NR = 2 * (TM + TN);                      // operand reads of a half (even)
+    constexpr int NW = (ALL_A || BM == 64 ? 8 : 0) + (ALL_B || BN == 64 ? 8 : 0);       // LDS stores of a thread with slots
+    constexpr int VPM = (8 * 12 + 8 * 10 + NM - 1) / NM;   // split VALU + ~10 per load for its pixel walk, offset, mask
+    constexpr int R0 = NH - NR / 2;                        // first gap with second-half reads
+    static_assert(R0 >= 0, "two reads per gap");
+    __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+      if (m >= 1 && m <= 8) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      if (m >= R0 && m < NH) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+      const int nw = (m + 1) * NW / NM - m * NW / NM;     // the LDS stores spread evenly over the MFMAs
+      if (nw >= 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if (nw >= 2) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+      if (nw >= 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
     __syncthreads();
-    cur ^= 1;
-  }
+  };
 
+  // The bias gradient (sum of dy over the pixels) belongs to the workgroups of tap 0 / input-channel tile 0: they walk
+  // their dy rows once more in front of the reduction loop (the rows then come out of L2 for the loop itself); kept
+  // out of the loop, whose registers are all spoken for.
+  const bool do_bias = a.dshift != nullptr && tap == 0 && tile_n == 0;      // block-uniform
   if (do_bias) {
-    // the 8 pixel runs of a channel vector sit in 8 threads: fold through LDS (free after the loop's last barrier)
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);      // channels oc0 + 4*qa .. +3 over this thread's pixel runs
+    unsigned o = a_off;
+    for (int it = 0; it < nk; ++it, o += a_step) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = bload4(rs_dy, a_act ? o + i * a_pix : OOB_OFF);
+      bsum.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+      bsum.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+      bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
+      bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+    }
+    // the 8 pixel runs of a channel vector sit in 8 threads: fold through LDS
     static_assert(8 * BM <= LDS_AB, "bias reduction layout");
     if (pra < 8) *(float4*)&smem[pra * BM + 4 * qa] = bsum;
     __syncthreads();
@@ -1317,6 +1369,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       atomicAdd(a.dshift + g * a.OCg + oc0 + tid, t);
     }
     __syncthreads();
+  }
+
+  load_chunk(nk > 0, ra0, rb0);
+  store_chunk(0, ra0, rb0);
+  load_chunk(nk > 1, ra1, rb1);
+  __syncthreads();
+  for (int it = 0; it < nk; it += 2) {
+    step(it, 0, ra0, rb0, ra1, rb1);
+    if (it + 1 < nk) step(it + 1, 1, ra1, rb1, ra0, rb0);
   }
 
   // un-permute through LDS: accumulator row R holds output channel (R % QA) * 4 + R / QA, column C input channel
@@ -2238,19 +2299,24 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   auto blocks = [&](int bm, int bn) {
     return (int64_t)cpm::cdiv(a.OCg, bm) * cpm::cdiv(a.Cg, bn) * taps * a.groups;
   };
-  // split of the pixel reduction: enough workgroups to fill the chip, chosen so that the grid is close to a whole
-  // number of residency rounds (2 workgroups per CU for the 128-tiles, 4 for the 64-tiles)
+  // Split of the pixel reduction.  Fitted to tools/sweep_wgrad_split.sh on MI355X: a workgroup costs its chunks PLUS a
+  // fixed ~9 chunk-times (prologue latency, the un-permuted 64 KB tile it writes, its share of the slab reduction), and
+  // the grid runs in residency rounds of per_cu workgroups per CU, a round that is at most half full running at
+  // 0.78 of a full one's time (a workgroup alone on a CU has the MFMA pipes to itself).  The earlier model (rounds / sk,
+  // i.e. no fixed cost) split the RoI-head and layer4 gradients 3-4x too deep: 576x576x3x3 over 64 RoIs 155 -> 107 us,
+  // 512x512x3x3 88 -> 60 us, fc6 232 -> 169 us.
   auto split_for = [&](int64_t nb, int per_cu) {
     const int64_t slots = (int64_t)per_cu * num_cus();
     const int maxs = a.chunks / 8 > 0 ? (a.chunks / 8 > 256 ? 256 : a.chunks / 8) : 1;
+    const double fixed = per_cu == 2 ? 9.0 : 5.0;
     int best = 1;
     double best_cost = 1e30;
     for (int sk = 1; sk <= maxs; ++sk) {
       const int64_t nblk = nb * sk;
-      const int64_t rounds = (nblk + slots - 1) / slots;
-      // time ~ rounds * (work per block) ~ rounds / sk; small penalty per extra split (slab traffic)
-      const double cost = (double)rounds / sk * (1.0 + 0.01 * sk);
-      if (cost < best_cost - 1e-12) { best_cost = cost; best = sk; }
+      const int64_t full = nblk / slots, tail = nblk % slots;
+      const double rounds = (double)full + (tail == 0 ? 0.0 : (tail * 2 <= slots ? 0.78 : 1.0));
+      const double cost = rounds * ((double)cpm::cdiv(a.chunks, sk) + fixed);
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = sk; }
     }
     return best;
   };
@@ -2270,6 +2336,7 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   }
   // (64x64 tiles on the 1x1 layers, to quarter the atomic bytes of their 32-way splits: measured 15 % slower)
   p.split = split_for(blocks(p.bm, p.bn), p.bm * p.bn >= 128 * 128 ? 2 : 4);
+  if (const int forced = env_int("CPM_WGRAD_SPLIT", 0)) p.split = forced < a.chunks ? forced : a.chunks;   // sweeps
   p.bf16 = wvec && g_conv_split && p.bm % 64 == 0 && p.bn % 64 == 0;
   // 3x3 / stride 1 / pad 1 on the split-bf16 arithmetic: one filter row per workgroup (wgrad_row3_kernel)
   // Measured (tools/bench_conv.py, CPM_WGRAD_ROW3=0/1/2): +13 % on the 2x256x200x336 layers (547 -> 482 us) and +25 %

@@ -27,7 +27,8 @@ for i in range(1, 8):
     for f in glob.glob("gpurun_out/%s_lp%d/**/*counter_collection.csv" % (tag, i), recursive=True):
         seen = set()
         for r in csv.DictReader(open(f)):
-            k = re.sub(r"\(.*", "", r["Kernel_Name"])[:60] + " g%s" % r["Grid_Size"]
+            nm = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            k = re.sub(r"\(.*", "", nm)[:50] + " g%s" % r["Grid_Size"]
             if not re.search(r"igemm|wgrad", k): continue
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (k, r["Dispatch_Id"])
