@@ -1849,6 +1849,10 @@ Plan plan_igemm(const IgemmArgs& a) {
       if (c.bm == 128 && c.bn == 128 && sp == 1 && full >= 1 && tail && tail * 2 < slots)
         rounds = (double)full + 0.30 + 0.7 * (double)tail / slots;
       double cost = rounds * per_block * c.per_cu;     // a round of per_cu workgroups shares the CU's MFMA pipes
+      // A short reduction on big tiles that fill the chip about once: every workgroup is in its prologue, then in its
+      // k-steps, then in its epilogue at the same time -- nothing overlaps (256->1024 1x1 on 8 400 pixels: 528 tiles,
+      // 42.4 us; as 2 112 64x64 tiles 34.6 us; tools/sweep_short_k.sh)
+      if (g_conv_split && a.ksteps <= 16 && c.bm == 128 && c.bn == 128 && sp == 1 && full <= 1) cost *= 1.15;
       if (sp > 1) cost += 3.0 * (double)a.M * a.OCg * a.groups / num_cus();            // memset + atomics + epilogue pass
       if (cost < best) { best = cost; p.bm = c.bm; p.bn = c.bn; p.split = sp; }
       if (blocks >= 4 * slots) break;
