@@ -1908,7 +1908,7 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
       a.in_bytes < 0x80000000u) {
     const int64_t patches = (int64_t)a.N * cpm::cdiv(a.OH, HT_H) * cpm::cdiv(a.OW, HT_W);
     const int64_t blocks = patches * cpm::cdiv(a.OCg, 128);
-    static const int halo_min = env_int("CPM_IGEMM_HALO_MIN", 128);
+    static const int halo_min = env_int("CPM_IGEMM_HALO_MIN", 320);    // below ~1.25 workgroups per CU the generic kernel's finer tiles win (128 ch on 100x168: 64 -> 60 us)
     if (blocks >= halo_min) {
       hipLaunchKernelGGL((igemm3x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
       return cpm::check_launch("conv igemm 3x3 (halo)");
