@@ -20,12 +20,16 @@ import os
 import sys
 import time
 
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "cpm-r-cnn_amd"))
 sys.path.insert(0, ROOT)
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
+
+SUM_LOSSES = os.environ.get("CPM_SUM_LOSSES", "0") != "0"      # 1: form the summed loss and call backward on it
+backward_losses_fn = None
 
 CPM_R50_OPTS = [  # cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml
     "MODEL.FPN_ON", True, "MODEL.FASTER_RCNN", False, "MODEL.GRID_ON", True, "MODEL.NUM_CLASSES", 81,
@@ -118,7 +122,9 @@ class Trainer(object):
         from pet.utils.lr_scheduler import LearningRateScheduler
         from pet.utils.net import convert_bn2affine_model
         from pet.utils.optimizer import Optimizer
-        from pet.utils.parallel import FlatGradReducer
+        from pet.utils.parallel import FlatGradReducer, backward_losses
+        global backward_losses_fn
+        backward_losses_fn = backward_losses
         config.reset_cfg()
         config.merge_cfg_from_list(CPM_R50_OPTS)
         if body == "x101dcn":
@@ -141,12 +147,13 @@ class Trainer(object):
         self.optimizer.zero_grad()
         self.reducer.begin_step()
         out = self.model(images, targets)
-        loss = sum(out["losses"].values())
-        loss.backward()
+        if SUM_LOSSES:
+            sum(out["losses"].values()).backward()
+        else:
+            backward_losses_fn(out["losses"])
         self.reducer.finish()
         self.optimizer.step()
         self.last_losses = out["losses"]
-        return loss
 
 
 def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):

@@ -29,7 +29,8 @@ from pet.utils.checkpointer import CheckPointer  # noqa: E402
 from pet.utils.lr_scheduler import LearningRateScheduler  # noqa: E402
 from pet.utils.net import convert_bn2affine_model, mismatch_params_filter  # noqa: E402
 from pet.utils.optimizer import Optimizer  # noqa: E402
-from pet.utils.parallel import FlatGradReducer, broadcast_initial_state, reduce_losses  # noqa: E402
+from pet.utils.parallel import (FlatGradReducer, backward_losses, broadcast_initial_state,  # noqa: E402
+                                reduce_losses)
 
 log = logging.getLogger("train_net")
 
@@ -53,8 +54,7 @@ def train(model, loader, optimizer, scheduler, checkpointer, reducer, device, ra
         targets = [t.to(device) for t in targets]
         reducer.begin_step()
         losses = model(images, targets)["losses"]
-        total = sum(losses.values())
-        total.backward()
+        backward_losses(losses)                                    # = sum(losses.values()).backward()
         reducer.finish()
         optimizer.step()
         seen += len(targets)
