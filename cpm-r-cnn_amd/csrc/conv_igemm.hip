@@ -2356,7 +2356,7 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   // LDS per workgroup leaves no room for a data-gradient workgroup beside it).  So: 0 = off (default), 1 = the layers
   // it wins on in isolation, 2 = every eligible layer (tests).
   const int row3 = env_int("CPM_WGRAD_ROW3", 0);              // read per call: the tests switch it
-  const bool row3_pays = row3 == 2 || (int64_t)a.M >= 65536 || (a.Cg >= 512 && a.OCg >= 512);
+  const bool row3_pays = row3 == 2 || (int64_t)a.M >= 65536;
   if (row3 && row3_pays && p.bf16 && p.bm == 128 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
       a.OH == a.IH && a.OW == a.IW && a.Cg >= 64 && a.x_bytes < 0x80000000u && a.dy_bytes < 0x80000000u) {
     p.row3 = true;
@@ -2367,10 +2367,12 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
     const int maxs = chunks3 / 8 > 0 ? (chunks3 / 8 > 256 ? 256 : chunks3 / 8) : 1;
     int best = 1;
     double best_cost = 1e30;
-    for (int sk = 1; sk <= maxs; ++sk) {
-      const int64_t rounds = (nb * sk + slots - 1) / slots;
-      const double cost = (double)rounds / sk * (1.0 + 0.01 * sk);
-      if (cost < best_cost - 1e-12) { best_cost = cost; best = sk; }
+    for (int sk = 1; sk <= maxs; ++sk) {              // same model as split_for; a chunk is 1.5 x the MFMAs, 3 tiles out
+      const int64_t nblk = nb * sk;
+      const int64_t full = nblk / slots, tail = nblk % slots;
+      const double rounds = (double)full + (tail == 0 ? 0.0 : (tail * 2 <= slots ? 0.78 : 1.0));
+      const double cost = rounds * ((double)cpm::cdiv(chunks3, sk) + 9.0);
+      if (cost < best_cost - 1e-9) { best_cost = cost; best = sk; }
     }
     p.split = best;
   }
