@@ -530,6 +530,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int tiles_n = (a.OCg + BN - 1) / BN;
   const int patches_x = (a.OW + HT_W - 1) / HT_W, patches_y = (a.OH + HT_H - 1) / HT_H;
   int bid = blockIdx.x;
+  if (a.xcd_swizzle) {                                // see igemm_kernel: contiguous logical ids per XCD, so that the
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;     // N-tiles of a patch and neighbouring
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);   // patches (shared halo) share an L2
+  }
   const int tile_n = bid % tiles_n; bid /= tiles_n;
   const int pxi = bid % patches_x; bid /= patches_x;
   const int pyi = bid % patches_y;
@@ -944,6 +948,7 @@ struct WgradArgs {
   int split_k, chunks;  // chunks = ceil(M/32)
   unsigned x_bytes, dy_bytes;
   int debug_nostore;
+  int xcd_swizzle;  // wgrad_split_kernel: give every XCD whole pixel splits (see the kernel)
   float* slab;      // split_k > 1: [split][OCtot][R][S][Cg] partial sums, one plane per reduction split, written with
                     // plain stores and folded into dw in split order by wgrad_reduce_kernel (deterministic; the
                     // float-atomic epilogue it replaces cost 23 % of the weight-gradient time).  null: see the epilogues
@@ -1170,10 +1175,25 @@ __global__ __launch_bounds__(256)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (a.Cg + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-  const int tap = blockIdx.y;
+  // XCD-aware order.  The (channel tile, tap) workgroups of one pixel split all stream the same dy and x chunks; in
+  // launch order (x fastest, workgroups dealt round-robin over the 8 XCDs) they land on all eight L2s, each of which
+  // then fetches those chunks from the Infinity Cache for itself (46 % of the kernel's L2 requests missed).  Give each
+  // XCD a contiguous run of logical ids instead, i.e. whole splits: the sharers sit behind one L2.  Bijective for
+  // any grid (the igemm kernels' formula); a speed hint only.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_swizzle) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int lin = bx + gx * (by + gy * bz), nwg = gx * gy * gridDim.z;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = lin & 7;
+    const int l2 = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (lin >> 3);
+    bx = l2 % gx;
+    by = (l2 / gx) % gy;
+    bz = l2 / (gx * gy);
+  }
+  const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
+  const int tap = by;
   const int r = tap / a.S, s = tap - r * a.S;
-  const int g = blockIdx.z / a.split_k, split = blockIdx.z % a.split_k;
+  const int g = bz / a.split_k, split = bz % a.split_k;
   const int oc0 = tile_m * BM, c0 = tile_n * BN;
 
   const int per = (a.chunks + a.split_k - 1) / a.split_k;
@@ -2400,6 +2420,8 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   static const int nostore = env_int("CPM_WGRAD_NOSTORE", 0);
   a.debug_nostore = nostore;
+  static const int wxcd = env_int("CPM_WGRAD_XCD", 1);
+  a.xcd_swizzle = wxcd;
   ProfScope prof_scope(s, 2);
   if (a.Cg == 1 && taps <= 16) {
     if (dbias) {
