@@ -39,7 +39,8 @@ def _run(body, layers, batch, meta_file, grid_cap):
         assert tuple(images.tensors.shape) == (batch, 3, 800, 1344)
         losses = []
         for it in range(2):
-            loss = tr.step(images, targets)
+            tr.step(images, targets)
+            loss = sum(v.detach() for v in tr.last_losses.values())
             torch.cuda.synchronize()
             assert torch.isfinite(loss), (it, {k: float(v) for k, v in tr.last_losses.items()})
             assert set(tr.last_losses) == {"loss_objectness", "loss_rpn_box_reg", "loss_classifier", "loss_grid_1",
