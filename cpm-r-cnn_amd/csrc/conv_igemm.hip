@@ -506,6 +506,300 @@ __global__ __launch_bounds__(64 * WM * WN)
   }
 }
 
+// ---- the same kernel with ONE LDS stage and one register set of loads (bf16x3, vector path, direct epilogues) --------
+// Measured with in-kernel stamps: a k-step of igemm_kernel costs a wave ~2 900 cycles for 768 cycles of
+// MFMA work whether or not it shares its SIMD, and two waves per SIMD overlap 1.84x -- what bounds the kernel is the
+// number of instruction streams per SIMD, which its 72 KB of LDS and ~240 VGPRs hold at two.  Here a k-step is
+//   barrier (every wave has its operands of tile t-1 in registers) -> split + store tile t into THE stage, issue the
+//   loads of tile t+1 into the same registers -> barrier -> all operand reads of tile t -> its 24 MFMAs,
+// which run in the pipe while the wave does the next step's split and stores.  32 KB of LDS and <= 168 VGPRs: three
+// workgroups per CU.  Epilogues that stage the tile through LDS (residual / staged) stay on igemm_kernel.
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_s1_kernel(IgemmArgs a) {
+  constexpr bool VEC = true, SPLIT = true;
+  constexpr int NT = 64 * WM * WN;              // threads
+  constexpr int RPP = NT / 8;                   // rows per load pass (8 threads x float4 cover a 32-float row)
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;   // MFMA tiles per wave
+  constexpr int AP = BM / RPP, BP = BN / RPP;   // load passes
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0 && BN % RPP == 0, "tile shape");
+
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * 32];      // hi / lo planes of A and B, one stage
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.OCg + BN - 1) / BN;
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (ids b and b+8 share an L2), so give
+  // each XCD a contiguous run of logical tiles -- the N-tiles of one row block and neighbouring row blocks (which
+  // share 3x3 halo rows) then hit the same L2.  Bijective for any grid size; a speed hint only.
+  int bid = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+  const int g = blockIdx.y;
+  const int split = blockIdx.z;
+  const int m0 = a.m_base + tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread load geometry --------------------------------------------------------------
+  // Everything a load needs per k-step is (row byte offset + one uniform tap offset) and two range checks; the
+  // offsets are pinned in registers (the empty asm) -- otherwise the compiler re-derives them from n/h/w with
+  // integer multiplies inside every k-step and sinks each load under its own exec-masked branch.
+  const int lrow = tid >> 3;        // 0..RPP-1
+  const int lcol = (tid & 7) * 4;   // 0,4,..,28
+  unsigned a_off[AP];
+  int a_h[AP], a_w[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = m0 + i * RPP + lrow;
+    const bool ok = m < a.M;
+    const int mm = ok ? m : 0;
+    const int jj = mm % a.OWp, t = mm / a.OWp;
+    const int ii = t % a.OHp, n = t / a.OHp;
+    a_h[i] = ok ? ii * a.ihmul + a.ihadd : -(1 << 28);      // a row past M never passes the range check
+    a_w[i] = jj * a.iwmul + a.iwadd;
+    a_off[i] = (unsigned)(((n * a.IH + (ok ? a_h[i] : 0)) * a.IW + a_w[i]) * a.Ctot + g * a.CgR + lcol) * 4u;
+    asm volatile("" : "+v"(a_off[i]), "+v"(a_h[i]), "+v"(a_w[i]));
+  }
+  unsigned b_off[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int oc = n0 + i * RPP + lrow;
+    b_off[i] = oc < a.OCg ? (unsigned)((g * a.OCg + oc) * a.R * a.S * a.CgR + lcol) * 4u : B_INVALID;
+    asm volatile("" : "+v"(b_off[i]));
+  }
+
+  // k-step range of this split
+  const int per = (a.ksteps + a.split_k - 1) / a.split_k;
+  const int k_begin = split * per;
+  const int k_end = min(a.ksteps, k_begin + per);
+  const int nk = k_end - k_begin;
+
+  // one register set: the loads of tile t+1 are issued right behind the stores of tile t
+  float4 ra0[AP], rb0[BP];
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
+
+  // position (tap row, tap column, channel block) of the NEXT tile to load, advanced without divisions: the loads of
+  // a k-step are then a handful of scalar instructions and sit in the same straight-line block as its MFMAs
+  int l_tr, l_ts, l_cb;
+  {
+    const int tap = k_begin / a.ksteps_per_tap;
+    l_cb = (k_begin - tap * a.ksteps_per_tap) * BK;
+    l_tr = tap / a.ns;
+    l_ts = tap - l_tr * a.ns;
+  }
+  const int cb_end = a.ksteps_per_tap * BK;
+  auto load_tile = [&](bool live, float4 (&ra)[AP], float4 (&rb)[BP]) {     // live == false: every lane masked
+    const int cb = l_cb;                                    // first reduction channel of this k-step (uniform)
+    const int dh = l_tr * a.hstep, dw = l_ts * a.wstep;
+    const unsigned wtap = (unsigned)(((a.r0 + l_tr * a.rstep) * a.S + a.s0 + l_ts * a.sstep) * a.CgR + cb) * 4u;
+    const unsigned aoff = (unsigned)((dh * a.IW + dw) * a.Ctot + cb) * 4u;
+    {
+      const int ncb = l_cb + BK;
+      const bool wrap_c = ncb >= cb_end;
+      const int nts = l_ts + (wrap_c ? 1 : 0);
+      const bool wrap_s = nts == a.ns;
+      l_cb = wrap_c ? 0 : ncb;
+      l_ts = wrap_s ? 0 : nts;
+      l_tr += wrap_s ? 1 : 0;
+    }
+    const bool c_ok = live & (cb + lcol < a.CgR);
+    if (VEC) {
+      // branch-free: all the step's loads issue back to back; a masked lane gets an out-of-range offset
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const bool ok = c_ok & ((unsigned)(a_h[i] + dh) < (unsigned)a.IH) & ((unsigned)(a_w[i] + dw) < (unsigned)a.IW);
+        ra[i] = bload4(rs_in, ok ? a_off[i] + aoff : OOB_OFF);
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) rb[i] = bload4(rs_wm, c_ok ? b_off[i] + wtap : OOB_OFF);
+      return;
+    }
+    const int c0 = cb + lcol;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const bool ok = c_ok && (unsigned)(a_h[i] + dh) < (unsigned)a.IH && (unsigned)(a_w[i] + dw) < (unsigned)a.IW;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) {
+        const float* src = a.in + ((a_off[i] + aoff) >> 2);
+        v.x = src[0];
+        if (c0 + 1 < a.CgR) v.y = src[1];
+        if (c0 + 2 < a.CgR) v.z = src[2];
+        if (c0 + 3 < a.CgR) v.w = src[3];
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c_ok && b_off[i] != B_INVALID) {
+        const float* src = a.wm + ((b_off[i] + wtap) >> 2);
+        v.x = src[0];
+        if (c0 + 1 < a.CgR) v.y = src[1];
+        if (c0 + 2 < a.CgR) v.z = src[2];
+        if (c0 + 3 < a.CgR) v.w = src[3];
+      }
+      rb[i] = v;
+    }
+  };
+  // SPLIT LDS image: four planes A_hi | A_lo | B_hi | B_lo, each [2 buffers][rows][32 bf16 = 64 B], no padding.
+  // A row's four 16-byte chunks are stored at chunk ^ ((row >> 2) & 3): the 16 lanes of a ds_read_b128 group (16
+  // consecutive rows, same chunk) then hit 16 distinct 4-bank groups, and so do the ds_write_b64 of two rows.
+  // hi and lo live in different planes (kilobytes apart), so the compiler cannot fuse them into one ds_write2.
+  unsigned* const sm = reinterpret_cast<unsigned*>(smem);
+  constexpr int PA_HI = 0, PA_LO = BM * 16, PB_HI = 2 * BM * 16, PB_LO = 2 * BM * 16 + BN * 16;
+  static_assert(!SPLIT || (RPP % 16 == 0 && WTM % 32 == 0), "swizzle assumes row blocks of 16");
+  const int w_sw = ((((lcol >> 3) ^ ((lrow >> 2) & 3)) << 2) | ((lcol >> 1) & 2));   // dword offset inside the row
+  auto store_tile = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP]) {
+    if (SPLIT) {
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        uint2 hi, lo;
+        split4(ra[i], hi, lo);
+        const int o = (buf * BM + i * RPP + lrow) * 16 + w_sw;
+        *(uint2*)(sm + PA_HI + o) = hi;
+        *(uint2*)(sm + PA_LO + o) = lo;
+      }
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        uint2 hi, lo;
+        split4(rb[i], hi, lo);
+        const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
+        *(uint2*)(sm + PB_HI + o) = hi;
+        *(uint2*)(sm + PB_LO + o) = lo;
+      }
+      return;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int frow = lane & 31;
+  // SPLIT: operand fetch and MFMAs as separate pieces, so that a k-step can fetch BOTH 16-deep halves first and
+  // then run its 24 MFMAs with the next tile's bf16 split + LDS stores laid into their issue gaps
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto fetch = [&](int cur, int sub, Frag& f) {
+    const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+    }
+  };
+  auto mfma3 = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+  load_tile(nk > 0, ra0, rb0);
+  for (int it = 0; it < nk; ++it) {
+    if (it) __syncthreads();                            // every wave holds its operands of tile it-1 in registers
+    store_tile(0, ra0, rb0);                            // (waits for the loads issued a step ago)
+    load_tile(it + 1 < nk, ra0, rb0);
+    __syncthreads();                                    // tile `it` complete in LDS
+    Frag f0, f1;
+    fetch(0, 0, f0);
+    fetch(0, 1, f1);
+    mfma3(f0);
+    mfma3(f1);
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  const bool dense_rows = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
+  // per-column epilogue constants once per lane (inside the store loop every one of these loads would sit behind
+  // the previous store: the compiler cannot hoist a load over a store that may alias it)
+  float e_sc[TN], e_sh[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ocl = n0 + wn * WTN + j * 32 + ecol;
+    const bool ok = ocl < a.OCg && !a.atomic_out;
+    e_sc[j] = (a.scale && ok) ? a.scale[g * a.OCg + ocl] : 1.f;
+    e_sh[j] = (a.shift && ok) ? a.shift[g * a.OCg + ocl] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    // gate operands of the 32-row slab first (independent loads in flight), see igemm3x3_kernel's epilogue
+    float gate[16][TN];
+    if (a.mask && !a.atomic_out) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+        int orow = m;
+        if (!dense_rows && m < a.M) {
+          const int jj = m % a.OWp, t = m / a.OWp;
+          orow = ((t / a.OHp) * a.OH + (t % a.OHp) * a.osh + a.oah) * a.OW + jj * a.osw + a.oaw;
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int ocl = n0 + wn * WTN + j * 32 + ecol;
+          gate[e][j] = (m < a.M && ocl < a.OCg) ? a.mask[(size_t)orow * a.OCtot + g * a.OCg + ocl] : 1.f;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int m = m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+      if (m >= a.M) continue;
+      int orow = m, oh = 0, ow = 0, n = 0;
+      if (!dense_rows || (a.res && a.res_mode == 1)) {
+        const int jj = m % a.OWp, t = m / a.OWp;
+        const int ii = t % a.OHp;
+        n = t / a.OHp;
+        oh = ii * a.osh + a.oah;
+        ow = jj * a.osw + a.oaw;
+        orow = (n * a.OH + oh) * a.OW + ow;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int ocl = n0 + wn * WTN + j * 32 + ecol;
+        if (ocl >= a.OCg) continue;
+        const int oc = g * a.OCg + ocl;
+        float v = acc[i][j][e];
+        float* dst = a.out + (size_t)orow * a.OCtot + oc;
+        if (a.atomic_out) {
+          if (a.slab) a.slab[(size_t)split * a.slab_stride + (size_t)orow * a.OCtot + oc] = v;
+          else atomicAdd(dst, v);
+        } else {
+          if (a.scale) v *= e_sc[j];
+          if (a.shift) v += e_sh[j];
+          if (a.res) {
+            if (a.res_mode == 0) {
+              v += a.res[(size_t)orow * a.OCtot + oc];
+            } else {
+              const int rh = (a.OH + 1) / 2, rw = (a.OW + 1) / 2;
+              v += a.res[((size_t)(n * rh + oh / 2) * rw + ow / 2) * a.OCtot + oc];
+            }
+          }
+          if (a.relu) v = fmaxf(v, 0.f);
+          if (a.mask) v = gate[e][j] > 0.f ? v : 0.f;
+          *dst = v;
+        }
+      }
+    }
+  }
+}
+
 // ---- 3x3 stride-1 convolution with the input patch staged ONCE per channel block (bf16x3 arithmetic) ----------
 // The generic kernel gathers (and splits, and stores to LDS) an A tile per tap: a 3x3 layer moves every input
 // element 9 x (K / BN) times through that path.  Here a workgroup owns an 8 x 16 patch of output pixels (128 GEMM
@@ -1888,6 +2182,17 @@ Plan plan_igemm(const IgemmArgs& a) {
 int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t s) {
   const int rows = a.M - a.m_base;
   if (g_conv_split && bn >= 64 && sp_eligible(a)) return launch_igemm_sp(a, bm, bn, s);
+  // one-LDS-stage variant (three workgroups per CU): pays once the grid holds three rounds' worth of workgroups per CU
+  // (256->256 1x1 on 200x336: 125 -> 109 us; 576x576x3x3 on 192 RoIs 209 -> 200 us), loses 5-10 % on grids that do not
+  // even fill two per CU (its workgroups are slower one by one).  CPM_IGEMM_S1: 0 off, 1 always (tests), 2 by grid size.
+  const int s1 = env_int("CPM_IGEMM_S1", 2);                  // read per call: the tests switch it
+  const int64_t s1_wgs = (int64_t)cpm::cdiv(rows, 128) * cpm::cdiv(a.OCg, 128) * a.groups * a.split_k;
+  if ((s1 == 1 || (s1 == 2 && s1_wgs >= 3ll * num_cus())) && vec && g_conv_split && bm == 128 && bn == 128 && wn == 2 &&
+      (a.atomic_out || !(a.res || a.staged_epi))) {
+    dim3 grid((unsigned)(cpm::cdiv(rows, 128) * cpm::cdiv(a.OCg, 128)), a.groups, a.split_k);
+    hipLaunchKernelGGL((igemm_s1_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+    return cpm::check_launch("conv igemm (one LDS stage)");
+  }
 #define LAUNCH(BM, BN, WM, WN)                                                                       \
   do {                                                                                               \
     dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);          \

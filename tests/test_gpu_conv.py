@@ -462,3 +462,43 @@ def test_mlp_chain_equals_layer_by_layer():
         _hip.set_deterministic(False)
         _hip.set_conv_math(prev_math)
         config.reset_cfg()
+
+
+@pytest.mark.parametrize("case", [(3, 256, 40, 56, 256, 1, 1, 0), (70, 576, 7, 7, 576, 3, 1, 1), (2, 256, 50, 84, 256, 3, 1, 1),
+                                  (1024, 1024, 1, 1, 1024, 1, 1, 0), (2, 512, 25, 42, 256, 3, 2, 1), (5, 132, 14, 14, 200, 3, 1, 1)],
+                         ids=["1x1", "roi7_576", "3x3_256", "fc", "stride2", "ragged"])
+def test_one_stage_igemm_equals_two_stage(case, monkeypatch):
+    """igemm_s1_kernel (one LDS stage, three workgroups per CU; taken by grid size, CPM_IGEMM_S1=1 forces it on every
+    eligible 128x128 launch) against igemm_kernel in the split-bf16 arithmetic: forward with bias + ReLU epilogue,
+    plain and gated data gradient (split-K slabs / atomics included) -- the same products in the same order per
+    output, so bit-identical where no float atomics are involved, and to the arithmetic's bound against torch-CPU."""
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as ops
+    N, C, H, W, K, R, st, pad = case
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    _hip.set_deterministic(True)                     # ordered split-K sums: the two kernels must then agree bitwise
+    try:
+        x = rnd(N, C, H, W, seed=21)
+        w = rnd(K, C, R, R, seed=22, scale=0.05)
+        b = rnd(K, seed=23)
+        yr = F.relu(F.conv2d(x, w, b, st, pad))
+        dy = rnd(*yr.shape, seed=24)
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, st, pad).backward(dy)
+        xd = x.cuda().contiguous(memory_format=CL)
+        wd = w.cuda().contiguous(memory_format=CL)
+        dyd = dy.cuda().contiguous(memory_format=CL)
+        bd = b.cuda()
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("CPM_IGEMM_S1", mode)
+            y = ops.conv2d_forward(xd, wd, None, bd, None, 0, True, st, pad, 1, 1)
+            dx = ops.conv2d_backward_data(dyd, wd, (N, C, H, W), st, pad, 1, 1)
+            got[mode] = (y, dx)
+        assert relerr(got["1"][0], yr) < TOL and relerr(got["1"][1], xr.grad) < TOL
+        assert torch.equal(got["1"][0], got["0"][0])
+        assert torch.equal(got["1"][1], got["0"][1])
+    finally:
+        _hip.set_deterministic(False)
+        _hip.set_conv_math(prev)
