@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-FAMILIES = [("igemm_kernel", r"igemm_kernel<"), ("igemm3x3_kernel", r"igemm3x3_kernel<"), ("igemm_sp_kernel", r"igemm_sp_kernel<"),
+FAMILIES = [("igemm_kernel", r"igemm(_s1)?_kernel<"), ("igemm3x3_kernel", r"igemm3x3_kernel<"), ("igemm_sp_kernel", r"igemm_sp_kernel<"),
             ("wgrad", r"wgrad_(split_)?kernel<"), ("wgrad_reduce_kernel", r"wgrad_reduce_kernel"),
             ("roi_align_fwd", r"roi_align_fwd"), ("roi_align_bwd_gather", r"roi_align_bwd_gather"),
             ("sgd_kernel", r"sgd_kernel")]
