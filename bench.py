@@ -116,7 +116,7 @@ def calibrate_frozen_affine(model, images):
 class Trainer(object):
     """The reference's loop body (tools/rcnn/train_net.py:62-78) over the HIP model."""
 
-    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3), body="resnet"):
+    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3), body="resnet", chunks=8):
         from pet.rcnn.core import config
         from pet.rcnn.modeling.model_builder import Generalized_RCNN
         from pet.utils.lr_scheduler import LearningRateScheduler
@@ -139,7 +139,7 @@ class Trainer(object):
         self.model.train()
         self.optimizer = Optimizer(self.model, self.cfg.SOLVER).build()
         self.scheduler = LearningRateScheduler(self.optimizer, self.cfg.SOLVER, start_iter=0)
-        self.reducer = FlatGradReducer(self.optimizer)
+        self.reducer = FlatGradReducer(self.optimizer, num_chunks=chunks)
         self.last_losses = None
 
     def step(self, images, targets):
@@ -381,6 +381,10 @@ def main():
     ap.add_argument("--no-full-rois", action="store_true", help="skip the worst-case-workload leg: 96 gt boxes per "
                     "image, which fill the 96-positives-per-image cap of every grid stage (>= 192 RoIs per stage at "
                     "bs=2, the RoI counts BASELINE.md's 6.3 TFLOP/step model assumes); reported as config.full_rois")
+    ap.add_argument("--no-other-bodies", action="store_true", help="skip the legs of the other BASELINE configs "
+                    "(R-101-FPN bs=2, X-101-64x4d-FPN-DCN bs=1; N=1 only; reported as config.other_bodies)")
+    ap.add_argument("--chunks", type=int, default=8, help="number of contiguous pieces the flat gradient is all-reduced "
+                    "in (pet/utils/parallel.py: default 8 x ~77 MB; sweep it on the 8-GPU node)")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
                     "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
@@ -404,10 +408,15 @@ def main():
     from pet.lib.ops import _hip
     _hip.set_conv_math(a.conv_math)
     layers = tuple(int(x) for x in a.layers.split(","))
-    trainer = Trainer(device, layers=layers, body=a.body)
+    trainer = Trainer(device, layers=layers, body=a.body, chunks=a.chunks)
     images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
     cal_img, _ = synthetic_batch(a.batch, a.height, a.width, 1, 4321, device)     # same on every rank
     calibrate_frozen_affine(trainer.model, cal_img.tensors)
+    if world > 1:
+        # rank 0's parameters, momentum and buffers everywhere (the seeds already agree; this is what a real run does
+        # and it makes the replicas identical by construction, not by seeding)
+        from pet.utils.parallel import broadcast_initial_state
+        broadcast_initial_state(trainer.model, trainer.optimizer, src=0)
 
     def sync():
         if world > 1:
@@ -520,6 +529,31 @@ def main():
         host_input = {"img_per_s": round(a.batch * k_h / el_h, 3), "ms_per_step": round(el_h / k_h * 1e3, 2),
                       "steps": k_h, "what": "per step: %d uint8 480x800 host images -> one pinned H2D copy -> "
                       "cpm_image_prep (resize to %dx%d, BGR, normalise, pad) -> training step" % (a.batch, oh, ow)}
+    other_bodies = None
+    if not a.no_other_bodies and world == 1 and a.body == "resnet" and layers == (3, 4, 6, 3):
+        # BASELINE configs #4 / #5 on one GPU, in the headline arithmetic: a fresh model each, 3 warm-up + 8 timed steps
+        other_bodies = {}
+        for name, kw, bs in (("R-101-FPN", dict(layers=(3, 4, 23, 3)), 2), ("X-101-64x4d-FPN-DCN", dict(body="x101dcn"), 1)):
+            tr2 = Trainer(device, chunks=a.chunks, **kw)
+            im2, tg2 = synthetic_batch(bs, a.height, a.width, 16, 1234, device)
+            cal2, _ = synthetic_batch(bs, a.height, a.width, 1, 4321, device)
+            calibrate_frozen_affine(tr2.model, cal2.tensors)
+            for _ in range(3):
+                tr2.step(im2, tg2)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                tr2.step(im2, tg2)
+            sync()
+            el2 = time.perf_counter() - t1
+            l2 = {k: float(v.detach()) for k, v in tr2.last_losses.items()}
+            other_bodies[name] = {"img_per_s": round(bs * 8 / el2, 3), "ms_per_step": round(1000.0 * el2 / 8, 2),
+                                  "batch": bs, "steps": 8, "warmup": 3,
+                                  "roi_counts_last_step": dict(tr2.model.Grid_Cascade_RCNN.last_counts),
+                                  "finite_loss": all(v == v and abs(v) != float("inf") for v in l2.values())}
+            del tr2, im2, tg2, cal2
+            torch.cuda.empty_cache()
+        _hip.set_conv_math(a.conv_math)
     hbm = None
     if not a.no_roofline and rank == 0:
         hbm = hbm_kernel_rooflines(device, a.batch, a.height, a.width, counts.get("cls", 512 * a.batch))
@@ -549,6 +583,8 @@ def main():
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        **({"host_input": host_input} if host_input else {}),
                        **({"full_rois": full_rois} if full_rois else {}),
+                       **({"other_bodies": other_bodies} if other_bodies else {}),
+                       "grad_allreduce_chunks": a.chunks,
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,

@@ -2419,7 +2419,7 @@ CPM_EXPORT int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, con
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(x && w && y, "null pointer");
   CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
-  CPM_REQUIRE(!y_sp || d->K % 4 == 0, "an SP output needs a multiple of 4 output channels");
+  CPM_REQUIRE(!y_sp || d->K % 32 == 0, "an SP output needs a multiple of 32 output channels");
   return conv_forward_impl(d, x, x_sp, w, w_sp, scale, shift, residual, res_mode, relu, y, y_sp, (hipStream_t)stream);
 }
 
@@ -2586,7 +2586,7 @@ CPM_EXPORT int cpm_conv2d_backward_data_sp(const cpm_conv_desc* d, const float* 
   CPM_REQUIRE(dy && wt && dx, "null pointer");
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
   CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
-  CPM_REQUIRE(!dx_sp || d->C % 4 == 0, "an SP output needs a multiple of 4 channels");
+  CPM_REQUIRE(!dx_sp || d->C % 32 == 0, "an SP output needs a multiple of 32 channels");
   return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, nullptr, 0, (hipStream_t)stream,
                    "cpm_conv2d_backward_data_sp", in_scale, in_act, true, dy_sp, wt_sp, dx_sp);
 }

@@ -1,24 +1,27 @@
-// Implicit-GEMM convolution over SPLIT-PLANE operands: 3-term split-bf16 arithmetic without any conversion in the loop.
+// Implicit-GEMM convolution over SPLIT-PLANE operands through an LDS-DMA ring: 3-term split-bf16 arithmetic with no
+// conversion, no register staging and no LDS stores in the loop.
 //
 // conv_igemm.hip splits every fp32 operand into hi = bf16(x), lo = bf16(x - hi) while it moves from registers to LDS:
-// per 128x128x32 k-step a wave issues ~200 VALU instructions and 16 LDS stores next to its 24 MFMAs, and with two
-// waves per SIMD those phases do not overlap (profiles/round1_kernel_stats.md: MFMA pipe ~30 % busy).  Here the
-// operands already LIE in memory as bf16 hi / lo planes -- written once by whoever produced them (the producing
-// convolution's epilogue, or cpm_split_planes) -- so a k-step is:
+// per 128x128x32 k-step a wave issues ~130 VALU instructions and 16 LDS stores next to its 24 MFMAs, the loads of only
+// two k-steps fit in registers, and a k-step ends up costing a wave ~2 900 cycles for 768 cycles of MFMA work
+// (DESIGN.md, round 2).  Here the operands already LIE in memory as bf16 hi / lo blocks -- written once by whoever
+// produced them (the producing kernel's epilogue, or cpm_split_planes) -- and a k-step of a wave is
 //
-//   8 x buffer_load_dwordx4 ... lds per wave   global -> LDS directly (no VGPRs, no VALU, no ds_write), masked gather
-//                                               lanes get an out-of-range offset and the DMA writes zeros
-//   16 x ds_read_b128 per wave                 conflict-free through an XOR swizzle applied on the SOURCE side (the
-//                                               DMA writes lane-linear: base + 16 * lane)
-//   24 x v_mfma_f32_32x32x16_bf16 per wave     a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulation
+//   DPW x buffer_load_dwordx4 ... lds       global -> LDS directly, S - 1 k-steps AHEAD of the one being multiplied (a ring
+//                                           of S stages; counted s_waitcnt vmcnt(N), never 0 inside the loop); masked gather
+//                                           lanes get an out-of-range offset and the DMA writes zeros
+//   4 (TM + TN) x ds_read_b128              conflict-free through an XOR swizzle applied on the SOURCE side (the DMA
+//                                           writes lane-linear: base + 16 * lane)
+//   6 TM TN x v_mfma_f32_32x32x16_bf16      a_lo*b_hi + a_hi*b_lo + a_hi*b_hi, fp32 accumulation
+//   one s_barrier
 //
-// Split-plane format ("SP") of a [rows][C] fp32 matrix (rows = pixels of an NHWC activation, or (oc, tap) rows of a
-// KRSC weight): [rows][2][C] bf16 -- per row C hi values, then C lo values: the same 4*C bytes as the fp32 row.
+// Split-plane format ("SP") of a [rows][C] fp32 matrix, C % 32 == 0 (rows = pixels of an NHWC activation, or (oc, tap)
+// rows of a KRSC weight): per row and per block of 32 channels 128 bytes = 32 bf16 hi values then 32 bf16 lo values --
+// the 4*C bytes of the fp32 row, and exactly one cache line per (row, k-step).
 //
-// Two LDS buffers of 4 planes (A_hi, A_lo, B_hi, B_lo; rows of 32 bf16 = 64 B); the DMA of k-step t+1 is issued
-// before the MFMAs of k-step t and is waited for (s_waitcnt vmcnt(0) + s_barrier) after them; two workgroups per CU.
-// Same gather description (IgemmArgs), tile order, split-K and fused epilogue as conv_igemm.hip; the epilogue can
-// write the result a second time as SP for the next convolution.
+// LDS stage: [BM + BN rows][128 B]; row r keeps source chunk c (16 B; c = 0..3 hi, 4..7 lo) in slot c ^ ((r >> 1) & 7):
+// the 16 lanes of a ds_read_b128 group then hit 16 distinct 16-byte bank groups for the 32x32x16 and the 16x16x32
+// operand maps alike.
 #include "common.h"
 #include "igemm_common.h"
 
@@ -30,30 +33,40 @@ constexpr unsigned OOB_V = 0x80000000u;      // voffset of a masked lane: beyond
 typedef __attribute__((address_space(3))) void* lds_void_p;
 
 // 16 bytes per lane, global -> LDS at (wave-uniform lds) + 16 * lane
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned* lds, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_p)lds, 16, (int)voff, (int)soff, 0, 0);
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned* lds, unsigned voff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void_p)lds, 16, (int)voff, 0, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm_sp_kernel(IgemmArgs a) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// PIPE: fragments of the next 16-deep half are read while the current half is multiplied, with the k-step's barrier
+// between the two halves (needs S >= 3; one stage less in flight than the plain order at the same S)
+template <int BM, int BN, int WM, int WN, int S, bool PIPE>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_ring_kernel(IgemmArgs a) {
   constexpr int NW = WM * WN, NT = 64 * NW;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
-  constexpr int AR = BM / NW, BR = BN / NW;          // rows a wave stages per plane
-  constexpr int AI = AR / 16, BI = BR / 16;          // DMA instructions per wave and plane (16 rows of 64 B each)
-  static_assert(AR % 16 == 0 && BR % 16 == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
-  constexpr int PA_HI = 0, PA_LO = BM * 16, PB_HI = 2 * BM * 16, PB_LO = 2 * BM * 16 + BN * 16;   // dwords in a stage
-  constexpr int STAGE = (2 * BM + 2 * BN) * 16;
+  constexpr int AR = BM / NW, BR = BN / NW;          // rows a wave stages
+  constexpr int AI = AR / 8, BI = BR / 8;            // DMA instructions per wave and stage (8 rows of 128 B each)
+  constexpr int DPW = AI + BI;
+  static_assert(AR % 8 == 0 && BR % 8 == 0 && WTM % 32 == 0 && WTN % 32 == 0, "tile shape");
+  static_assert(S >= (PIPE ? 3 : 2), "ring depth");
+  constexpr int ROWDW = 32;                          // dwords per LDS row
+  constexpr int OFF_B = BM * ROWDW;
+  constexpr int STAGE = (BM + BN) * ROWDW;           // dwords
   constexpr int CP = BN + 4;
   constexpr int CROWS = 32 * WM;                     // the epilogue stages one 32-row slab of every wave at a time
-  constexpr int LDS_DW = 2 * STAGE > CROWS * CP ? 2 * STAGE : CROWS * CP;
-  __shared__ __attribute__((aligned(16))) unsigned sm[LDS_DW];
+  constexpr int LDS_DW = S * STAGE > CROWS * CP ? S * STAGE : CROWS * CP;
+  __shared__ __attribute__((aligned(128))) unsigned sm[LDS_DW];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (a.OCg + BN - 1) / BN;
   int bid = blockIdx.x;
-  if (a.xcd_swizzle) {                                // see igemm_kernel: contiguous logical tiles per XCD
+  if (a.xcd_swizzle) {                                // contiguous logical tiles per XCD (see igemm_kernel)
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
@@ -61,15 +74,15 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
   const int g = blockIdx.y, split = blockIdx.z;
   const int m0 = a.m_base + tile_m * BM, n0 = tile_n * BN;
 
-  // ---- DMA geometry: lane -> (row, 16-byte slot); the slot holds source chunk slot ^ ((row >> 2) & 3) ----------
-  const int drow = lane >> 2, dslot = lane & 3;
+  // ---- DMA geometry: lane -> (row, 16-byte slot); the slot holds source chunk slot ^ ((row >> 1) & 7) ------------
+  const int drow = lane >> 3, dslot = lane & 7;
   const unsigned in_pitch = (unsigned)a.Ctot * 4u, w_pitch = (unsigned)a.CgR * 4u;       // bytes per SP row
   unsigned a_off[AI];
-  int a_h[AI], a_w[AI], a_cmax[AI];
+  int a_h[AI], a_w[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int row = wave * AR + i * 16 + drow;
-    const int chunk = dslot ^ ((row >> 2) & 3);
+    const int row = wave * AR + i * 8 + drow;
+    const int chunk = dslot ^ ((row >> 1) & 7);
     const int m = m0 + row;
     const bool ok = m < a.M;
     const int mm = ok ? m : 0;
@@ -77,24 +90,21 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     const int ii = t % a.OHp, n = t / a.OHp;
     a_h[i] = ok ? ii * a.ihmul + a.ihadd : -(1 << 28);
     a_w[i] = jj * a.iwmul + a.iwadd;
-    a_off[i] = (unsigned)((n * a.IH + (ok ? a_h[i] : 0)) * a.IW + a_w[i]) * in_pitch + (unsigned)(g * a.CgR + chunk * 8) * 2u;
-    a_cmax[i] = a.CgR - chunk * 8;                    // the chunk holds channels of this group while cb < a_cmax
-    asm volatile("" : "+v"(a_off[i]), "+v"(a_h[i]), "+v"(a_w[i]), "+v"(a_cmax[i]));
+    a_off[i] = (unsigned)((n * a.IH + (ok ? a_h[i] : 0)) * a.IW + a_w[i]) * in_pitch + (unsigned)(g * a.CgR) * 4u +
+               (unsigned)chunk * 16u;
+    asm volatile("" : "+v"(a_off[i]), "+v"(a_h[i]), "+v"(a_w[i]));
   }
   unsigned b_off[BI];
-  int b_cmax[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int row = wave * BR + i * 16 + drow;
-    const int chunk = dslot ^ ((row >> 2) & 3);
+    const int row = wave * BR + i * 8 + drow;
+    const int chunk = dslot ^ ((row >> 1) & 7);
     const int oc = n0 + row;
-    b_off[i] = oc < a.OCg ? (unsigned)((g * a.OCg + oc) * a.R * a.S) * w_pitch + (unsigned)(chunk * 8) * 2u : OOB_V;
-    b_cmax[i] = oc < a.OCg ? a.CgR - chunk * 8 : -(1 << 28);
-    asm volatile("" : "+v"(b_off[i]), "+v"(b_cmax[i]));
+    b_off[i] = oc < a.OCg ? (unsigned)((g * a.OCg + oc) * a.R * a.S) * w_pitch + (unsigned)chunk * 16u : OOB_V;
+    asm volatile("" : "+v"(b_off[i]));
   }
-  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc((const float*)a.in_sp, a.in_bytes),
-                               rs_wm = make_rsrc((const float*)a.wm_sp, a.wm_bytes);
-  const unsigned a_lo = (unsigned)a.Ctot * 2u, b_lo = (unsigned)a.CgR * 2u;   // lo plane of a row (scalar offset)
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc((const float*)a.in_sp, (a.dbg & 2) ? 0u : a.in_bytes),
+                               rs_wm = make_rsrc((const float*)a.wm_sp, (a.dbg & 2) ? 0u : a.wm_bytes);
 
   const int per = (a.ksteps + a.split_k - 1) / a.split_k;
   const int k_begin = split * per;
@@ -109,32 +119,28 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
     s_tr = tap / a.ns;
     s_ts = tap - s_tr * a.ns;
   }
-  auto stage_tile = [&](int buf) {
+  const int cb_end = a.ksteps_per_tap * BK;
+  auto stage_tile = [&](int buf, bool live) {          // live == false: every lane masked (the DMA count stays fixed)
+    if (a.dbg & 1) return;
     const int dh = s_tr * a.hstep, dw = s_ts * a.wstep;
-    const unsigned wtap = (unsigned)((a.r0 + s_tr * a.rstep) * a.S + a.s0 + s_ts * a.sstep) * w_pitch + (unsigned)s_cb * 2u;
-    const unsigned aoff = (unsigned)(dh * a.IW + dw) * in_pitch + (unsigned)s_cb * 2u;     // wraps for negative taps
+    const unsigned wtap = (unsigned)((a.r0 + s_tr * a.rstep) * a.S + a.s0 + s_ts * a.sstep) * w_pitch + (unsigned)s_cb * 4u;
+    const unsigned aoff = (unsigned)(dh * a.IW + dw) * in_pitch + (unsigned)s_cb * 4u;     // wraps for negative taps
     unsigned* const base = sm + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      const bool ok = (s_cb < a_cmax[i]) & ((unsigned)(a_h[i] + dh) < (unsigned)a.IH) &
-                      ((unsigned)(a_w[i] + dw) < (unsigned)a.IW);
-      const unsigned vo = ok ? a_off[i] + aoff : OOB_V;
-      unsigned* const dst = base + (wave * AR + i * 16) * 16;
-      dma16(rs_in, dst + PA_HI, vo, 0);
-      dma16(rs_in, dst + PA_LO, vo, a_lo);
+      const bool ok = live & ((unsigned)(a_h[i] + dh) < (unsigned)a.IH) & ((unsigned)(a_w[i] + dw) < (unsigned)a.IW);
+      dma16(rs_in, base + (wave * AR + i * 8) * ROWDW, ok ? a_off[i] + aoff : OOB_V);
     }
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const unsigned vo = s_cb < b_cmax[i] ? b_off[i] + wtap : OOB_V;
-      unsigned* const dst = base + (wave * BR + i * 16) * 16;
-      dma16(rs_wm, dst + PB_HI, vo, 0);
-      dma16(rs_wm, dst + PB_LO, vo, b_lo);
-    }
-    s_cb += BK;
-    if (s_cb >= a.ksteps_per_tap * BK) {
-      s_cb = 0;
-      if (++s_ts == a.ns) { s_ts = 0; ++s_tr; }
-    }
+    for (int i = 0; i < BI; ++i)
+      dma16(rs_wm, base + OFF_B + (wave * BR + i * 8) * ROWDW, live ? b_off[i] + wtap : OOB_V);
+    const int ncb = s_cb + BK;
+    const bool wrap_c = ncb >= cb_end;
+    const int nts = s_ts + (wrap_c ? 1 : 0);
+    const bool wrap_s = nts == a.ns;
+    s_cb = wrap_c ? 0 : ncb;
+    s_ts = wrap_s ? 0 : nts;
+    s_tr += wrap_s ? 1 : 0;
   };
 
   f32x16 acc[TM][TN];
@@ -145,23 +151,36 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // operand fetch: lane (frow, khalf) reads the 8 consecutive k = 16*sub + 8*khalf .. +7 of its row: chunk sub*2 + khalf
+  // of the hi block, + 4 for lo
   const int frow = lane & 31, khalf = lane >> 5;
+  const int f_sw = (frow >> 1) & 7;
   struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
   auto fetch = [&](int buf, int sub, Frag& f) {
-    const int r_sw = (((sub * 2 + khalf) ^ ((frow >> 2) & 3)) << 2);
+    if (a.dbg & 4) return;
+    const int ch = sub * 2 + khalf;
+    const int o_hi = frow * ROWDW + ((ch ^ f_sw) << 2), o_lo = frow * ROWDW + (((ch + 4) ^ f_sw) << 2);
     const unsigned* const base = sm + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int o = (wm * WTM + i * 32 + frow) * 16 + r_sw;
-      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + PA_HI + o));
-      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + PA_LO + o));
+      const int r = (wm * WTM + i * 32) * ROWDW;
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + r + o_hi));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + r + o_lo));
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      const int o = (wn * WTN + j * 32 + frow) * 16 + r_sw;
-      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + PB_HI + o));
-      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + PB_LO + o));
+      const int r = OFF_B + (wn * WTN + j * 32) * ROWDW;
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + r + o_hi));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(base + r + o_lo));
     }
+  };
+  auto seed_frag = [&](Frag& f) {                       // defined operands for the timing-only builds (dbg & 4)
+    const unsigned u = 0x3f803f80u ^ ((unsigned)lane * 0x00010001u);
+    const bf16x8 v = __builtin_bit_cast(bf16x8, make_uint4(u, u ^ 0x80008000u, u + 0x00010001u, u));
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { f.ah[i] = v; f.al[i] = v; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { f.bh[j] = v; f.bl[j] = v; }
   };
   auto mfma3 = [&](const Frag& f) {
 #pragma unroll
@@ -173,22 +192,50 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
       }
   };
-  auto step = [&](int it, int cur) {
-    if (it + 1 < nk) stage_tile(cur ^ 1);             // lands under this step's MFMAs
-    Frag f0, f1;
-    fetch(cur, 0, f0);
-    fetch(cur, 1, f1);
-    mfma3(f0);
-    mfma3(f1);
-    __syncthreads();                                  // s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
-  };
 
-  if (nk > 0) stage_tile(0);
-  __syncthreads();
-  for (int it = 0; it < nk; it += 2) {
-    step(it, 0);
-    if (it + 1 < nk) step(it + 1, 1);
+  // ---- the ring -------------------------------------------------------------------------------------------------------
+  // Stage t lives in buffer t % S.  Every wave issues exactly DPW DMAs per stage (dead stages past the end are fully
+  // masked), so "all but the youngest N of MY DMAs have landed" is a compile-time vmcnt; the barrier behind that wait
+  // makes it true for every wave's share of the stage, and it is also the point behind which nobody reads stage t - 1
+  // any more -- the buffer the next DMA refills.
+#pragma unroll
+  for (int s = 0; s < S - 1; ++s) stage_tile(s, s < nk);
+  int cur = 0, refill = S - 1;
+  if (!PIPE) {
+    for (int t = 0; t < nk; ++t) {
+      wait_vmcnt<(S - 2) * DPW>();
+      __builtin_amdgcn_s_barrier();
+      stage_tile(refill, t + S - 1 < nk);
+      Frag f0, f1;
+      if (a.dbg & 4) { seed_frag(f0); seed_frag(f1); }
+      fetch(cur, 0, f0);
+      fetch(cur, 1, f1);
+      mfma3(f0);
+      mfma3(f1);
+      refill = cur;
+      cur = cur + 1 == S ? 0 : cur + 1;
+    }
+  } else {
+    Frag fa, fb;
+    if (a.dbg & 4) { seed_frag(fa); seed_frag(fb); }
+    wait_vmcnt<(S - 2) * DPW>();
+    __builtin_amdgcn_s_barrier();
+    fetch(0, 0, fa);
+    for (int t = 0; t < nk; ++t) {
+      const int nxt = cur + 1 == S ? 0 : cur + 1;
+      fetch(cur, 1, fb);
+      mfma3(fa);
+      wait_vmcnt<(S - 3) * DPW>();                      // stage t + 1 (mine) has landed
+      __builtin_amdgcn_s_barrier();
+      stage_tile(refill, t + S - 1 < nk);
+      fetch(nxt, 0, fa);                                // (past the end: a dead stage's zeros, never multiplied)
+      mfma3(fb);
+      refill = cur;
+      cur = nxt;
+    }
   }
+  wait_vmcnt<0>();                                      // dead stages may still be landing in the ring the epilogue reuses
+  __syncthreads();
 
   // ---- epilogue ------------------------------------------------------------------------------------------
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
@@ -216,15 +263,14 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
       }
     return;
   }
-  // Stage the tile through LDS (free after the loop's last barrier), one 32-row slab of every wave at a time, and
-  // finish it row-wise with 16-byte accesses: residual / gate reads and the fp32 + SP stores are whole rows instead of
-  // 4-byte column slices.  Slab row wm * 32 + r is tile row wm * WTM + i * 32 + r.
+  // Stage the tile through LDS (free after the barrier above), one 32-row slab of every wave at a time, and finish it
+  // row-wise with 16-byte accesses: residual / gate reads and the fp32 + SP stores are whole rows instead of 4-byte
+  // column slices.  Slab row wm * 32 + r is tile row wm * WTM + i * 32 + r.
   float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(sm);
-  constexpr int CV = BN / 4, RPS = NT / CV;
-  static_assert(NT % CV == 0 && CROWS % RPS == 0, "epilogue layout");
+  constexpr int CV = BN / 4, RPS = NT / CV;        // (threads beyond RPS * CV idle: 192-wide tiles)
   const int cv = (tid % CV) * 4, r0 = tid / CV;
   const int ocl = n0 + cv;
-  const bool col_ok = ocl < a.OCg;
+  const bool col_ok = ocl < a.OCg && tid < RPS * CV;
   const bool vec_out = (a.OCg & 3) == 0 && (a.OCtot & 3) == 0 && ocl + 3 < a.OCg;
   const int oc = g * a.OCg + ocl;
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -237,6 +283,8 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         if (a.shift) shp[k] = a.shift[oc + k];
       }
   }
+  // SP position of channel oc in its row: block (oc >> 5) of 128 bytes, hi at 2 * (oc & 31), lo 64 bytes further
+  const size_t sp_col = (size_t)(oc >> 5) * 128 + (size_t)(oc & 31) * 2;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     if (i) __syncthreads();
@@ -281,9 +329,9 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
         if (a.out_sp) {
           uint2 hi, lo;
           split4(v, hi, lo);
-          char* const row = (char*)a.out_sp + (size_t)orow * a.OCtot * 4;
-          *(uint2*)(row + (size_t)oc * 2) = hi;
-          *(uint2*)(row + (size_t)(a.OCtot + oc) * 2) = lo;
+          char* const row = (char*)a.out_sp + (size_t)orow * a.OCtot * 4 + sp_col;
+          *(uint2*)row = hi;
+          *(uint2*)(row + 64) = lo;
         }
       } else {
         float* vp = &v.x;
@@ -293,10 +341,11 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
           if (a.mask) t = a.mask[o + k] > 0.f ? t : 0.f;
           a.out[o + k] = t;
           if (a.out_sp) {
-            __bf16* const row = (__bf16*)((char*)a.out_sp + (size_t)orow * a.OCtot * 4);
+            const int c = oc + k;
+            __bf16* const row = (__bf16*)((char*)a.out_sp + (size_t)orow * a.OCtot * 4 + (size_t)(c >> 5) * 128);
             const __bf16 h = (__bf16)t;
-            row[oc + k] = h;
-            row[a.OCtot + oc + k] = (__bf16)(t - (float)h);
+            row[c & 31] = h;
+            row[32 + (c & 31)] = (__bf16)(t - (float)h);
           }
         }
       }
@@ -304,17 +353,29 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2,
   }
 }
 
-// fp32 [rows][C] -> SP [rows][2][C]
-__global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restrict__ x, int64_t total4, int c4,
-                                                           uint2* __restrict__ sp) {
+// fp32 [rows][C] -> SP [rows][C / 32][hi 32 | lo 32]
+__global__ __launch_bounds__(256) void split_planes_kernel(const float4* __restrict__ x, int64_t total4, uint2* __restrict__ sp) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / c4;
-    const int c = (int)(i - row * c4);
     uint2 hi, lo;
     split4(x[i], hi, lo);
-    sp[row * 2 * c4 + c] = hi;
-    sp[(row * 2 + 1) * c4 + c] = lo;
+    // float4 i covers channels 4 * (i & 7) .. + 3 of 32-channel block i >> 3 (C % 32 == 0: blocks never straddle rows)
+    const int64_t blk = i >> 3;
+    const int q = (int)(i & 7);
+    sp[blk * 16 + q] = hi;
+    sp[blk * 16 + 8 + q] = lo;
   }
+}
+
+struct RingCfg { int bm, bn, waves, stages, pipe; };
+
+template <int BM, int BN, int WM, int WN, int S, bool PIPE>
+int launch_cfg(IgemmArgs a, hipStream_t s) {
+  static const int dbg = [] { const char* v = getenv("CPM_RING_DBG"); return v ? atoi(v) : 0; }();
+  a.dbg = dbg;
+  const int rows = a.M - a.m_base;
+  dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);
+  hipLaunchKernelGGL((igemm_ring_kernel<BM, BN, WM, WN, S, PIPE>), grid, dim3(64 * WM * WN), 0, s, a);
+  return cpm::check_launch("conv igemm (LDS-DMA ring)");
 }
 
 }  // namespace
@@ -323,39 +384,59 @@ namespace cpmconv {
 
 bool sp_eligible(const IgemmArgs& a) {
   static const int on = [] { const char* v = getenv("CPM_CONV_SP"); return v ? atoi(v) : 1; }();
-  return on && a.in_sp && a.wm_sp && (a.CgR % 8 == 0) && (a.Ctot % 8 == 0) && a.OCg > 32 &&
-         a.in_bytes < OOB_V && a.wm_bytes < OOB_V && (((uintptr_t)a.in_sp | (uintptr_t)a.wm_sp) & 15) == 0 &&
-         (!a.out_sp || ((a.OCtot & 3) == 0 && (a.OCg & 3) == 0 && ((uintptr_t)a.out_sp & 15) == 0));
+  return on && a.in_sp && a.wm_sp && (a.CgR % 32 == 0) && (a.Ctot % 32 == 0) && a.OCg > 32 &&
+         a.in_bytes < OOB_V && a.wm_bytes < OOB_V && (((uintptr_t)a.in_sp | (uintptr_t)a.wm_sp) & 127) == 0 &&
+         (!a.out_sp || ((a.OCtot & 31) == 0 && (a.OCg & 3) == 0 && ((uintptr_t)a.out_sp & 127) == 0));
 }
 
 int launch_igemm_sp(const IgemmArgs& a, int bm, int bn, hipStream_t s) {
-  const int rows = a.M - a.m_base;
-#define LAUNCH_SP(BM, BN, WM, WN)                                                             \
-  do {                                                                                        \
-    dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);   \
-    hipLaunchKernelGGL((igemm_sp_kernel<BM, BN, WM, WN>), grid, dim3(64 * WM * WN), 0, s, a); \
-  } while (0)
-  static const int big = [] { const char* v = getenv("CPM_SP_BIG"); return v ? atoi(v) : 0; }();
-  if (bm == 128 && bn == 128 && big == 1) LAUNCH_SP(256, 128, 4, 2);
-  else if (bm == 128 && bn == 128 && big == 2) LAUNCH_SP(256, 256, 2, 4);
-  else if (bm == 128 && bn == 128 && big == 3) LAUNCH_SP(256, 256, 4, 2);
-  else if (bm == 128 && bn == 128) LAUNCH_SP(128, 128, 2, 2);
-  else if (bm == 128 && bn == 64) LAUNCH_SP(128, 64, 2, 2);
-  else LAUNCH_SP(64, 64, 2, 2);
-#undef LAUNCH_SP
-  return cpm::check_launch("conv igemm (split planes)");
+  // CPM_RING_CFG="bm,bn,waves,stages,pipe" (experiments); otherwise by the planner's tile
+  RingCfg c = {bm, bn, 4, 4, 1};
+  if (bm == 128 && bn == 128) c = {128, 128, 8, 4, 1};
+  else if (bm == 128 && bn == 64) c = {128, 64, 4, 4, 1};
+  else c = {64, 64, 4, 4, 1};
+  if (const char* f = getenv("CPM_RING_CFG")) {
+    RingCfg e;
+    if (sscanf(f, "%d,%d,%d,%d,%d", &e.bm, &e.bn, &e.waves, &e.stages, &e.pipe) == 5) c = e;
+  }
+#define RCASE(BM, BN, WM, WN, S, P) \
+  if (c.bm == BM && c.bn == BN && c.waves == WM * WN && c.stages == S && c.pipe == P) return launch_cfg<BM, BN, WM, WN, S, P>(a, s)
+  RCASE(128, 128, 2, 4, 4, true);
+  RCASE(128, 128, 2, 4, 4, false);
+  RCASE(128, 128, 2, 4, 3, false);
+  RCASE(128, 128, 2, 2, 4, true);
+  RCASE(128, 128, 2, 2, 4, false);
+  RCASE(128, 128, 2, 2, 2, false);
+  RCASE(256, 128, 4, 2, 3, true);
+  RCASE(256, 128, 4, 2, 3, false);
+  RCASE(128, 192, 4, 2, 3, true);
+  RCASE(128, 192, 4, 2, 3, false);
+  RCASE(128, 192, 4, 2, 2, false);
+  RCASE(128, 192, 2, 2, 2, false);
+  RCASE(64, 192, 2, 2, 2, false);
+  RCASE(64, 192, 2, 2, 4, true);
+  RCASE(64, 192, 2, 2, 4, false);
+  RCASE(128, 64, 2, 2, 4, true);
+  RCASE(128, 64, 2, 2, 3, false);
+  RCASE(64, 64, 2, 2, 4, true);
+  RCASE(64, 64, 2, 2, 4, false);
+  RCASE(64, 64, 2, 2, 6, true);
+#undef RCASE
+  cpm::set_error("conv igemm (LDS-DMA ring): no kernel for tile %dx%d waves %d stages %d pipe %d", c.bm, c.bn, c.waves,
+                 c.stages, c.pipe);
+  return CPM_EINVAL;
 }
 
 }  // namespace cpmconv
 
 CPM_EXPORT int cpm_split_planes(const float* x, int64_t rows, int channels, void* sp, void* stream) {
-  CPM_REQUIRE(rows >= 0 && channels > 0 && channels % 4 == 0, "channels must be a positive multiple of 4");
+  CPM_REQUIRE(rows >= 0 && channels > 0 && channels % 32 == 0, "channels must be a positive multiple of 32");
   if (rows == 0) return CPM_OK;
   CPM_REQUIRE(x && sp, "null pointer");
   CPM_REQUIRE((((uintptr_t)x | (uintptr_t)sp) & 15) == 0, "pointers must be 16-byte aligned");
   const int64_t total4 = rows * (channels / 4);
   const int64_t b = (total4 + 255) / 256;
   hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)x, total4, channels / 4, (uint2*)sp);
+                     (const float4*)x, total4, (uint2*)sp);
   return cpm::check_launch("split_planes");
 }

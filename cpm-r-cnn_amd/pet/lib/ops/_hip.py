@@ -167,14 +167,32 @@ def f(x):
 
 
 _ws = {}
+_ws_retired = []        # buffers replaced while a non-compute stream may still use them (see workspace / release_retired)
 
 
 def workspace(nbytes, device):
-    """A grow-only scratch buffer per (device, stream); callers never hold it across ops."""
+    """A grow-only scratch buffer per (device, stream); callers never hold it across ops.
+
+    Under use_stream() the buffer belongs to the override (side) stream, but torch's caching allocator only knows the
+    compute stream it was allocated on: dropping it on growth would let the allocator hand the block straight back to
+    the compute stream while side-stream kernels already queued (weight-gradient slab planes in deterministic mode)
+    still use it.  A replaced side-stream buffer is therefore parked until release_retired() -- called once the compute
+    stream has been made to wait for the side stream (conv._join_side) -- and it grows geometrically so that a rising
+    RoI count parks O(log) buffers."""
     idx = device.index if device.index is not None else _cur_device()
     key = (idx, _override if _override is not None else _raw_stream(idx))
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        want = max(int(nbytes), 1 << 20)
+        if buf is not None and _override is not None:
+            _ws_retired.append(buf)
+            want = max(want, 2 * buf.numel())
+        buf = torch.empty(want, dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
+
+
+def release_retired():
+    """Drop the parked side-stream workspaces: only after the compute stream waits for everything the side stream has
+    been given (the join at the end of a backward pass)."""
+    del _ws_retired[:]

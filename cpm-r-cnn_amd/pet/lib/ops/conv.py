@@ -72,7 +72,7 @@ def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, di
     if y.numel() == 0:
         return y
     if x_sp is not None or w_sp is not None or want_sp:
-        y_sp = SP.empty_like(y) if (want_sp and k % 4 == 0) else None
+        y_sp = SP.empty_like(y) if (want_sp and k % 32 == 0) else None
         with H.guard(x.device):
             rc = H.lib().cpm_conv2d_forward_sp(H.ctypes.byref(d), H.ptr(x), H.ptr(x_sp), H.ptr(w), H.ptr(w_sp),
                                                H.ptr(scale), H.ptr(shift), H.ptr(residual), int(res_mode),
@@ -101,7 +101,7 @@ def conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, x_shape, w_shape, stride, pad,
         return dx
     if dy.numel() == 0:
         return dx if accumulate_into is not None else dx.zero_()
-    dx_sp = SP.empty_like(dx) if (want_sp and c % 4 == 0 and accumulate_into is None) else None
+    dx_sp = SP.empty_like(dx) if (want_sp and c % 32 == 0 and accumulate_into is None) else None
     with H.guard(dy.device):
         rc = H.lib().cpm_conv2d_backward_data_sp(H.ctypes.byref(d), H.ptr(dy), H.ptr(dy_sp), H.ptr(wt), H.ptr(wt_sp),
                                                  H.ptr(dx), H.ptr(dx_sp), 1 if accumulate_into is not None else 0,
@@ -300,6 +300,7 @@ def _join_side():
     for idx, main_raw in list(_side_armed.items()):
         H.fork(_side[idx][1], main_raw)
     _side_armed.clear()
+    H.release_retired()         # side-stream workspaces replaced during this pass: the join above orders their reuse
 
 
 def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):

@@ -1,8 +1,9 @@
 """Split-plane ("SP") operands of the split-bf16 conv arithmetic (include/cpmrcnn_hip.h: cpm_split_planes,
 cpm_conv2d_*_sp; kernel cpm-r-cnn_amd/csrc/conv_sp.hip).
 
-An SP twin of an fp32 tensor holds, per memory row of C channels (an NHWC pixel, a (k, r, s) row of a KRSC weight),
-C bf16 `hi = bf16(v)` values followed by C bf16 `lo = bf16(v - hi)` values -- the same 4*C bytes as the fp32 row.  It
+An SP twin of an fp32 tensor holds, per memory row of C channels (an NHWC pixel, a (k, r, s) row of a KRSC weight;
+C % 32 == 0) and per block of 32 channels, 32 bf16 `hi = bf16(v)` values followed by 32 bf16 `lo = bf16(v - hi)` values:
+128 bytes = one cache line per (row, 32-channel reduction step), the same 4*C bytes as the fp32 row.  It
 is carried as an int32 tensor of the fp32 tensor's shape and strides (opaque to torch: only the kernels read it) in the
 attribute `_cpm_sp` of the tensor it mirrors; producers that can write it for free (conv epilogues) attach it, consumers
 without one make it with one elementwise launch and cache it on the tensor for the other consumers (the weight
@@ -31,10 +32,11 @@ def _rows_channels(t):
 
 
 def split(t):
-    """A fresh SP twin of fp32 tensor `t` (one launch)."""
+    """A fresh SP twin of fp32 tensor `t` (one launch); None when its channel count is not a multiple of 32 (twins
+    are accelerators, never requirements: the convolutions then split in flight)."""
     rows, c = _rows_channels(t)
-    if c % 4:
-        raise RuntimeError("SP needs a multiple of 4 channels")
+    if c % 32:
+        return None
     sp = torch.empty_like(t, dtype=torch.int32)
     if t.numel():
         with H.guard(t.device):
@@ -54,7 +56,7 @@ def of(t, make=True):
         rows, c = _rows_channels(t)
     except RuntimeError:
         return None
-    if c % 8:
+    if c % 32:
         return None
     sp = split(t)
     attach(t, sp)

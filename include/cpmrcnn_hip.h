@@ -187,13 +187,14 @@ int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, c
 /* ---- split-plane ("SP") operands for the CPM_MATH_BF16X3 arithmetic ------------------------------------------------
  * The 3-term split-bf16 product needs hi = bf16(v), lo = bf16(v - hi) of every operand.  The plain entry points above
  * split fp32 operands inside the kernel, for every tile that reads them; the _sp entry points take the operands
- * ALREADY split, as bf16 planes in memory, and stage them by LDS-DMA (conv_sp.hip): same arithmetic, same results to
- * rounding of the accumulation order, no conversion work in the loop.
- *   SP of a [rows][C] fp32 matrix (rows = NHWC pixels, or (k, r, s) rows of a KRSC weight) = [rows][2][C] bf16: per
- *   row C hi values then C lo values -- 4*C bytes, like the fp32 row.  C % 4 == 0, 16-byte aligned.
+ * ALREADY split, as bf16 blocks in memory, and stage them by LDS-DMA through a ring of stages (conv_sp.hip): same
+ * arithmetic, same results to rounding of the accumulation order, no conversion work in the loop.
+ *   SP of a [rows][C] fp32 matrix (rows = NHWC pixels, or (k, r, s) rows of a KRSC weight) = [rows][C/32][2][32] bf16:
+ *   per row and 32-channel block 32 hi values then 32 lo values (128 bytes: one cache line per row and reduction
+ *   step) -- 4*C bytes, like the fp32 row.  C % 32 == 0, 128-byte aligned.
  * cpm_split_planes makes one; the convolutions can also emit their result in that form (y_sp / dx_sp, may be NULL)
  * for the convolution that consumes it.  The fp32 tensors stay the interface (x, w are still required): an operand
- * without an SP twin (x_sp / w_sp NULL), or a shape outside the DMA kernel's rules (C/groups % 8, K/groups > 32),
+ * without an SP twin (x_sp / w_sp NULL), or a shape outside the DMA kernel's rules (C/groups % 32, K/groups > 32),
  * takes the in-kernel split path.  Replaces the same ATen/cuDNN calls as cpm_conv2d_* (pet/lib/ops call sites above). */
 int cpm_split_planes(const float* x, int64_t rows, int channels, void* sp, void* stream);
 int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w, const void* w_sp,

@@ -713,6 +713,79 @@ def gen_cpm_train():
           % (meta["min_argmax_gap"], meta["max_heat_prob"]))
 
 
+def gen_rpn():
+    """Row a-3 as wholes: the REFERENCE RPNLossComputation.__call__ (rpn/loss.py:88-126) and
+    RPNPostProcessor.forward (rpn/inference.py:67-172, training mode: per-level top-k, decode, clip, NMS, post-NMS top-n,
+    the batch-wide top-k over all levels, gt append) on a 2-image batch over five FPN levels.  RPN.BATCH_SIZE_PER_IMAGE is
+    raised so far that the sampler keeps every valid anchor (no random draw; the cfg key is the reference's own), and
+    torchvision's nms -- absent here -- is the oracle's greedy NMS, which tests/test_oracle_golden.py pins to the
+    reference's compiled soft_nms.cpp ('hard' method).  Objectness and deltas are drawn directly (continuous: no score
+    ties); stored: both losses, their gradients w.r.t. every level's objectness / delta map, and the proposals."""
+    import oracle.pyoracle as O
+    import pet.lib.ops.nms as ref_nms_mod
+    import pet.utils.data.structures.boxlist_ops as ref_bl
+    from pet.rcnn.modeling.rpn.rpn import RPNModule
+    from pet.utils.data.structures.bounding_box import BoxList
+    from pet.utils.data.structures.image_list import ImageList
+
+    def oracle_nms(boxes, scores, thr):
+        return torch.from_numpy(O.nms(boxes.detach().numpy(), scores.detach().numpy(), float(thr))).long()
+    ref_nms_mod.nms = oracle_nms
+    ref_bl._box_nms = oracle_nms
+    cfg = _cpm_cfg()
+    cfg.RPN.BATCH_SIZE_PER_IMAGE = 1000000
+    cfg.RPN.PRE_NMS_TOP_N_TRAIN = 300
+    cfg.RPN.POST_NMS_TOP_N_TRAIN = 120
+    cfg.RPN.FPN_POST_NMS_TOP_N_TRAIN = 260
+    assert cfg.RPN.FPN_POST_NMS_PER_BATCH and cfg.RPN.MIN_SIZE == 0
+    H, W, N = 160, 224, 2
+    rng = np.random.default_rng(11)
+    torch.manual_seed(0)
+    rpn = RPNModule([256] * 5)
+    rpn.train()
+    A = rpn.anchor_generator.num_anchors_per_location()[0]
+    shapes = [((H + s - 1) // s, (W + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+    feats = [torch.zeros(N, 4, h, w) for h, w in shapes]
+    images = ImageList(torch.zeros(N, 3, H, W), [(H, W)] * N)
+    gts = [np.array([[12, 20, 96, 130], [100, 8, 215, 90], [60, 70, 180, 150], [150, 100, 200, 155], [5, 5, 40, 44]],
+                    np.float32),
+           np.array([[30, 30, 190, 140], [8, 90, 70, 156], [120, 12, 160, 60]], np.float32)]
+    targets = []
+    for g_ in gts:
+        t = BoxList(torch.from_numpy(g_.copy()), (W, H))
+        t.add_field("labels", torch.ones(len(g_), dtype=torch.int64))
+        targets.append(t)
+    obj = [torch.from_numpy(rng.normal(0, 2.0, (N, A, h, w)).astype(np.float32)).requires_grad_(True) for h, w in shapes]
+    reg = [torch.from_numpy(rng.normal(0, 0.4, (N, 4 * A, h, w)).astype(np.float32)).requires_grad_(True) for h, w in shapes]
+    anchors = rpn.anchor_generator(images, feats)
+    l_obj, l_box = rpn.loss_evaluator(anchors, obj, reg, targets)
+    (l_obj + l_box).backward()
+    with torch.no_grad():
+        props = rpn.box_selector_train(anchors, obj, reg, targets)
+    # how many anchors the loss looked at (the fixture is only meaningful with positives and negatives in both images)
+    lab, _ = rpn.loss_evaluator.prepare_targets([ref_bl.cat_boxlist(a) for a in anchors], targets)
+    out = {"H": H, "W": W, "loss_objectness": float(l_obj), "loss_rpn_box_reg": float(l_box),
+           "n_pos": [int((l == 1).sum()) for l in lab], "n_neg": [int((l == 0).sum()) for l in lab],
+           "pre_nms": 300, "post_nms": 120, "fpn_post_nms": 260}
+    arrs = {}
+    for i in range(5):
+        arrs["obj%d" % i] = obj[i].detach().numpy()
+        arrs["reg%d" % i] = reg[i].detach().numpy()
+        arrs["dobj%d" % i] = obj[i].grad.numpy()
+        arrs["dreg%d" % i] = reg[i].grad.numpy()
+    for n in range(N):
+        arrs["gt%d" % n] = gts[n]
+        arrs["prop_box%d" % n] = props[n].bbox.numpy()
+        arrs["prop_obj%d" % n] = props[n].get_field("objectness").numpy()
+    assert all(p > 0 for p in out["n_pos"]) and all(q > 0 for q in out["n_neg"]), out
+    # robustness margin of the fixture: the gap between the batch-wide top-k's last kept and first dropped score
+    np.savez_compressed(os.path.join(HERE, "rpn_whole.npz"), **arrs)
+    with open(os.path.join(HERE, "rpn_whole_meta.json"), "w") as f:
+        json.dump(out, f)
+    print("rpn:", out, [len(p) for p in props])
+
+
+
 def gen_soft_nms(ref_ext):
     """soft_nms_cpu of the reference (csrc/NMS/soft_nms.cpp compiled into oracle/_ref) on seeded box sets: all three
     methods, ties in the scores, heavy overlap (many removals), n = 0 / 1."""
@@ -858,6 +931,8 @@ def main():
         return gen_model_big()
     if sys.argv[1:] == ["cpm"]:
         return gen_cpm_train()
+    if sys.argv[1:] == ["rpn"]:
+        return gen_rpn()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
     cfg.DEVICE = "cpu"
     ops = {}

@@ -32,14 +32,15 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def test_split_planes_roundtrip():
-    """hi + lo reproduces the fp32 value to 2^-17 relative; layout [rows][2][C] bf16."""
+    """hi + lo reproduces the fp32 value to 2^-17 relative; layout [rows][C/32][2][32] bf16."""
     from pet.lib.ops import sp as SP
-    x = rnd(3, 40, 5, 7, seed=1).cuda().contiguous(memory_format=CL)
+    x = rnd(3, 96, 5, 7, seed=1).cuda().contiguous(memory_format=CL)
     x[0, 0, 0, 0] = 0.0
     sp = SP.split(x)
-    raw = sp.permute(0, 2, 3, 1).contiguous().view(torch.bfloat16).view(3, 5, 7, 2, 40).float()     # [N,H,W,2,C]
+    raw = sp.permute(0, 2, 3, 1).contiguous().view(torch.bfloat16).view(3, 5, 7, 3, 2, 32).float()  # [N,H,W,C/32,2,32]
     xs = x.permute(0, 2, 3, 1)
-    hi, lo = raw[..., 0, :], raw[..., 1, :]
+    hi, lo = raw[..., 0, :].reshape(3, 5, 7, 96), raw[..., 1, :].reshape(3, 5, 7, 96)
+    assert SP.split(rnd(2, 40, 3, 3).cuda().contiguous(memory_format=CL)) is None     # C % 32 != 0: no twin
     assert torch.equal(hi, xs.to(torch.bfloat16).float())
     assert torch.equal(lo, (xs - hi).to(torch.bfloat16).float())
     assert float(((hi + lo) - xs).abs().max() / xs.abs().max()) < 2.0 ** -16
@@ -89,7 +90,7 @@ def test_sp_forward_and_dgrad(case, epi):
     y_old = ops.conv2d_forward(xd, wd, cu(scale), cu(shift), cu(res), 0, relu, stride, pad, 1, groups)
     assert relerr(y, y_old) < 2e-5, "SP vs in-kernel split"
     # the SP twin written by the epilogue == the split of y
-    if K % 4 == 0:
+    if K % 32 == 0:
         assert torch.equal(y._cpm_sp, SP.split(y)), "epilogue SP output"
     # data gradient on the prepared weight image
     dy = rnd(N, K, P, Q, seed=6)
@@ -103,7 +104,7 @@ def test_sp_forward_and_dgrad(case, epi):
     dx = ops.conv2d_backward_data_sp(dyd, SP.split(dyd), wt2, wt_sp, (N, C, H, W), tuple(w.shape), stride, pad, 1,
                                      groups, want_sp=True)
     assert relerr(dx, xr.grad) < TOL, "dgrad"
-    if C % 4 == 0 and getattr(dx, "_cpm_sp", None) is not None:
+    if C % 32 == 0 and getattr(dx, "_cpm_sp", None) is not None:
         assert torch.equal(dx._cpm_sp, SP.split(dx)), "dgrad SP output"
     # accumulate: dx += ...
     acc = dx.clone()
@@ -122,4 +123,4 @@ def test_sp_missing_twin_falls_back_to_in_kernel_split():
     y = ops.conv2d_forward(xd, wd, None, None, None, 0, False, 1, 1, 1, 1, x_sp=SP.split(xd), w_sp=SP.split(wd),
                            want_sp=True)
     assert relerr(y, F.conv2d(x, w, None, 1, 1)) < TOL
-    assert torch.equal(y._cpm_sp, SP.split(y))
+    assert getattr(y, "_cpm_sp", None) is None
