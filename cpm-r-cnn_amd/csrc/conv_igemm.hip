@@ -1158,8 +1158,10 @@ __global__ void __launch_bounds__(256) seed_rows_kernel(float* __restrict__ out,
 // Per (group, tap) this is a Kg x Cg transpose.  32x32 tiles through LDS: the reads run along c and the writes along
 // k, both as contiguous 128-byte rows (a thread-per-destination-element version reads with a stride of R*S*Cg floats
 // and ran at a fraction of the copy rate on the 12-29 M element FC weights).
+// k_scale ([groups*Kg] or null): the image of diag(k_scale) * W -- a frozen per-output-channel factor behind the conv
+// (AffineChannel2d) is then applied by the data gradient's reduction itself: dx = W^T (scale * g).
 __global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__ w, int groups, int Kg, int RS, int Cg,
-                                                       float* __restrict__ wt) {
+                                                       float* __restrict__ wt, const float* __restrict__ k_scale) {
   __shared__ float tile[32][33];
   const int tiles_c = (Cg + 31) / 32, tiles_k = (Kg + 31) / 32;
   const int64_t per_gt = (int64_t)tiles_c * tiles_k;
@@ -1175,7 +1177,9 @@ __global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
       const int k = k0 + ty + j, c = c0 + tx;
-      tile[ty + j][tx] = (k < Kg && c < Cg) ? w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c] : 0.f;
+      float v = (k < Kg && c < Cg) ? w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c] : 0.f;
+      if (k_scale && k < Kg) v *= k_scale[g * Kg + k];
+      tile[ty + j][tx] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -1215,7 +1219,9 @@ __global__ __launch_bounds__(256) void weights_to_dgrad_batched(const cpm_wt_des
 #pragma unroll
     for (int j = 0; j < 32; j += 8) {
       const int k = k0 + ty + j, c = c0 + tx;
-      tile[ty + j][tx] = (k < Kg && c < Cg) ? w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c] : 0.f;
+      float v = (k < Kg && c < Cg) ? w[(((int64_t)(g * Kg + k)) * RS + t) * Cg + c] : 0.f;
+      if (d.k_scale && k < Kg) v *= d.k_scale[g * Kg + k];
+      tile[ty + j][tx] = v;
     }
     __syncthreads();
 #pragma unroll
@@ -1249,6 +1255,8 @@ struct WgradArgs {
   size_t slab_stride;   // floats per plane
   float* dshift;    // [OCtot] or null: += sum over pixels of dy (the bias gradient), folded into the dy reads of the
                     // workgroups that own tap 0 / input-channel tile 0 (every dy element passes exactly one of them)
+  const float* row_scale;   // [OCtot] or null: dw[oc] += row_scale[oc] * (the sums) -- the frozen per-channel factor
+                    // behind the conv (y = conv * scale + shift): dy arrives as the gradient at y, dw = scale * (dy^T x)
 };
 
 template <int BM, int BN, int WM, int WN, bool VEC>
@@ -1434,9 +1442,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         const int ocl = oc0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
         if (ocl >= a.OCg) continue;
         const size_t o = ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl;
-        if (a.slab) a.slab[(size_t)split * a.slab_stride + o] = acc[i][j][e];      // this split's plane
-        else if (a.split_k == 1) a.dw[o] += acc[i][j][e];                           // the element's only writer
-        else atomicAdd(a.dw + o, acc[i][j][e]);
+        const float v = a.row_scale ? acc[i][j][e] * a.row_scale[g * a.OCg + ocl] : acc[i][j][e];
+        if (a.slab) a.slab[(size_t)split * a.slab_stride + o] = v;                  // this split's plane
+        else if (a.split_k == 1) a.dw[o] += v;                                      // the element's only writer
+        else atomicAdd(a.dw + o, v);
       }
   }
 }
@@ -1726,6 +1735,7 @@ __global__ __launch_bounds__(256)
       if (ocl >= a.OCg || cl >= a.Cg) continue;
       float* p = base + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl;
       float4 v = *(const float4*)&Cs[row][col];
+      if (a.row_scale) { const float rs = a.row_scale[g * a.OCg + ocl]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
       if (cl + 3 < a.Cg) {                                   // Cg % 4 == 0 on this kernel (wvec)
         if (!a.slab) { const float4 o = *(const float4*)p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *(float4*)p = v;
@@ -1737,7 +1747,8 @@ __global__ __launch_bounds__(256)
     const int row = idx / BN, col = idx - row * BN;
     const int ocl = oc0 + row, cl = c0 + col;
     if (ocl < a.OCg && cl < a.Cg)
-      atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl, Cs[row][col]);
+      atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * a.R * a.S + tap) * a.Cg + cl,
+                a.row_scale ? Cs[row][col] * a.row_scale[g * a.OCg + ocl] : Cs[row][col]);
   }
 }
 
@@ -2427,7 +2438,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
                      const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr,
                      bool prepared = false, const void* dy_sp = nullptr, const void* wt_sp = nullptr,
-                     void* dx_sp = nullptr) {
+                     void* dx_sp = nullptr, const float* k_scale = nullptr) {
   const size_t need = dgrad_weight_bytes(d);
   if (!prepared && (!workspace || workspace_bytes < need)) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
@@ -2439,7 +2450,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   if (!prepared) {
     const int64_t b = (int64_t)cpm::cdiv(Cg, 32) * cpm::cdiv(Kg, 32) * d->R * d->S * d->groups;
     hipLaunchKernelGGL(weight_to_dgrad, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, s, w, d->groups, Kg,
-                       d->R * d->S, Cg, (float*)workspace);
+                       d->R * d->S, Cg, (float*)workspace, k_scale);
   }
   IgemmArgs a = {};
   if (prepared) { a.in_sp = dy_sp; a.wm_sp = wt_sp; }     // wt_sp: the SP form of the prepared [g][c][tap][k] image
@@ -2568,13 +2579,25 @@ CPM_EXPORT int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const floa
                    "cpm_conv2d_backward_data_gated", in_scale, in_act);
 }
 
+CPM_EXPORT int cpm_conv2d_backward_data_fused(const cpm_conv_desc* d, const float* dy, const float* w,
+                                              const float* k_scale, float* dx, int accumulate, const float* in_scale,
+                                              const float* in_act, void* workspace, size_t workspace_bytes,
+                                              void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(dy && w && dx, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
+  CPM_REQUIRE(!(accumulate && in_scale), "an accumulated data gradient takes a gate only: dx = (dx + W^T dy) * [act > 0]");
+  return run_dgrad(d, dy, w, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
+                   "cpm_conv2d_backward_data_fused", in_scale, in_act, false, nullptr, nullptr, nullptr, k_scale);
+}
+
 CPM_EXPORT int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
                                                  int accumulate, const float* in_scale, const float* in_act,
                                                  void* workspace, size_t workspace_bytes, void* stream) {
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(dy && wt && dx, "null pointer");
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
-  CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
+  CPM_REQUIRE(!(accumulate && in_scale), "an accumulated data gradient takes a gate only: dx = (dx + W^T dy) * [act > 0]");
   return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
                    "cpm_conv2d_backward_data_prepared", in_scale, in_act, true);
 }
@@ -2682,7 +2705,7 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   // it wins on in isolation, 2 = every eligible layer (tests).
   const int row3 = env_int("CPM_WGRAD_ROW3", 0);              // read per call: the tests switch it
   const bool row3_pays = row3 == 2 || (int64_t)a.M >= 65536;
-  if (row3 && row3_pays && p.bf16 && p.bm == 128 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
+  if (row3 && row3_pays && !a.row_scale && p.bf16 && p.bm == 128 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
       a.OH == a.IH && a.OW == a.IW && a.Cg >= 64 && a.x_bytes < 0x80000000u && a.dy_bytes < 0x80000000u) {
     p.row3 = true;
     const int OWp = (a.OW + 3) & ~3;
@@ -2718,8 +2741,15 @@ static size_t wgrad_slab_bytes(const cpm_conv_desc* d) {
 }
 
 static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                     void* workspace, size_t workspace_bytes, hipStream_t s, const float* row_scale);
+static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
                      void* workspace, size_t workspace_bytes, hipStream_t s) {
+  return run_wgrad(d, x, dy, dw, dbias, workspace, workspace_bytes, s, nullptr);
+}
+static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias,
+                     void* workspace, size_t workspace_bytes, hipStream_t s, const float* row_scale) {
   WgradArgs a = wgrad_args(d, x, dy, dw, dbias);
+  a.row_scale = row_scale;
   const int taps = d->R * d->S;
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
@@ -2729,6 +2759,10 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   a.xcd_swizzle = wxcd;
   ProfScope prof_scope(s, 2);
   if (a.Cg == 1 && taps <= 16) {
+    if (row_scale) {
+      cpm::set_error("cpm_conv2d_backward_weight_scaled: one input channel per group is not covered");
+      return CPM_EINVAL;
+    }
     if (dbias) {
       cpm::set_error("cpm_conv2d_backward_weight_bias: one input channel per group is not covered, use cpm_epilogue_backward");
       return CPM_EINVAL;
@@ -2827,6 +2861,14 @@ CPM_EXPORT int cpm_conv2d_backward_weight_bias(const cpm_conv_desc* d, const flo
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(x && dy && dw && dbias, "null pointer");
   return run_wgrad(d, x, dy, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+CPM_EXPORT int cpm_conv2d_backward_weight_scaled(const cpm_conv_desc* d, const float* x, const float* dy,
+                                                 const float* k_scale, float* dw, float* dbias, void* workspace,
+                                                 size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && dy && dw, "null pointer");
+  return run_wgrad(d, x, dy, dw, dbias, workspace, workspace_bytes, (hipStream_t)stream, k_scale);
 }
 
 // ---- profiling hooks (bench.py roofline leg) -----------------------------------------------------------

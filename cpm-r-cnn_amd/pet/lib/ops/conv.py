@@ -115,33 +115,40 @@ def conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, x_shape, w_shape, stride, pad,
 _WT_CACHE = os.environ.get("CPM_DGRAD_WT_CACHE", "1") != "0"
 
 
-def _prepared_wt(wparam, groups, kg, rs, cg):
+def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
     """The data-gradient image of a weight owned by the flat optimizer, made for ALL such weights in one launch after
     every optimizer step (pet/utils/optimizer.py: FlatSGD._refresh_dgrad_weights) -- or None (transform per call):
     first use (this call registers the weight with its convolution geometry), foreign weights, or a weight modified
-    since the last refresh (`_version` moved: load_state_dict, manual edits)."""
+    since the last refresh (`_version` moved: load_state_dict, manual edits).  k_scale: the frozen per-output-channel
+    factor behind the conv; the image is that of diag(k_scale) * W (cpm_conv2d_backward_data_fused)."""
     if wparam is None or not _WT_CACHE:
         return None
     wparam = getattr(wparam, "_cpm_owner", wparam)      # a Linear's per-call [K,C,1,1] view stands for its parameter
-    key = (groups, kg, rs, cg)
+    key = (groups, kg, rs, cg, 0 if k_scale is None else k_scale.data_ptr())
     reg = getattr(wparam, "_cpm_wt_desc", None)
     if reg is None:
         if getattr(wparam, "_cpm_grad_sink", None) is not None:
             wparam._cpm_wt_desc = key
+            wparam._cpm_wt_scale = k_scale
         return None
     wt = getattr(wparam, "_cpm_wt", None)
     if wt is None or reg != key or wparam._cpm_wt_version != wparam._version:
         return None
+    if k_scale is not None and getattr(wparam, "_cpm_wt_scale_version", None) != k_scale._version:
+        return None
     return wt
 
 
-def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_into=None, wparam=None):
-    """dx = conv^T(dy, w); with `accumulate_into` (an NHWC tensor of x's shape) the result is ADDED to it instead.
-    `wparam`: the parameter `w` is (a view of), for the once-per-step weight image (_prepared_wt)."""
+def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_into=None, wparam=None, k_scale=None,
+                         gate=None):
+    """dx = conv^T(k_scale * dy, w); with `accumulate_into` (an NHWC tensor of x's shape) the result is ADDED to it
+    instead, and with `gate` (the conv's input x = relu(..)) the running sum is masked: acc = (acc + dx) * [gate > 0].
+    `wparam`: the parameter `w` is (a view of), for the once-per-step weight image (_prepared_wt).
+    k_scale [K]: the frozen per-channel factor behind the conv (dy is the gradient at conv * k_scale + shift)."""
     n, c, h, wd = x_shape
     k, _, r, s = w.shape
     full_window = (r, s) == (h, wd) and pad == 0 and stride == 1 and dil == 1 and groups == 1 and (r > 1 or s > 1)
-    wt = None if full_window else _prepared_wt(wparam, groups, k // groups, r * s, c // groups)
+    wt = None if full_window else _prepared_wt(wparam, groups, k // groups, r * s, c // groups, k_scale)
     if accumulate_into is not None:
         acc = accumulate_into
         assert tuple(acc.shape) == tuple(x_shape) and acc.is_contiguous(memory_format=CL)
@@ -152,19 +159,22 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
             ws = _ws(d, dy.device)
             if wt is not None:
                 rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(acc), 1,
-                                                               None, None, H.ptr(ws), H.c_size_t(ws.numel()),
+                                                               None, H.ptr(gate), H.ptr(ws), H.c_size_t(ws.numel()),
                                                                H.stream())
             else:
-                rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(acc), 1,
-                                                      H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+                rc = H.lib().cpm_conv2d_backward_data_fused(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(k_scale),
+                                                            H.ptr(acc), 1, None, H.ptr(gate), H.ptr(ws),
+                                                            H.c_size_t(ws.numel()), H.stream())
         H.check(rc, "conv2d_backward_data(accumulate)")
         return acc
+    assert gate is None, "a gated data gradient without accumulation: conv2d_backward_data_gated"
     if full_window:
         # full-window conv (an FC over a flattened NHWC map): every input pixel sees exactly one tap, so the data
         # gradient is the plain GEMM dy[N,K] x W[K, R*S*C] -- run it as a 1x1 problem over R*S*C "channels"
         # (the KRSC weight bytes are already that matrix) instead of 49 taps of which 48 are masked per row
         w2 = w.permute(0, 2, 3, 1).reshape(k, r * s * c, 1, 1)
-        dx2 = conv2d_backward_data(dy.reshape(n, k, 1, 1), w2, (n, r * s * c, 1, 1), 1, 0, 1, 1, wparam=wparam)
+        dx2 = conv2d_backward_data(dy.reshape(n, k, 1, 1), w2, (n, r * s * c, 1, 1), 1, 0, 1, 1, wparam=wparam,
+                                   k_scale=k_scale)
         return dx2.view(n, r, s, c).permute(0, 3, 1, 2)
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     dx = empty_nhwc((n, c, h, wd), dy)
@@ -177,6 +187,10 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
         if wt is not None:
             rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0, None,
                                                            None, H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+        elif k_scale is not None:
+            rc = H.lib().cpm_conv2d_backward_data_fused(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(k_scale),
+                                                        H.ptr(dx), 0, None, None, H.ptr(ws), H.c_size_t(ws.numel()),
+                                                        H.stream())
         else:
             rc = H.lib().cpm_conv2d_backward_data(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx), 0, H.ptr(ws),
                                                   H.c_size_t(ws.numel()), H.stream())
@@ -184,11 +198,12 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
     return dx
 
 
-def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wparam=None):
-    """Data gradient with the producer's ReLU gate (x > 0) and frozen scale folded into the epilogue."""
+def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wparam=None, k_scale=None):
+    """Data gradient with the producer's ReLU gate (x > 0) (and an optional factor on dx) folded into the epilogue;
+    k_scale as in conv2d_backward_data."""
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
-    wt = _prepared_wt(wparam, groups, k // groups, r * s, c // groups)
+    wt = _prepared_wt(wparam, groups, k // groups, r * s, c // groups, k_scale)
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     dx = empty_nhwc((n, c, h, wd), dy)
     if dx.numel() == 0:
@@ -202,16 +217,17 @@ def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wpa
                                                            H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()),
                                                            H.stream())
         else:
-            rc = H.lib().cpm_conv2d_backward_data_gated(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(dx),
-                                                        H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()),
-                                                        H.stream())
+            rc = H.lib().cpm_conv2d_backward_data_fused(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(k_scale),
+                                                        H.ptr(dx), 0, H.ptr(in_scale), H.ptr(x), H.ptr(ws),
+                                                        H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_backward_data_gated")
     return dx
 
 
-def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None, dbias=None):
-    """dw (+)= x (*) dy.  `out` (same strides as the weight) is accumulated into when given.
-    dbias [K]: the bias gradient sum_m dy[m, k] is ADDED to it by the same launch (cpm_conv2d_backward_weight_bias)."""
+def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None, dbias=None, k_scale=None):
+    """dw (+)= k_scale * (x (*) dy).  `out` (same strides as the weight) is accumulated into when given.
+    dbias [K]: the bias gradient sum_m dy[m, k] is ADDED to it by the same launch (cpm_conv2d_backward_weight_bias).
+    k_scale [K]: the frozen per-channel factor behind the conv (dy is the gradient at conv * k_scale + shift)."""
     n, c, h, wd = x.shape
     k, _, r, s = w_like.shape
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
@@ -220,7 +236,11 @@ def conv2d_backward_weight(x, dy, w_like, stride, pad, dil, groups, out=None, db
         return dw
     ws = _ws(d, x.device)
     with H.guard(x.device):
-        if dbias is not None:
+        if k_scale is not None:
+            rc = H.lib().cpm_conv2d_backward_weight_scaled(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(k_scale),
+                                                           H.ptr(dw), H.ptr(dbias), H.ptr(ws), H.c_size_t(ws.numel()),
+                                                           H.stream())
+        elif dbias is not None:
             rc = H.lib().cpm_conv2d_backward_weight_bias(H.ctypes.byref(d), H.ptr(x), H.ptr(dy), H.ptr(dw),
                                                          H.ptr(dbias), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
         else:
@@ -303,7 +323,10 @@ def _join_side():
     H.release_retired()         # side-stream workspaces replaced during this pass: the join above orders their reuse
 
 
-def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):
+def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias, k_scale=None, want_event=False):
+    """The weight gradient on the second stream.  want_event: an event behind it on that stream -- `dy` is about to
+    be parked as a shared gradient accumulator that later consumers write IN PLACE on the compute stream; they wait
+    for this event first (_wait_readers)."""
     dev = x.device
     idx = dev.index
     st = _side.get(idx)
@@ -313,7 +336,11 @@ def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):
     main_raw = H._raw_stream(idx)                   # the stream this op's forward ran on (autograd made it current)
     H.fork(main_raw, st[1])                         # everything queued so far: dy, the gate pass
     with H.use_stream(st[1]):
-        conv2d_backward_weight(x, dy, w, stride, pad, dil, groups, out=out, dbias=dbias)
+        conv2d_backward_weight(x, dy, w, stride, pad, dil, groups, out=out, dbias=dbias, k_scale=k_scale)
+    ev = None
+    if want_event:
+        ev = torch.cuda.Event()
+        ev.record(st[0])
     # the caching allocator must not hand these blocks to the compute stream while the side stream still reads them
     x.record_stream(st[0])
     dy.record_stream(st[0])
@@ -321,6 +348,15 @@ def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias):
     # that died half-way must not leave a stale "already armed" mark behind that would skip the join of the next one
     _side_armed[idx] = main_raw
     torch.autograd.Variable._execution_engine.queue_callback(_join_side)
+    return ev
+
+
+def _wait_readers(h):
+    """before an in-place update of the shared accumulator h["acc"] on the compute stream: wait for the side-stream
+    weight gradient that still reads it (the tensor was that layer's own incoming gradient)"""
+    ev = h.pop("rd_event", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
 
 
 class _ConvFn(Function):
@@ -347,14 +383,17 @@ class _ConvFn(Function):
         ctx.wsrc = w_in if (w is w_in and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         ctx.bparam = _sink_of(shift, shift is not None and ctx.needs_input_grad[3])
         y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
-        # Epilogue-backward folded into the consumer: when the caller promises that y feeds exactly one consumer
-        # (bottleneck conv1 -> conv2 -> conv3) and y = relu(conv*scale + frozen shift), y carries a tag; a consuming
-        # _ConvFn gates its data gradient with (y > 0) * scale in the dgrad epilogue and flips `applied`, and this
-        # layer's backward then takes dy as the pre-activation gradient without a pass of its own.
+        # Epilogue-backward folded into the consumers.  y = relu(..) may carry a tag (conv2d: sole_consumer /
+        # gate_by_consumers): every consuming _ConvFn then masks its data gradient with (y > 0) in the kernel's epilogue
+        # -- the running sum of the shared accumulator when it adds to one: masking is linear and idempotent -- and
+        # records in the tag whether everything accumulated so far is masked.  This layer's backward then takes dy as
+        # the gradient at its pre-activation without a pass of its own.  Its own frozen scale needs no pass either: it
+        # is folded into the reductions (k_scale of the data- and weight-gradient kernels).
         ctx.in_tag = getattr(x_in, "_cpm_epi", None)
         ctx.out_tag = out_tag                       # the same dict is attached to y by conv2d() after apply()
         ctx.x_holder = getattr(x_in, "_cpm_gacc", None)
         ctx.res_holder = getattr(residual, "_cpm_gacc", None) if residual is not None else None
+        ctx.res_tag = getattr(residual, "_cpm_epi", None) if residual is not None else None
         ctx.cfg = (stride, pad, dil, groups, relu, res_mode, tuple(x.shape),
                    None if residual is None else tuple(residual.shape))
         ctx.has = (scale is not None, shift is not None, residual is not None)
@@ -369,40 +408,29 @@ class _ConvFn(Function):
         has_scale, has_shift, has_res = ctx.has
         need_x, need_w, _, need_shift, need_res = ctx.needs_input_grad[:5]
         dy = nhwc(dy)
-        # g = dy * [y > 0]  (gradient at the pre-activation sum);  dpre = g * scale;  dres = g;  dshift = sum g
-        masked = relu or has_scale
-        if ctx.out_tag is not None and ctx.out_tag["applied"]:
-            masked = False                              # the consumer's dgrad epilogue already applied gate and scale
+        # g = dy * [y > 0]: the gradient at the pre-activation sum v*scale + shift + res;  dres = g;  dshift = sum g;
+        # the conv itself sees scale * g, which the kernels form inside their reductions (k_scale)
+        k_scale = scale if has_scale else None
+        need_gate = relu and not (ctx.out_tag is not None and ctx.out_tag["applied"])
         want_shift = has_shift and need_shift
         want_res = has_res and need_res
-        dpre, g, dshift = dy, dy, None
-        # a bias gradient alone (no gate, no frozen scale to apply) rides on the weight-gradient kernel's dy reads
-        fuse_bias = (want_shift and not masked and need_w and groups == 1 and x_shape[1] > 1 and x.numel() > 0
+        g, dshift = dy, None
+        # a bias gradient alone (no gate to apply) rides on the weight-gradient kernel's dy reads
+        fuse_bias = (want_shift and not need_gate and need_w and groups == 1 and x_shape[1] > 1 and x.numel() > 0
                      and dy.numel() > 0)
-        if masked or (want_shift and not fuse_bias):
-            split_res = want_res and has_scale          # g and g*scale are both needed
+        if need_gate or (want_shift and not fuse_bias):
             bp = ctx.bparam if want_shift else None
-            dpre_k, dres_k, dshift = epilogue_backward(dy, y, scale, relu, want_dpre=masked, want_dres=split_res,
-                                                       want_dshift=want_shift,
-                                                       dshift_out=bp._cpm_grad_sink if bp is not None else None)
+            g_k, _, dshift = epilogue_backward(dy, y, None, need_gate, want_dpre=need_gate, want_dres=False,
+                                               want_dshift=want_shift,
+                                               dshift_out=bp._cpm_grad_sink if bp is not None else None)
             if bp is not None:
                 dshift = None                   # accumulated in place
                 _sink_done(bp)
-            if masked:
-                dpre = dpre_k
-                g = dres_k if split_res else (dpre_k if not has_scale else None)
-        gres = None
-        if want_res:
-            gres = g if res_mode == 0 else upsample2x_add_backward(g, res_shape)
-            h = ctx.res_holder
-            if h is not None:
-                if "acc" in h:
-                    h["acc"].add_(gres)
-                    gres = None
-                else:
-                    h["acc"] = gres
+            if need_gate:
+                g = g_k
         # the weight gradient first: forked onto the second stream it starts together with the data gradient below
         dw = None
+        rd_event = None
         if need_w:
             wp = ctx.wparam
             dbias = None
@@ -413,44 +441,81 @@ class _ConvFn(Function):
                 if bp is None:
                     dshift = dbias
             if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
-                if _SIDE_WGRAD and x.numel() and dpre.numel() and not (fuse_bias and ctx.bparam is None):
-                    _wgrad_on_side(x, dpre, w, stride, pad, dil, groups, wp._cpm_grad_sink, dbias)
+                if _SIDE_WGRAD and x.numel() and g.numel() and not (fuse_bias and ctx.bparam is None):
+                    # g itself becomes the residual branch's gradient below (no copy): whoever later updates it in
+                    # place on the compute stream must wait for this read
+                    rd_event = _wgrad_on_side(x, g, w, stride, pad, dil, groups, wp._cpm_grad_sink, dbias, k_scale,
+                                              want_event=want_res and res_mode == 0)
                 else:
-                    conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias)
+                    conv2d_backward_weight(x, g, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias,
+                                           k_scale=k_scale)
                 _sink_done(getattr(wp, "_cpm_owner", wp))
             else:
-                dw = conv2d_backward_weight(x, dpre, w, stride, pad, dil, groups, dbias=dbias)
+                dw = conv2d_backward_weight(x, g, w, stride, pad, dil, groups, dbias=dbias, k_scale=k_scale)
                 if wp is not None:                      # this use reaches the parameter through autograd's accumulation
                     own = getattr(wp, "_cpm_owner", wp)
                     own._cpm_uses -= 1
             if fuse_bias and ctx.bparam is not None:
                 _sink_done(ctx.bparam)                  # accumulated in place
+        gres = None
+        if want_res:
+            gres = g if res_mode == 0 else upsample2x_add_backward(g, res_shape)
+            if ctx.res_tag is not None:
+                ctx.res_tag["applied"] = False          # an unmasked contribution to the residual tensor's gradient
+            h = ctx.res_holder
+            if h is not None:
+                if "acc" in h:
+                    _wait_readers(h)
+                    h["acc"].add_(gres)
+                    gres = None
+                else:
+                    h["acc"] = gres
+                    if rd_event is not None:
+                        h["rd_event"] = rd_event
         dx = None
         if need_x:
             h = ctx.x_holder
+            tag = ctx.in_tag
+            full_window = (w.shape[2], w.shape[3]) == (x_shape[2], x_shape[3]) and (w.shape[2] > 1 or w.shape[3] > 1)
+            can_gate = tag is not None and dil == 1 and not full_window
+            # a producer outside _ConvFn (pet.lib.ops.deform_conv) may still ask its one consumer for its frozen scale
+            # too: tag["scale"], applied with the gate -- only possible without accumulation
+            legacy_scale = tag.get("scale") if tag is not None else None
             if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(x_shape):
-                conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, accumulate_into=h["acc"],
-                                     wparam=ctx.wsrc)
+                can_gate = can_gate and legacy_scale is None
+                _wait_readers(h)
+                conv2d_backward_data(g, w, x_shape, stride, pad, dil, groups, accumulate_into=h["acc"],
+                                     wparam=ctx.wsrc, k_scale=k_scale, gate=x if can_gate else None)
+                if tag is not None:
+                    if not can_gate:
+                        tag["applied"] = False
+                    elif stride == 1:
+                        tag["applied"] = True           # the whole running sum is masked now
+                    # stride > 1: masked where this conv reaches; what the tag said about the rest still holds
             else:
-                tag = ctx.in_tag
-                if tag is not None and not tag["applied"] and h is None and dil == 1 and \
-                        not ((w.shape[2], w.shape[3]) == (x_shape[2], x_shape[3]) and (w.shape[2] > 1 or w.shape[3] > 1)):
-                    dx = conv2d_backward_data_gated(dpre, w, x, tag["scale"], stride, pad, dil, groups, wparam=ctx.wsrc)
+                if can_gate:
+                    dx = conv2d_backward_data_gated(g, w, x, legacy_scale, stride, pad, dil, groups, wparam=ctx.wsrc,
+                                                    k_scale=k_scale)
                     tag["applied"] = True
                 else:
-                    dx = conv2d_backward_data(dpre, w, x_shape, stride, pad, dil, groups, wparam=ctx.wsrc)
+                    dx = conv2d_backward_data(g, w, x_shape, stride, pad, dil, groups, wparam=ctx.wsrc, k_scale=k_scale)
+                    if tag is not None:
+                        tag["applied"] = False
                 if h is not None:
                     h["acc"] = dx
         return dx, dw, None, dshift, gres, None, None, None, None, None, None, None
 
 
 def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, groups=1, relu=False, res_mode=0,
-           sole_consumer=False):
+           sole_consumer=False, gate_by_consumers=False):
+    """sole_consumer / gate_by_consumers: the caller promises that y = relu(..) is consumed ONLY by convolutions of
+    this package (conv2d / linear; as their input, or as the residual of one) -- they then apply y's ReLU gate inside
+    their data-gradient kernels (see _ConvFn.forward) and this layer's backward needs no elementwise pass.
+    sole_consumer: exactly one consumer (bottleneck conv1 -> conv2 -> conv3); gate_by_consumers: several (a bottleneck's
+    output: the next block's conv1, its downsample conv or residual add, an FPN lateral)."""
     tag = None
-    # (a trainable bias is fine: once the consumer has applied the gate, this layer's backward takes dy as the
-    # pre-activation gradient and the bias gradient rides on the weight-gradient launch)
-    if sole_consumer and relu and residual is None and torch.is_grad_enabled():
-        tag = {"scale": scale, "applied": False}
+    if relu and torch.is_grad_enabled() and ((sole_consumer and residual is None) or gate_by_consumers):
+        tag = {"applied": False}
     y = _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode, tag)
     if tag is not None:
         y._cpm_epi = tag

@@ -10,7 +10,8 @@ from . import conv as F
 
 
 class Conv2d(nn.Conv2d):
-    def forward(self, x, scale=None, shift=None, residual=None, relu=False, res_mode=0, sole_consumer=False):
+    def forward(self, x, scale=None, shift=None, residual=None, relu=False, res_mode=0, sole_consumer=False,
+                gate_by_consumers=False):
         assert self.padding[0] == self.padding[1] and self.stride[0] == self.stride[1] and self.padding_mode == "zeros"
         if shift is None:
             shift = self.bias
@@ -24,7 +25,7 @@ class Conv2d(nn.Conv2d):
             return cols_conv(x, None, self.weight, scale, shift, self.stride, self.padding, self.dilation,
                              self.groups, 1, relu, sole_consumer)
         return F.conv2d(x, self.weight, scale, shift, residual, self.stride[0], self.padding[0], self.dilation[0],
-                        self.groups, relu, res_mode, sole_consumer)
+                        self.groups, relu, res_mode, sole_consumer, gate_by_consumers)
 
 
 class Linear(nn.Linear):

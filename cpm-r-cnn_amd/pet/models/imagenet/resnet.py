@@ -37,6 +37,10 @@ class Bottleneck(nn.Module):
         self.bn3 = make_norm(planes * self.expansion, norm=norm.split("_")[-1])
         self.relu = nn.ReLU(inplace=True)
         self.downsample = downsample
+        # every consumer of this block's output is a convolution of pet.lib.ops (or the residual add of one): they apply
+        # its ReLU gate inside their data-gradient kernels (ops.conv2d: gate_by_consumers).  Set by whoever wires the
+        # blocks together (_make_layer: blocks inside a stage; the detection backbone: stage outputs under an FPN)
+        self.gate_out = False
 
     def forward(self, x):
         ops.mark_shared_grad(x)       # consumers: conv1, the downsample conv or conv3's residual -- all in-package
@@ -49,7 +53,7 @@ class Bottleneck(nn.Module):
             s, b = _affine(self.downsample[1])
             residual = self.downsample[0](x, scale=s, shift=b)
         s, b = _affine(self.bn3)
-        return self.conv3(out, scale=s, shift=b, residual=residual, relu=True)
+        return self.conv3(out, scale=s, shift=b, residual=residual, relu=True, gate_by_consumers=self.gate_out)
 
 
 class ResNet(nn.Module):
@@ -92,4 +96,6 @@ class ResNet(nn.Module):
         for _ in range(1, blocks):
             layers.append(block(self.inplanes, planes, self.base_width, 1, dilation, self.norm, conv, context,
                                 self.ctx_ratio, self.stride_3x3))
+        for blk in layers[:-1]:            # consumed by the next block's conv1 / residual add only
+            blk.gate_out = True
         return nn.Sequential(*layers)

@@ -46,6 +46,11 @@ class ResNeXt(resx.ResNeXt):
         self.dim_out = self.stage_out_dim[1:int(math.log(self.stride, 2))]
         self._init_weights()
         self._init_modules()
+        if cfg.MODEL.FPN_ON:
+            # C2..C5 are consumed by the next stage's first block and by the FPN laterals: convolutions of this package
+            # only, so the stage outputs' ReLU gates are applied by their consumers too (Bottleneck.gate_out)
+            for li in range(1, len(layers) + 1):
+                getattr(self, "layer%d" % li)[-1].gate_out = True
         self._stem_cache = None
 
     def _init_modules(self):

@@ -176,13 +176,15 @@ class FlatSGD(torch.optim.Optimizer):
             begins = self.seg_begin.tolist()
             rows, tiles = [], 0
             for p in params:
-                groups, kg, rs, cg = p._cpm_wt_desc
+                groups, kg, rs, cg, scale_ptr = p._cpm_wt_desc
                 off = begins[self._seg_index[id(p)]]
-                rows.append((off, off, groups, kg, rs, cg, tiles))
+                # scale_ptr: the frozen per-channel factor behind the conv (AffineChannel2d.weight: never reallocated),
+                # folded into the image (cpm_wt_desc.k_scale)
+                rows.append((off, off, groups, kg, rs, cg, tiles, scale_ptr))
                 tiles += ((cg + 31) // 32) * ((kg + 31) // 32) * rs * groups
             import numpy as np
             tab = np.zeros(len(rows), dtype=[("src", "<i8"), ("dst", "<i8"), ("g", "<i4"), ("kg", "<i4"), ("rs", "<i4"),
-                                             ("cg", "<i4"), ("t0", "<i8")])
+                                             ("cg", "<i4"), ("t0", "<i8"), ("scale", "<i8")])
             for i, r in enumerate(rows):
                 tab[i] = r
             self._wt_table = torch.from_numpy(tab.view(np.uint8).copy()).to(self.flat_param.device)
@@ -198,6 +200,9 @@ class FlatSGD(torch.optim.Optimizer):
         H.check(rc, "weights_to_dgrad_batched")
         for p in self._wt_params:
             p._cpm_wt_version = p._version
+            sc = getattr(p, "_cpm_wt_scale", None)
+            if sc is not None:
+                p._cpm_wt_scale_version = sc._version
 
 
 class Optimizer(object):

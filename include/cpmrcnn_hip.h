@@ -168,15 +168,33 @@ int cpm_conv2d_backward_weight_bias(const cpm_conv_desc* d, const float* x, cons
 int cpm_conv2d_backward_data_gated(const cpm_conv_desc* d, const float* dy, const float* w, float* dx,
                                    const float* in_scale, const float* in_act, void* workspace,
                                    size_t workspace_bytes, void* stream);
+/* The general fused form: the frozen per-output-channel factor BEHIND this conv (y = conv(x, w) * k_scale + shift,
+ * AffineChannel2d after a conv: pet/models/imagenet/resnet.py:114-136) is folded into the reduction -- dy is the
+ * gradient at y and dx = gate( [dx +] conv^T(k_scale * dy, w) ) -- so no elementwise pass forms k_scale * dy; and the
+ * gate of the layer that produced x may be combined with accumulation:
+ *   accumulate = 0:  dx = (in_act > 0) * in_scale * conv^T(..)          (in_scale / in_act may be NULL)
+ *   accumulate = 1:  dx = (in_act > 0) * (dx + conv^T(..))              (in_scale must be NULL)
+ * The second form is how a ReLU'd tensor with SEVERAL consuming convs (a bottleneck output: next block's conv1, the
+ * downsample conv, an FPN lateral) gets its gate applied by its consumers: masking is linear and idempotent, so every
+ * consumer masks the running sum.  k_scale [K] or NULL. */
+int cpm_conv2d_backward_data_fused(const cpm_conv_desc* d, const float* dy, const float* w, const float* k_scale,
+                                   float* dx, int accumulate, const float* in_scale, const float* in_act,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+/* Weight (+ bias) gradient with the same frozen factor: dw[k] += k_scale[k] * sum_m dy[m][k] x[..], dbias (may be NULL)
+ * += sum_m dy[m][k] (the shift sits behind the factor).  k_scale NULL: cpm_conv2d_backward_weight(_bias). */
+int cpm_conv2d_backward_weight_scaled(const cpm_conv_desc* d, const float* x, const float* dy, const float* k_scale,
+                                      float* dw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Data gradient with the weight ALREADY in the data-gradient image ([group][c][tap][k], what the calls above build
  * in their workspace on every call): `wt` comes from cpm_weights_to_dgrad_batched, which transforms all conv weights
  * of a flat parameter buffer in ONE launch per optimizer step (101 small launches per step otherwise).  in_scale /
- * in_act as in cpm_conv2d_backward_data_gated (both NULL: plain).  No workspace. */
+ * in_act as in cpm_conv2d_backward_data_gated (both NULL: plain); with accumulate = 1 an in_act gate masks the running
+ * sum as in cpm_conv2d_backward_data_fused (in_scale must then be NULL).  No workspace. */
 typedef struct {
   int64_t src_off, dst_off;   /* element offsets of the KRSC weight in src_base and of its image in dst_base */
   int32_t groups, Kg, RS, Cg; /* K/groups, R*S, C/groups of the convolution the weight belongs to */
   int64_t tile_start;         /* number of 32x32 tiles (ceil(Cg/32)*ceil(Kg/32)*RS*groups) of all earlier entries */
+  const float* k_scale;       /* [groups*Kg] or NULL: the image is that of diag(k_scale) * W (see _fused above) */
 } cpm_wt_desc;
 int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs /* DEVICE table, sorted by tile_start */, int n,
                                  int64_t total_tiles, const float* src_base, float* dst_base, void* stream);

@@ -274,6 +274,133 @@ def test_sole_consumer_chain_gated_dgrad(stride2):
     assert relerr(w2g.grad, w2r.grad) < TOL
 
 
+def _bottleneck_pair(xr, P, stride):
+    """two bottleneck blocks in torch: block A (identity residual) -> y, consumed by block B's conv1 (stride), B's
+    downsample conv (stride) and a lateral 1x1 conv (the FPN's); returns (y, sum of the three heads' outputs)"""
+    def aff(t, k):
+        return t * P["s" + k].view(1, -1, 1, 1) + P["b" + k].view(1, -1, 1, 1)
+    h = F.relu(aff(F.conv2d(xr, P["a1"]), "a1"))
+    h = F.relu(aff(F.conv2d(h, P["a2"], None, 1, 1), "a2"))
+    y = F.relu(aff(F.conv2d(h, P["a3"]), "a3") + xr)
+    c1 = F.relu(aff(F.conv2d(y, P["c1"], None, stride), "c1"))
+    ds = aff(F.conv2d(y, P["ds"], None, stride), "ds")
+    lat = F.conv2d(y, P["lat"], P["blat"])
+    return y, c1, ds, lat
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("side", ["1", "0"], ids=["wgrad_stream", "one_stream"])
+def test_block_output_gate_applied_by_its_consumers(stride, side, monkeypatch):
+    """A bottleneck output y = relu(conv3 * scale + shift + x) with gate_by_consumers: its three consumers (next conv1,
+    downsample conv, FPN lateral) mask the shared gradient accumulator in their data-gradient epilogues, conv3's frozen
+    scale is folded into its data- and weight-gradient reductions (k_scale), and NO cpm_epilogue_backward pass runs for
+    the block output.  All gradients vs torch-CPU; the accumulator the residual branch shares with conv3's
+    side-stream weight gradient is checked by running both stream modes."""
+    import pet.lib.ops as ops
+    from pet.lib.ops import conv as C
+    monkeypatch.setattr(C, "_SIDE_WGRAD", side == "1")
+    cl = torch.channels_last
+    Cc, Wd = 64, 32
+    shp = {"a1": (Wd, Cc, 1, 1), "a2": (Wd, Wd, 3, 3), "a3": (Cc, Wd, 1, 1), "c1": (48, Cc, 1, 1), "ds": (96, Cc, 1, 1),
+           "lat": (40, Cc, 1, 1)}
+    P = {}
+    for i, (k, v) in enumerate(shp.items()):
+        P[k] = rnd(*v, seed=20 + i, scale=1.0 / np.sqrt(v[1] * v[2] * v[3]))
+        if k != "lat":
+            P["s" + k] = rnd(v[0], seed=40 + i).abs() + 0.5
+            P["b" + k] = rnd(v[0], seed=60 + i) * 0.1
+    P["blat"] = rnd(40, seed=90) * 0.1
+    x = rnd(2, Cc, 14, 18, seed=1).abs()                           # a block input is itself a ReLU output
+    xr = x.clone().requires_grad_(True)
+    Pr = {k: v.clone().requires_grad_(not k.startswith(("s", "b")) or k == "blat") for k, v in P.items()}
+    y, c1, ds, lat = _bottleneck_pair(xr, Pr, stride)
+    go = [rnd(*t.shape, seed=100 + i) for i, t in enumerate((c1, ds, lat))]
+    (c1 * go[0]).sum().backward(retain_graph=True)
+    (ds * go[1]).sum().backward(retain_graph=True)
+    (lat * go[2]).sum().backward()
+    # the same on the device, wired like pet.models.imagenet.resnet.Bottleneck
+    G = {k: (v.cuda().contiguous(memory_format=cl) if v.dim() == 4 else v.cuda()) for k, v in P.items()}
+    for k in shp:
+        G[k].requires_grad_(True)
+    G["blat"].requires_grad_(True)
+    xg = x.cuda().contiguous(memory_format=cl).requires_grad_(True)
+    calls = {"n": 0}
+    real = C.epilogue_backward
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    monkeypatch.setattr(C, "epilogue_backward", counting)
+    ops.mark_shared_grad(xg)
+    h = ops.conv2d(xg, G["a1"], G["sa1"], G["ba1"], relu=True, sole_consumer=True)
+    h = ops.conv2d(h, G["a2"], G["sa2"], G["ba2"], pad=1, relu=True, sole_consumer=True)
+    yg = ops.conv2d(h, G["a3"], G["sa3"], G["ba3"], residual=xg, relu=True, gate_by_consumers=True)
+    assert yg._cpm_epi == {"applied": False}
+    ops.mark_shared_grad(yg)
+    c1g = ops.conv2d(yg, G["c1"], G["sc1"], G["bc1"], stride=stride, relu=True)
+    dsg = ops.conv2d(yg, G["ds"], G["sds"], G["bds"], stride=stride)
+    latg = ops.conv2d(yg, G["lat"], None, G["blat"])
+    for a, b in ((yg, y), (c1g, c1), (dsg, ds), (latg, lat)):
+        assert relerr(a, b) < TOL
+    loss = (c1g * go[0].cuda().contiguous(memory_format=cl)).sum() + (dsg * go[1].cuda().contiguous(memory_format=cl)).sum() \
+        + (latg * go[2].cuda().contiguous(memory_format=cl)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert yg._cpm_epi["applied"] is True
+    # one pass only: c1's own ReLU (its output has no tag); the block output and the sole-consumer chain need none
+    assert calls["n"] == 1, calls
+    tol = 5e-4          # a few pre-activations within rounding of 0 may gate differently
+    for k in list(shp) + ["blat"]:
+        assert relerr(G[k].grad, Pr[k].grad) < tol, k
+    assert relerr(xg.grad, xr.grad) < tol
+
+
+def test_fused_dgrad_and_scaled_wgrad_kernels():
+    """cpm_conv2d_backward_data_fused / cpm_conv2d_backward_weight_scaled against torch: k_scale inside the reductions,
+    accumulate + gate = (acc + dx) * [act > 0], with and without the reduction split (a thin grid forces split-K)."""
+    from pet.lib.ops import conv as C
+    cl = torch.channels_last
+    for (N, Cc, Hh, Ww, K, R, stride, pad) in [(2, 64, 15, 17, 96, 1, 1, 0), (1, 512, 6, 7, 64, 3, 1, 1),
+                                               (2, 64, 16, 18, 128, 1, 2, 0)]:
+        x = rnd(N, Cc, Hh, Ww, seed=1)
+        w = rnd(K, Cc, R, R, seed=2, scale=1.0 / np.sqrt(Cc * R * R))
+        ks = rnd(K, seed=3).abs() + 0.5
+        P, Q = C.out_size(Hh, R, stride, pad), C.out_size(Ww, R, stride, pad)
+        dy = rnd(N, K, P, Q, seed=4)
+        acc0 = rnd(N, Cc, Hh, Ww, seed=5)
+        act = rnd(N, Cc, Hh, Ww, seed=6)
+        dx_ref = F.conv_transpose2d(dy * ks.view(1, -1, 1, 1), w, None, stride, pad,
+                                    output_padding=(Hh - ((P - 1) * stride - 2 * pad + R), Ww - ((Q - 1) * stride - 2 * pad + R)))
+        xr = x.clone()
+        dw_ref = torch.nn.grad.conv2d_weight(xr, w.shape, dy * ks.view(1, -1, 1, 1), stride, pad)
+        dyd, wd = dy.cuda().contiguous(memory_format=cl), w.cuda().contiguous(memory_format=cl)
+        ksd = ks.cuda()
+        dx = C.conv2d_backward_data(dyd, wd, (N, Cc, Hh, Ww), stride, pad, 1, 1, k_scale=ksd)
+        assert relerr(dx, dx_ref) < TOL
+        actd = act.cuda().contiguous(memory_format=cl)
+        dxg = C.conv2d_backward_data_gated(dyd, wd, actd, None, stride, pad, 1, 1, k_scale=ksd)
+        assert relerr(dxg, dx_ref * (act > 0)) < TOL
+        accd = acc0.cuda().contiguous(memory_format=cl).clone()
+        C.conv2d_backward_data(dyd, wd, (N, Cc, Hh, Ww), stride, pad, 1, 1, accumulate_into=accd, k_scale=ksd, gate=actd)
+        want = (acc0 + dx_ref) * (act > 0)
+        if stride == 1:
+            assert relerr(accd, want) < TOL
+        else:       # a strided 1x1 reaches every stride-th pixel only: the gate is guaranteed where the conv writes
+            m = torch.zeros_like(act, dtype=torch.bool)
+            m[:, :, ::stride, ::stride] = True
+            got = accd.cpu()
+            assert relerr(torch.where(m, got, torch.zeros_like(got)), torch.where(m, want, torch.zeros_like(want))) < TOL
+            rest = torch.where(m, torch.zeros_like(got), got)
+            assert torch.equal(rest, torch.where(m, torch.zeros_like(got), acc0)) or \
+                torch.equal(rest, torch.where(m, torch.zeros_like(got), acc0 * (act > 0)))
+        dw = C.conv2d_backward_weight(x.cuda().contiguous(memory_format=cl), dyd, wd, stride, pad, 1, 1, k_scale=ksd)
+        assert relerr(dw, dw_ref) < TOL
+        db = torch.zeros(K, device="cuda")
+        dw2 = C.conv2d_backward_weight(x.cuda().contiguous(memory_format=cl), dyd, wd, stride, pad, 1, 1, dbias=db,
+                                       k_scale=ksd)
+        assert relerr(dw2, dw_ref) < TOL and relerr(db, dy.sum(dim=(0, 2, 3))) < TOL      # the bias sum is NOT scaled
+
+
 def test_error_bound_of_both_arithmetics_wide_dynamic_range(conv_math):
     """Error of a conv output against a float64 reference, measured against the natural scale sum|x||w| (so that
     cancellation cannot hide it), on inputs spanning 8 decades: the exact-f32 MFMA chain stays at fp32 rounding
