@@ -1752,229 +1752,6 @@ __global__ __launch_bounds__(256)
   }
 }
 
-// ---- weight gradient of a 3x3 / stride 1 / pad 1 layer, one FILTER ROW per workgroup ------------------------------
-// wgrad_split_kernel gives every tap its own workgroup: the nine workgroups of a (channel tile, pixel range) read the
-// same dy tile nine times and nine shifted copies of the same x tile (2.9x the algorithmic bytes over the step).  Here
-// a workgroup owns the three taps s = 0, 1, 2 of filter row r: the dy tile (128 output channels x 32 pixels) is
-// loaded, split and stored ONCE per chunk, and the x tile (64 input channels) is loaded once with a one-pixel halo on
-// either side -- a thread that owns pixels ow..ow+3 of a row fetches ow-1..ow+4 (6 loads instead of 3 x 4) and writes
-// the three shifted 4-pixel groups to three LDS images.  For the shifted groups to come from ONE row the pixel index
-// runs over rows padded to a multiple of 4 (a 7-wide RoI map is walked as 8 slots per row, the slot past the end
-// carries dy = 0): runs of 4 never straddle a row.  Three accumulator sets (96 registers), 36 MFMAs per chunk and wave
-// for 20 operand reads (24 for 16 before).  LDS: 2 buffers x (A hi/lo 16 KB + 3 x B hi/lo 8 KB) = 80 KB (dynamic).
-constexpr int R3_BM = 128, R3_BN = 64;
-constexpr int R3_BUF = (2 * R3_BM + 6 * R3_BN) * 16;            // dwords per LDS buffer
-constexpr int R3_LDS_BYTES = 2 * R3_BUF * 4;
-
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_row3_kernel(WgradArgs a) {
-  constexpr int BM = R3_BM, BN = R3_BN, WN = 2;
-  constexpr int WTM = 64, WTN = 32, TM = 2;                    // 2 x 2 waves, wave tile 64 x 32
-  constexpr int QA = BM / 4, QB = BN / 4;                      // 32 / 16 channel vectors
-  constexpr int CP = BN + 4;
-  static_assert(BM * CP * 4 <= R3_LDS_BYTES, "epilogue staging fits");
-  extern __shared__ __attribute__((aligned(16))) float smem_dyn[];
-  unsigned* const sm = reinterpret_cast<unsigned*>(smem_dyn);
-  constexpr int PA_HI = 0, PA_LO = BM * 16, PB0 = 2 * BM * 16;  // + s * 2 * BN * 16 (+ BN * 16 for the lo plane)
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  const int tiles_n = (a.Cg + BN - 1) / BN;
-  const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x % tiles_n;
-  const int r = blockIdx.y;                                    // filter row; taps r*3 + {0, 1, 2}
-  const int g = blockIdx.z / a.split_k, split = blockIdx.z % a.split_k;
-  const int oc0 = tile_m * BM, c0 = tile_n * BN;
-
-  const int OWp = (a.OW + 3) & ~3;                             // padded row length
-  const int Mp = a.N * a.OH * OWp;
-  const int chunks = (Mp + 31) >> 5;
-  const int per = (chunks + a.split_k - 1) / a.split_k;
-  const int ch_begin = split * per, ch_end = min(chunks, ch_begin + per);
-  const int nk = ch_end - ch_begin;
-
-  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
-
-  const int l16 = tid & 15, half_run = (tid >> 4) & 1, hi = tid >> 5;
-  const int qa = (hi % (QA / 16)) * 16 + l16, pra = (hi / (QA / 16)) * 2 + half_run;      // every thread: pra < 8
-  const int qb = l16, prb = hi * 2 + half_run;                                          // prb < 8 <=> tid < 128
-  const bool a_act = oc0 + 4 * qa < a.OCg;
-  const bool b_act = prb < 8 && c0 + 4 * qb < a.Cg;
-  const unsigned a_chan = (unsigned)(g * a.OCg + oc0 + 4 * qa) * 4u, a_pix = (unsigned)a.OCtot * 4u;
-  const unsigned b_chan = (unsigned)(g * a.Cg + c0 + 4 * qb) * 4u, b_pix = (unsigned)a.Ctot * 4u;
-
-  // (n, oh, first padded column) of the thread's A run and B run, stepped by 32 padded pixels per chunk
-  const int hw = a.OH * OWp;
-  const int dn = 32 / hw, rem = 32 % hw;
-  const int dh = rem / OWp, dwid = rem % OWp;
-  int an, aoh, aow, bn, boh, bow;
-  {
-    int m = ch_begin * 32 + 4 * pra;
-    aow = m % OWp; m /= OWp; aoh = m % a.OH; an = m / a.OH;
-    m = ch_begin * 32 + 4 * (prb & 7);
-    bow = m % OWp; m /= OWp; boh = m % a.OH; bn = m / a.OH;
-  }
-  auto advance = [&](int& n, int& oh, int& ow) {
-    n += dn; oh += dh; ow += dwid;
-    if (ow >= OWp) { ow -= OWp; ++oh; }
-    if (oh >= a.OH) { oh -= a.OH; ++n; }
-  };
-
-  float4 ra[4], rb[6];
-  auto load_chunk = [&]() {
-    const bool arow = a_act & (an < a.N);
-    const unsigned abase = (unsigned)(((an * a.OH + aoh) * a.OW + aow)) * a_pix + a_chan;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, (arow & (aow + i < a.OW)) ? abase + i * a_pix : OOB_OFF);
-    advance(an, aoh, aow);
-    const int ih = boh + r - 1;
-    const bool brow = b_act & (bn < a.N) & ((unsigned)ih < (unsigned)a.IH);
-    const unsigned bbase = (unsigned)(((bn * a.IH + ih) * a.IW + bow - 1)) * b_pix + b_chan;   // slot 0 = column bow - 1
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-      rb[k] = bload4(rs_x, (brow & ((unsigned)(bow - 1 + k) < (unsigned)a.IW)) ? bbase + k * b_pix : OOB_OFF);
-    advance(bn, boh, bow);
-  };
-  const int wa_sw = (((pra >> 1) ^ ((qa >> 2) & 3)) << 2) | ((pra & 1) << 1);
-  const int wb_sw = ((((prb & 7) >> 1) ^ ((qb >> 2) & 3)) << 2) | ((prb & 1) << 1);
-  const bool do_bias = a.dshift != nullptr && r == 0 && tile_n == 0;       // block-uniform
-  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto store_chunk = [&](int buf) {
-    unsigned* const sb = sm + buf * R3_BUF;
-    {
-      const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
-                            make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
-      if (do_bias) {
-        bsum.x += (ch[0].x + ch[0].y) + (ch[0].z + ch[0].w);
-        bsum.y += (ch[1].x + ch[1].y) + (ch[1].z + ch[1].w);
-        bsum.z += (ch[2].x + ch[2].y) + (ch[2].z + ch[2].w);
-        bsum.w += (ch[3].x + ch[3].y) + (ch[3].z + ch[3].w);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        uint2 h, l;
-        split4(ch[j], h, l);
-        const int o = (j * QA + qa) * 16 + wa_sw;
-        *(uint2*)(sb + PA_HI + o) = h;
-        *(uint2*)(sb + PA_LO + o) = l;
-      }
-    }
-    if (prb < 8) {
-      const float* f[6] = {&rb[0].x, &rb[1].x, &rb[2].x, &rb[3].x, &rb[4].x, &rb[5].x};
-#pragma unroll
-      for (int s = 0; s < 3; ++s)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          uint2 h, l;
-          split4(make_float4(f[s][j], f[s + 1][j], f[s + 2][j], f[s + 3][j]), h, l);     // pixels i -> slot i + s
-          const int o = (j * QB + qb) * 16 + wb_sw;
-          *(uint2*)(sb + PB0 + s * 2 * BN * 16 + o) = h;
-          *(uint2*)(sb + PB0 + s * 2 * BN * 16 + BN * 16 + o) = l;
-        }
-    }
-  };
-
-  f32x16 acc[3][TM];
-#pragma unroll
-  for (int s = 0; s < 3; ++s)
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[s][i][e] = 0.f;
-
-  const int frow = lane & 31;
-  auto mma_half = [&](int cur, int sub) {
-    const unsigned* const sb = sm + cur * R3_BUF;
-    const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
-    bf16x8 ah[TM], al[TM];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int o = (wm * WTM + i * 32 + frow) * 16 + r_sw;
-      ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + PA_HI + o));
-      al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + PA_LO + o));
-    }
-#pragma unroll
-    for (int s = 0; s < 3; ++s) {
-      const int o = (wn * WTN + frow) * 16 + r_sw;
-      const bf16x8 bh = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + PB0 + s * 2 * BN * 16 + o));
-      const bf16x8 bl = __builtin_bit_cast(bf16x8, *(const uint4*)(sb + PB0 + s * 2 * BN * 16 + BN * 16 + o));
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[s][i], 0, 0, 0);
-        acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[s][i], 0, 0, 0);
-        acc[s][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[s][i], 0, 0, 0);
-      }
-    }
-  };
-
-  if (nk > 0) {
-    load_chunk();
-    store_chunk(0);
-  }
-  __syncthreads();
-  int cur = 0;
-  for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) load_chunk();
-    mma_half(cur, 0);
-    mma_half(cur, 1);
-    if (it + 1 < nk) store_chunk(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  if (do_bias) {
-    float* const sf = smem_dyn;
-    *(float4*)&sf[pra * BM + 4 * qa] = bsum;
-    __syncthreads();
-    if (tid < BM && oc0 + tid < a.OCg) {
-      float t = 0.f;
-#pragma unroll
-      for (int p = 0; p < 8; ++p) t += sf[p * BM + tid];
-      atomicAdd(a.dshift + g * a.OCg + oc0 + tid, t);
-    }
-    __syncthreads();
-  }
-  if (a.debug_nostore) return;
-
-  // per tap: un-permute the accumulator tile through LDS (row R = channel (R % QA) * 4 + R / QA, column likewise)
-  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem_dyn);
-  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
-#pragma unroll
-  for (int s = 0; s < 3; ++s) {
-    const int tap = r * 3 + s;
-    {
-      const int C = wn * WTN + ecol;
-      const int cl = (C % QB) * 4 + C / QB;
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int R = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
-          Cs[(R % QA) * 4 + R / QA][cl] = acc[s][i][e];
-        }
-    }
-    __syncthreads();
-    if (a.slab || a.split_k == 1) {
-      float* const base = a.slab ? a.slab + (size_t)split * a.slab_stride : a.dw;
-      for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
-        const int row = idx / (BN / 4), col = (idx - row * (BN / 4)) * 4;
-        const int ocl = oc0 + row, cl = c0 + col;
-        if (ocl >= a.OCg || cl + 3 >= a.Cg) continue;            // Cg % 4 == 0 on this kernel
-        float* p = base + ((size_t)(g * a.OCg + ocl) * 9 + tap) * a.Cg + cl;
-        float4 v = *(const float4*)&Cs[row][col];
-        if (!a.slab) { const float4 o = *(const float4*)p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *(float4*)p = v;
-      }
-    } else {
-      for (int idx = tid; idx < BM * BN; idx += 256) {
-        const int row = idx / BN, col = idx - row * BN;
-        const int ocl = oc0 + row, cl = c0 + col;
-        if (ocl < a.OCg && cl < a.Cg)
-          atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * 9 + tap) * a.Cg + cl, Cs[row][col]);
-      }
-    }
-    __syncthreads();
-  }
-}
-
 // dw += slab[0] + slab[1] + ... in split order (fixed association: bit-reproducible weight gradients)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t stride,
                                                            int64_t n, float* __restrict__ dw) {
@@ -2636,7 +2413,7 @@ CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float*
 }
 
 // tile and reduction split of a weight-gradient problem (shared by the launcher and the workspace query)
-struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; bool row3 = false; };
+struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; };
 
 static WgradArgs wgrad_args(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias) {
   WgradArgs a = {};
@@ -2695,35 +2472,6 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   p.split = split_for(blocks(p.bm, p.bn), p.bm * p.bn >= 128 * 128 ? 2 : 4);
   if (const int forced = env_int("CPM_WGRAD_SPLIT", 0)) p.split = forced < a.chunks ? forced : a.chunks;   // sweeps
   p.bf16 = wvec && g_conv_split && p.bm % 64 == 0 && p.bn % 64 == 0;
-  // 3x3 / stride 1 / pad 1 on the split-bf16 arithmetic: one filter row per workgroup (wgrad_row3_kernel)
-  // Measured (tools/bench_conv.py, CPM_WGRAD_ROW3=0/1/2): +13 % on the 2x256x200x336 layers (547 -> 482 us) and +25 %
-  // on layer4's 512-channel ones (83 -> 66 us), but 10-20 % SLOWER on everything between (8 400 pixels x 256 channels,
-  // 64 RoIs x 576 channels): a third of the workgroups for the same reduction means deeper pixel splits, and each
-  // workgroup ends with three tiles of atomics.  And inside the training step, where the weight gradients share the
-  // device with the data-gradient chain, the two winners give nothing back (24.2-24.6 ms/step either way: 80 KB of
-  // LDS per workgroup leaves no room for a data-gradient workgroup beside it).  So: 0 = off (default), 1 = the layers
-  // it wins on in isolation, 2 = every eligible layer (tests).
-  const int row3 = env_int("CPM_WGRAD_ROW3", 0);              // read per call: the tests switch it
-  const bool row3_pays = row3 == 2 || (int64_t)a.M >= 65536;
-  if (row3 && row3_pays && !a.row_scale && p.bf16 && p.bm == 128 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 &&
-      a.OH == a.IH && a.OW == a.IW && a.Cg >= 64 && a.x_bytes < 0x80000000u && a.dy_bytes < 0x80000000u) {
-    p.row3 = true;
-    const int OWp = (a.OW + 3) & ~3;
-    const int chunks3 = cpm::cdiv((int64_t)a.N * a.OH * OWp, 32);
-    const int64_t nb = (int64_t)cpm::cdiv(a.OCg, R3_BM) * cpm::cdiv(a.Cg, R3_BN) * 3 * a.groups;
-    const int64_t slots = 2ll * num_cus();
-    const int maxs = chunks3 / 8 > 0 ? (chunks3 / 8 > 256 ? 256 : chunks3 / 8) : 1;
-    int best = 1;
-    double best_cost = 1e30;
-    for (int sk = 1; sk <= maxs; ++sk) {              // same model as split_for; a chunk is 1.5 x the MFMAs, 3 tiles out
-      const int64_t nblk = nb * sk;
-      const int64_t full = nblk / slots, tail = nblk % slots;
-      const double rounds = (double)full + (tail == 0 ? 0.0 : (tail * 2 <= slots ? 0.78 : 1.0));
-      const double cost = rounds * ((double)cpm::cdiv(chunks3, sk) + 9.0);
-      if (cost < best_cost - 1e-9) { best_cost = cost; best = sk; }
-    }
-    p.split = best;
-  }
   return p;
 }
 
@@ -2806,24 +2554,6 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
       ((uintptr_t)workspace & 15) == 0) {
     a.slab = (float*)workspace;
     a.slab_stride = plane;
-  }
-  if (p.row3) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      (void)hipFuncSetAttribute((const void*)wgrad_row3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, R3_LDS_BYTES);
-      attr_set = true;
-    }
-    dim3 grid3((unsigned)(cpm::cdiv(a.OCg, R3_BM) * cpm::cdiv(a.Cg, R3_BN)), 3, a.groups * a.split_k);
-    hipLaunchKernelGGL(wgrad_row3_kernel, grid3, dim3(256), R3_LDS_BYTES, s, a);
-    int rc3 = cpm::check_launch("conv wgrad (filter rows)");
-    if (rc3 == CPM_OK && a.slab) {
-      const int64_t n = (int64_t)dw_elems;
-      int64_t b = (n / 4 + 255) / 256;
-      b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, n, dw);
-      rc3 = cpm::check_launch("conv wgrad reduce");
-    }
-    return rc3;
   }
   dim3 grid((unsigned)(cpm::cdiv(a.OCg, p.bm) * cpm::cdiv(a.Cg, p.bn)), taps, a.groups * a.split_k);
 #define WCASE(BM, BN, WM, WN)                                                                        \

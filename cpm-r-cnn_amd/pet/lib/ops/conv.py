@@ -113,6 +113,9 @@ def conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, x_shape, w_shape, stride, pad,
 
 
 _WT_CACHE = os.environ.get("CPM_DGRAD_WT_CACHE", "1") != "0"
+# CPM_GATE_BY_CONSUMERS=0: multi-consumer ReLU outputs (bottleneck outputs, the RPN's shared conv) run their own
+# epilogue-backward pass again (A/B switch; the sole-consumer chains are not affected)
+_GATE_BY_CONSUMERS = os.environ.get("CPM_GATE_BY_CONSUMERS", "1") != "0"
 
 
 def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
@@ -514,6 +517,8 @@ def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, 
     sole_consumer: exactly one consumer (bottleneck conv1 -> conv2 -> conv3); gate_by_consumers: several (a bottleneck's
     output: the next block's conv1, its downsample conv or residual add, an FPN lateral)."""
     tag = None
+    if gate_by_consumers and not _GATE_BY_CONSUMERS:
+        gate_by_consumers = False
     if relu and torch.is_grad_enabled() and ((sole_consumer and residual is None) or gate_by_consumers):
         tag = {"applied": False}
     y = _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode, tag)

@@ -16,9 +16,13 @@ iouType = 'bbox' in numpy:
     cumulative tp / fp over the non-ignored ones, precision made monotonically non-increasing from the right and
     sampled at the 101 recall thresholds by searchsorted(side='left'); recall = last tp / number of non-ignored gts;
   summarize: means over the entries that are not -1: AP, AP50, AP75, APs, APm, APl, AR1, AR10, AR100, ARs, ARm, ARl and
-    the reference's extra AP60 / AP70 / AP80 (mycocoeval.py:476-478).
+    the reference's extra AP60 / AP70 / AP80 / AP90 (mycocoeval.py:476-479; AP90 from the threshold index the
+    reference hard-codes there).
 
-PARITY UNPINNED against a pycocotools binary (absent); held by known answers in tests/test_cocoeval.py."""
+Pinned to the reference's vendored evaluator: tests/golden/cocoeval_ref.* is written by running mycocoeval.py:62-423
+itself (make_golden.py cocoeval; only pycocotools' box IoU routine, its one third-party call, is supplied by the harness)
+and tests/test_cocoeval.py holds this module's precision / recall arrays EQUAL to it and the 16 summary numbers to
+1e-12; the known-answer tests stay."""
 import collections
 
 import numpy as np
@@ -159,12 +163,12 @@ class COCOBoxEval(object):
 
     def summarize(self):
         names = ["AP", "AP50", "AP75", "APs", "APm", "APl", "AR1", "AR10", "AR100", "ARs", "ARm", "ARl", "AP60", "AP70",
-                 "AP80"]
+                 "AP80", "AP90"]
         vals = [self._summ(1), self._summ(1, 0.5), self._summ(1, 0.75), self._summ(1, area="small"),
                 self._summ(1, area="medium"), self._summ(1, area="large"), self._summ(0, max_det=1),
                 self._summ(0, max_det=10), self._summ(0, max_det=100), self._summ(0, area="small"),
                 self._summ(0, area="medium"), self._summ(0, area="large"), self._summ(1, 0.6), self._summ(1, 0.7),
-                self._summ(1, 0.8)]
+                self._summ(1, 0.8), self._summ(1, 0.9)]
         self.stats = collections.OrderedDict(zip(names, vals))
         return self.stats
 

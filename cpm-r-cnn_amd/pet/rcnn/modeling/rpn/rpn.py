@@ -25,7 +25,8 @@ class RPNHead(nn.Module):
     def forward(self, x):
         logits, bbox_reg = [], []
         for feature in x:
-            t = ops.mark_shared_grad(self.conv(feature, relu=True))     # consumers: the two 1x1 predictors
+            # consumers: the two 1x1 predictors, which also apply this conv's ReLU gate in their data gradients
+            t = ops.mark_shared_grad(self.conv(feature, relu=True, gate_by_consumers=True))
             logits.append(self.cls_logits(t))
             bbox_reg.append(self.bbox_pred(t))
         return logits, bbox_reg

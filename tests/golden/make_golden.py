@@ -786,6 +786,102 @@ def gen_rpn():
 
 
 
+def gen_cocoeval():
+    """Row f-3: the reference's vendored COCOeval (pet/rcnn/datasets/mycocoeval.py:62-423, bbox
+    protocol) run here on a synthetic dataset.  Its only third-party call is pycocotools' compiled box IoU
+    (mycocoeval.py:190, maskUtils.iou); the harness supplies that one function in numpy (intersection over union of
+    [x, y, w, h] boxes, over the detection's area against a crowd) and a minimal in-memory COCO index with the four
+    accessors COCOeval uses (getImgIds / getCatIds / getAnnIds / loadAnns).  Stored: the dataset, the detections, the 16
+    summary numbers and the precision / recall arrays."""
+    import importlib
+
+    def iou(d, g, iscrowd):
+        d, g = np.asarray(d, np.float64).reshape(-1, 4), np.asarray(g, np.float64).reshape(-1, 4)
+        out = np.zeros((len(d), len(g)))
+        for j in range(len(g)):
+            for i in range(len(d)):
+                w = min(d[i, 0] + d[i, 2], g[j, 0] + g[j, 2]) - max(d[i, 0], g[j, 0])
+                h = min(d[i, 1] + d[i, 3], g[j, 1] + g[j, 3]) - max(d[i, 1], g[j, 1])
+                if w <= 0 or h <= 0:
+                    continue
+                inter = w * h
+                da, ga = d[i, 2] * d[i, 3], g[j, 2] * g[j, 3]
+                out[i, j] = inter / (da if iscrowd[j] else da + ga - inter)
+        return out
+    sys.modules["pycocotools.mask"].iou = iou
+    sys.modules["pycocotools"].mask = sys.modules["pycocotools.mask"]
+    # the file on its own, where it lies (pet/rcnn/datasets/__init__.py pulls in the torchvision-based loaders)
+    ref = _load_ref_file("pet/rcnn/datasets/mycocoeval.py", "ref_mycocoeval")
+    # numpy 2 refuses the float sample count the file passes to np.linspace (np.round(..) + 1, mycocoeval.py Params):
+    # the numpy of the reference's day truncated it -- same stand-in class as np.float = float above
+    _linspace = np.linspace
+    np.linspace = lambda start, stop, num=50, **kw: _linspace(start, stop, int(num), **kw)
+
+    class MiniCOCO(object):
+        def __init__(self, images, cats, anns):
+            self.images, self.cats, self.anns = images, cats, {a["id"]: a for a in anns}
+
+        def getImgIds(self):
+            return [im["id"] for im in self.images]
+
+        def getCatIds(self):
+            return [c["id"] for c in self.cats]
+
+        def getAnnIds(self, imgIds=[], catIds=[]):
+            return [a["id"] for a in self.anns.values()
+                    if (not len(imgIds) or a["image_id"] in imgIds) and (not len(catIds) or a["category_id"] in catIds)]
+
+        def loadAnns(self, ids):
+            return [self.anns[i] for i in ids]
+
+    rng = np.random.default_rng(5)
+    images = [{"id": i, "width": 640, "height": 480} for i in range(1, 15)]
+    cats = [{"id": c, "name": "c%d" % c} for c in (1, 2, 5)]
+    anns, dets = [], []
+    for im in images:
+        for c in cats:
+            n_gt = int(rng.integers(0, 5))
+            for _ in range(n_gt):
+                side = float(rng.choice([12.0, 40.0, 150.0])) * float(rng.uniform(0.7, 1.4))
+                w, h = side * float(rng.uniform(0.6, 1.6)), side
+                x, y = float(rng.uniform(0, 640 - w)), float(rng.uniform(0, 480 - h))
+                crowd = int(rng.uniform() < 0.12)
+                anns.append({"id": len(anns) + 1, "image_id": im["id"], "category_id": c["id"], "bbox": [x, y, w, h],
+                             "area": w * h * float(rng.uniform(0.5, 1.0)), "iscrowd": crowd})
+                for _ in range(int(rng.integers(0, 3))):          # jittered copies: true positives at various IoU
+                    j = rng.normal(0, 0.12, 4)
+                    dets.append({"image_id": im["id"], "category_id": c["id"],
+                                 "bbox": [x + j[0] * w, y + j[1] * h, w * float(np.exp(j[2])), h * float(np.exp(j[3]))],
+                                 "score": float(rng.uniform(0.05, 1.0))})
+            for _ in range(int(rng.integers(0, 4))):              # false positives
+                w, h = float(rng.uniform(8, 300)), float(rng.uniform(8, 300))
+                dets.append({"image_id": im["id"], "category_id": c["id"],
+                             "bbox": [float(rng.uniform(0, 640 - w)), float(rng.uniform(0, 480 - h)), w, h],
+                             "score": float(rng.uniform(0.0, 0.8))})
+    # one (image, category) cell beyond maxDets = 100
+    for _ in range(130):
+        w, h = float(rng.uniform(8, 120)), float(rng.uniform(8, 120))
+        dets.append({"image_id": 3, "category_id": 2, "bbox": [float(rng.uniform(0, 500)), float(rng.uniform(0, 350)), w, h],
+                     "score": float(rng.uniform(0.0, 1.0))})
+    gt_json = {"images": images, "categories": cats, "annotations": anns}
+    dt_anns = []
+    for i, d in enumerate(dets):                                  # what COCO.loadRes adds to bbox results
+        a = dict(d)
+        a["id"], a["area"], a["iscrowd"] = i + 1, d["bbox"][2] * d["bbox"][3], 0
+        dt_anns.append(a)
+    import copy
+    E = ref.COCOeval(MiniCOCO(images, cats, copy.deepcopy(anns)), MiniCOCO(images, cats, dt_anns), "bbox")
+    E.evaluate()
+    E.accumulate()
+    E.summarize()
+    np.linspace = _linspace
+    with open(os.path.join(HERE, "cocoeval_ref.json"), "w") as f:
+        json.dump({"gt": gt_json, "dt": dets, "stats": [float(v) for v in E.stats]}, f)
+    np.savez_compressed(os.path.join(HERE, "cocoeval_ref.npz"), precision=E.eval["precision"], recall=E.eval["recall"])
+    print("cocoeval:", len(anns), "gts", len(dets), "dets", [round(float(v), 4) for v in E.stats])
+
+
+
 def gen_soft_nms(ref_ext):
     """soft_nms_cpu of the reference (csrc/NMS/soft_nms.cpp compiled into oracle/_ref) on seeded box sets: all three
     methods, ties in the scores, heavy overlap (many removals), n = 0 / 1."""
@@ -933,6 +1029,8 @@ def main():
         return gen_cpm_train()
     if sys.argv[1:] == ["rpn"]:
         return gen_rpn()
+    if sys.argv[1:] == ["cocoeval"]:
+        return gen_cocoeval()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")
     cfg.DEVICE = "cpu"
     ops = {}

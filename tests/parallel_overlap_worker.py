@@ -2,7 +2,10 @@
 (gloo backend, CUDA tensors), exercising pet/utils/parallel.py's overlap path: post-accumulate hooks, the in-place
 gradient sinks of the HIP conv / Linear / GroupNorm kernels, chunk all-reduces on a side stream in buffer order.
 
-    python tests/parallel_overlap_worker.py RANK WORLD PORT OUTFILE
+    python tests/parallel_overlap_worker.py RANK WORLD PORT OUTFILE [BACKEND]
+
+BACKEND "nccl" (= RCCL on ROCm): one GPU per rank (cuda:RANK) -- the configuration the 8-GPU scaling run uses; the
+test that passes it only runs on a box with at least two GPUs.
 """
 import json
 import os
@@ -15,6 +18,8 @@ sys.path.insert(0, os.path.join(ROOT, "cpm-r-cnn_amd"))
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    backend = sys.argv[5] if len(sys.argv) > 5 else "gloo"
+    dev_index = rank if backend == "nccl" else 0
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", port
     import torch
     import torch.distributed as dist
@@ -22,11 +27,13 @@ def main():
     import pet.lib.ops as ops
     from pet.utils.optimizer import FlatSGD
     from pet.utils.parallel import FlatGradReducer, broadcast_initial_state
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    res = {"rank": rank}
+    if backend == "nccl":
+        torch.cuda.set_device(dev_index)
+    dist.init_process_group(backend, rank=rank, world_size=world)
+    res = {"rank": rank, "backend": backend}
     try:
-        torch.cuda.set_device(0)
-        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev_index)
+        dev = torch.device("cuda", dev_index)
         CL = torch.channels_last
 
         class Net(nn.Module):

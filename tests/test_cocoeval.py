@@ -88,3 +88,28 @@ def test_evaluation_entry_point_scores_without_pycocotools(tmp_path):
     finally:
         config.reset_cfg()
     assert abs(res["bbox"]["AP"] - 1.0) < 1e-12 and (tmp_path / "test" / "bbox.json").exists()
+
+
+def test_equals_the_references_vendored_cocoeval():
+    """tests/golden/cocoeval_ref.* (make_golden.py cocoeval): the reference's own COCOeval (pet/rcnn/datasets/
+    mycocoeval.py:62-423, bbox protocol) run on 14 images x 3 categories with crowds, all three area ranges, jittered
+    true positives, false positives and one (image, category) cell beyond maxDets -- only the box IoU routine it takes
+    from pycocotools was supplied by the harness.  Precision [T,R,K,A,M] and recall [T,K,A,M] arrays must be EQUAL and
+    the summary numbers agree to 1e-12 (AP90, which the reference prints from a hard-coded threshold index, included)."""
+    import json
+    import os
+    from pet.rcnn.datasets.cocoeval import COCOBoxEval
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    with open(os.path.join(here, "cocoeval_ref.json")) as f:
+        ref = json.load(f)
+    arr = np.load(os.path.join(here, "cocoeval_ref.npz"))
+    ev = COCOBoxEval(ref["gt"], ref["dt"]).evaluate().accumulate()
+    assert ev.eval["precision"].shape == arr["precision"].shape
+    assert np.array_equal(ev.eval["precision"], arr["precision"])
+    assert np.array_equal(ev.eval["recall"], arr["recall"])
+    s = ev.summarize()
+    names = ["AP", "AP50", "AP75", "APs", "APm", "APl", "AR1", "AR10", "AR100", "ARs", "ARm", "ARl", "AP60", "AP70", "AP80",
+             "AP90"]
+    assert len(ref["stats"]) == 16
+    for n, want in zip(names, ref["stats"]):
+        assert abs(s[n] - want) < 1e-12, (n, s[n], want)

@@ -29,7 +29,7 @@ def _free_port():
     return p
 
 
-def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
+def _run_two_ranks(tmp_path, backend):
     import torch
     if torch.cuda.is_initialized():
         pytest.skip("must start its child ranks before this process touches the GPU (run the file on its own)")
@@ -40,7 +40,7 @@ def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
         out = str(tmp_path / ("rank%d.json" % r))
         outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "parallel_overlap_worker.py"), str(r), "2",
-                                       port, out], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+                                       port, out, backend], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
@@ -54,6 +54,10 @@ def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
         assert os.path.exists(out), log
         with open(out) as f:
             res.append(json.load(f))
+    return res
+
+
+def _check(res):
     for r in res:
         assert r["ok"], r.get("error")
         assert r["overlap"] and r["same_start"] and r["nonzero"]
@@ -64,3 +68,18 @@ def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
     assert res[0]["order"] == res[1]["order"]
     per_step = res[0]["chunks"]
     assert res[0]["order"] == list(range(per_step)) * 2               # buffer order, every step
+
+
+def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
+    _check(_run_two_ranks(tmp_path, "gloo"))
+
+
+def test_overlapped_flat_gradient_reduce_two_ranks_rccl(tmp_path):
+    """The same over backend "nccl" (RCCL), one GPU per rank: runs wherever the box has two GPUs (the driver's 8-GPU
+    node); skipped on the one-GPU boxes the builder gets."""
+    import torch
+    if torch.cuda.device_count() < 2:                 # (device_count does not initialise the GPU on this image)
+        pytest.skip("RCCL needs one GPU per rank: this box has %d" % torch.cuda.device_count())
+    res = _run_two_ranks(tmp_path, "nccl")
+    _check(res)
+    assert all(r["backend"] == "nccl" for r in res)

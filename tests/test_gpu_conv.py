@@ -422,54 +422,6 @@ def test_error_bound_of_both_arithmetics_wide_dynamic_range(conv_math):
     assert err < (2e-6 if conv_math == "f32" else 3e-5), (conv_math, err)
 
 
-@pytest.mark.parametrize("case", [(2, 128, 40, 56, 128, 1), (40, 128, 7, 7, 192, 1), (20, 576, 7, 7, 576, 1),
-                                  (8, 256, 14, 14, 256, 1), (1, 96, 21, 25, 136, 1), (2, 256, 9, 42, 256, 2),
-                                  (24, 100, 6, 5, 132, 1)],
-                         ids=["w56", "roi7", "grid576", "w14", "w25_ragged_k", "groups2_w42", "ragged_c100"])
-@pytest.mark.parametrize("deterministic", [False, True], ids=["atomics", "slabs"])
-def test_filter_row_weight_gradient(case, deterministic, monkeypatch):
-    """wgrad_row3_kernel (3x3 / stride 1 / pad 1 in the split-bf16 arithmetic: one filter row per workgroup, dy tile
-    shared by the row's three taps, rows walked padded to a multiple of 4) forced on (CPM_WGRAD_ROW3=2; by default
-    only the layers it speeds up take it): equal to torch-CPU to the arithmetic's bound, equal to the tap-per-workgroup
-    kernel to summation order, the fused bias gradient too, bit-reproducible in deterministic mode."""
-    from pet.lib.ops import _hip
-    from pet.lib.ops import conv as ops
-    N, C, H, W, K, g = case
-    prev = _hip.get_conv_math()
-    _hip.set_conv_math("bf16x3")
-    _hip.set_deterministic(deterministic)
-    try:
-        x = rnd(N, C, H, W, seed=11)
-        w = rnd(K, C // g, 3, 3, seed=12, scale=0.05)
-        wr = w.clone().requires_grad_(True)
-        yr = F.conv2d(x, wr, None, 1, 1, 1, g)
-        dy = rnd(*yr.shape, seed=13)
-        yr.backward(dy)
-        xd = x.cuda().contiguous(memory_format=CL)
-        dyd = dy.cuda().contiguous(memory_format=CL)
-        wd = w.cuda().contiguous(memory_format=CL)
-        got = {}
-        for mode in ("2", "0"):
-            monkeypatch.setenv("CPM_WGRAD_ROW3", mode)
-            dw, db = torch.zeros_like(wd), torch.zeros(K, device="cuda")
-            ops.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, g, out=dw, dbias=db if g == 1 else None)
-            got[mode] = (dw, db)
-        assert relerr(got["2"][0], wr.grad) < TOL
-        assert relerr(got["2"][0], got["0"][0]) < 1e-5
-        if g == 1:
-            assert relerr(got["2"][1], dy.sum(dim=(0, 2, 3))) < TOL
-        if deterministic:
-            monkeypatch.setenv("CPM_WGRAD_ROW3", "2")
-            dw2 = torch.zeros_like(wd)
-            ops.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, g, out=dw2)
-            dw3 = torch.zeros_like(wd)
-            ops.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, g, out=dw3)
-            assert torch.equal(dw2, dw3)
-    finally:
-        _hip.set_deterministic(False)
-        _hip.set_conv_math(prev)
-
-
 def test_conv_gn_stack_equals_layer_by_layer():
     """cpm_layer_chain_forward / _backward (one native call per direction for a stack of conv + bias -> GroupNorm ->
     ReLU layers, the grid head's shape) against the same layers run op by op: the same C-ABI calls in the same order,

@@ -451,9 +451,15 @@ def test_dgrad_weight_images_follow_the_optimizer():
         torch.cuda.synchronize()
         reg = [(k, p) for k, p in m.named_parameters() if getattr(p, "_cpm_wt_desc", None) is not None]
         assert len(reg) >= 60                                    # every trainable conv / FC-as-conv weight with a dgrad
+        n_scaled = 0
         for k, p in reg:
-            groups, kg, rs, cg = p._cpm_wt_desc
+            groups, kg, rs, cg, scale_ptr = p._cpm_wt_desc
             w = p.detach()
+            sc = getattr(p, "_cpm_wt_scale", None)               # the frozen affine behind a backbone conv: folded in
+            assert (sc is None) == (scale_ptr == 0) and (sc is None or sc.data_ptr() == scale_ptr)
+            if sc is not None:
+                n_scaled += 1
+                w = w * sc.detach().view(-1, 1, 1, 1)
             if w.dim() == 2:                                     # nn.Linear used as a 1x1 conv on a 1x1 image
                 want = w.t().reshape(-1)
             elif rs == 1 and w.shape[2] * w.shape[3] > 1:        # full-window conv registered as a [K, R*S*C] matrix
@@ -462,15 +468,17 @@ def test_dgrad_weight_images_follow_the_optimizer():
                 K, Cg, R, S = w.shape
                 want = w.reshape(groups, kg, Cg, R * S).permute(0, 2, 3, 1).reshape(-1)
             assert torch.equal(p._cpm_wt, want), k
-            assert _prepared_wt(p, groups, kg, rs, cg) is p._cpm_wt
+            assert _prepared_wt(p, groups, kg, rs, cg, sc) is p._cpm_wt
+        assert n_scaled >= 30                                    # layer2..layer4 convs (conv1 of the first trained block has no dgrad)
         k0, p0 = reg[0]
+        sc0 = getattr(p0, "_cpm_wt_scale", None)
         with torch.no_grad():
             p0.mul_(1.0)                                         # an edit outside the optimizer moves _version
-        assert _prepared_wt(p0, *p0._cpm_wt_desc) is None
+        assert _prepared_wt(p0, *p0._cpm_wt_desc[:4], sc0) is None
         opt.zero_grad()
         loss = sum(m(images, targets)["losses"].values())
         loss.backward()
         opt.step()
-        assert torch.isfinite(loss) and _prepared_wt(p0, *p0._cpm_wt_desc) is p0._cpm_wt
+        assert torch.isfinite(loss) and _prepared_wt(p0, *p0._cpm_wt_desc[:4], sc0) is p0._cpm_wt
     finally:
         config.reset_cfg()
