@@ -385,6 +385,9 @@ def main():
                     "(R-101-FPN bs=2, X-101-64x4d-FPN-DCN bs=1; N=1 only; reported as config.other_bodies)")
     ap.add_argument("--chunks", type=int, default=8, help="number of contiguous pieces the flat gradient is all-reduced "
                     "in (pet/utils/parallel.py: default 8 x ~77 MB; sweep it on the 8-GPU node)")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("CPM_GRAPH_STATIC", "0")),
+                    help="1: backbone + FPN + RPN-head convolutions (static shapes) run as captured hipGraphs, forward "
+                         "and backward (Generalized_RCNN.capture_static_part), after the eager warm-up steps")
     ap.add_argument("--verbose", action="store_true", help="print the losses of every step (adds a sync per step)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend: nccl (= RCCL, default) or gloo "
                     "(rehearsal of the N > 1 path on a box with fewer GPUs than ranks)")
@@ -428,6 +431,11 @@ def main():
         if a.verbose and rank == 0:
             print("warmup %d lr=%.5f %s" % (i, trainer.scheduler.new_lr, {k: round(float(v.detach()), 4)
                                                                       for k, v in trainer.last_losses.items()}), flush=True)
+    if a.graph:
+        assert a.warmup >= 1, "capture needs one eager optimizer step first (data-gradient weight images)"
+        trainer.model.capture_static_part(images.tensors)
+        for _ in range(2):                                  # (zero_grad of these steps clears what the capture left)
+            trainer.step(images, targets)
     sync()
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -584,7 +592,7 @@ def main():
                        **({"host_input": host_input} if host_input else {}),
                        **({"full_rois": full_rois} if full_rois else {}),
                        **({"other_bodies": other_bodies} if other_bodies else {}),
-                       "grad_allreduce_chunks": a.chunks,
+                       "grad_allreduce_chunks": a.chunks, "static_part_as_hipgraph": bool(a.graph),
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,

@@ -118,6 +118,16 @@ _WT_CACHE = os.environ.get("CPM_DGRAD_WT_CACHE", "1") != "0"
 _GATE_BY_CONSUMERS = os.environ.get("CPM_GATE_BY_CONSUMERS", "1") != "0"
 
 
+_pending_wt_event = None
+
+
+def set_pending_wt_event(ev):
+    """The optimizer's once-per-step weight-image transform runs on the second stream (FlatSGD._refresh_dgrad_weights):
+    whoever reads an image next makes its stream wait for this event first (_prepared_wt)."""
+    global _pending_wt_event
+    _pending_wt_event = ev
+
+
 def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
     """The data-gradient image of a weight owned by the flat optimizer, made for ALL such weights in one launch after
     every optimizer step (pet/utils/optimizer.py: FlatSGD._refresh_dgrad_weights) -- or None (transform per call):
@@ -139,6 +149,10 @@ def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
         return None
     if k_scale is not None and getattr(wparam, "_cpm_wt_scale_version", None) != k_scale._version:
         return None
+    global _pending_wt_event
+    if _pending_wt_event is not None:                  # first reader after an optimizer step: the transform must be done
+        torch.cuda.current_stream().wait_event(_pending_wt_event)
+        _pending_wt_event = None
     return wt
 
 
@@ -313,7 +327,10 @@ def wgrad_stream(device):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     st = _side.get(idx)
     if st is None:
-        t = torch.cuda.Stream(device=device)
+        # CPM_WGRAD_PRIO: queue priority of the second stream (lower number = higher priority; out-of-range values map to
+        # the nearest valid one): the weight gradients are leaves nothing waits for until the optimizer step, the
+        # data-gradient chain on the compute stream is the critical path
+        t = torch.cuda.Stream(device=device, priority=int(os.environ.get("CPM_WGRAD_PRIO", "0")))
         st = _side[idx] = (t, t.cuda_stream)
     return st[0]
 

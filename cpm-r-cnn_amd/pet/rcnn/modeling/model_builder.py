@@ -65,12 +65,60 @@ class Generalized_RCNN(nn.Module):
         feats = self.Conv_Body(x)
         return self.Conv_Body_FPN(feats) if cfg.MODEL.FPN_ON else [feats[-1]]
 
+    # ---- the static part of the training step as hipGraphs --------------------------------------------------------------
+    # Backbone, FPN and the RPN head's convolutions have no data-dependent shape: for a given padded batch size they are
+    # the same ~370 kernel launches forward and ~600 backward every step, issued by ~130 Python autograd nodes.  On a
+    # busy host that Python work, not the device, bounds the step.  capture_static_part() records both directions once
+    # (torch.cuda.make_graphed_callables: warm-up, then a forward and a backward hipGraph in a private memory pool, the
+    # second stream's weight gradients included through the fork / join events) and forward() replays them for batches of
+    # the captured shape; the weight gradients still land in the flat optimizer's buffer (the kernels' sinks are fixed
+    # addresses), other shapes run eagerly.  What a replay cannot do is call back into Python: the data-parallel
+    # reducer hears about these parameters at FlatGradReducer.finish() instead of during the backward pass.
+    def _static_part(self):
+        model = self
+
+        class StaticPart(nn.Module):
+            def forward(self, x):
+                feats = model._features(x)
+                obj, reg = model.RPN.head(feats)
+                return tuple(feats) + tuple(obj) + tuple(reg)
+        return StaticPart()
+
+    def capture_static_part(self, sample):
+        """sample: an image batch tensor [N,3,H,W] of the shape to capture (its values are used for the warm-up only).
+        Call it once the optimizer has stepped at least once (the data-gradient weight images exist from then on) and
+        BEFORE zero_grad of the next step: warm-up and capture leave gradients in the parameters' sinks."""
+        import torch
+        if not self.training:
+            raise RuntimeError("capture_static_part is for training steps")
+        part = self._static_part()
+        params = [p for p in list(self.Conv_Body.parameters()) + list(self.RPN.head.parameters()) +
+                  (list(self.Conv_Body_FPN.parameters()) if cfg.MODEL.FPN_ON else []) if p.requires_grad]
+        # make_graphed_callables finds a module's parameters through .parameters(): hand it the real ones
+        for i, p_ in enumerate(params):
+            part.register_parameter("p%d" % i, p_)
+        x = sample.detach().clone()
+        graphed = torch.cuda.make_graphed_callables(part, (x,), allow_unused_input=True)
+        self._graphed = getattr(self, "_graphed", {})
+        self._graphed[tuple(sample.shape)] = graphed
+        return graphed
+
     def forward(self, images, targets=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         images = to_image_list(images)
-        feats = self._features(images.tensors)
-        proposals, proposal_losses = self.RPN(images, feats, targets)
+        graphed = getattr(self, "_graphed", {}).get(tuple(images.tensors.shape)) if self.training else None
+        if graphed is not None:
+            outs = graphed(images.tensors)
+            nf = nl = len(outs) // 3                 # feature maps, objectness maps, delta maps: one each per level
+            # the replayed outputs are fresh tensor objects: the RoI heads' RoIAlign calls share ONE gradient
+            # accumulator per level again (ops.mark_shared_grad, as FPN.forward does for the eager tensors)
+            feats = [ops.mark_shared_grad(o) for o in outs[:nf]]
+            proposals, proposal_losses = self.RPN(images, feats, targets,
+                                                  head_out=(list(outs[nf:nf + nl]), list(outs[nf + nl:])))
+        else:
+            feats = self._features(images.tensors)
+            proposals, proposal_losses = self.RPN(images, feats, targets)
         roi_losses = {}
         if not cfg.MODEL.RPN_ONLY:
             _, result, roi_losses = self._roi_heads()(feats, proposals, targets)

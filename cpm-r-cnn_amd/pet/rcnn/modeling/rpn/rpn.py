@@ -42,8 +42,10 @@ class RPNModule(nn.Module):
         self.box_selector_test = make_rpn_postprocessor(coder, is_train=False)
         self.loss_evaluator = make_rpn_loss_evaluator(coder)
 
-    def forward(self, images, features, targets=None):
-        objectness, rpn_box_regression = self.head(features)
+    def forward(self, images, features, targets=None, head_out=None):
+        """head_out: (objectness, box deltas) already computed by the caller -- the statically captured part of the step
+        (Generalized_RCNN.capture_static_part) ends behind the head's convolutions."""
+        objectness, rpn_box_regression = self.head(features) if head_out is None else head_out
         anchors = self.anchor_generator(images, features)
         if self.training:
             return self._forward_train(anchors, objectness, rpn_box_regression, targets)
