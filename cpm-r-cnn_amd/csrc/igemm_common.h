@@ -2,6 +2,7 @@
 // conv_sp.hip: operands already stored as bf16 hi/lo planes, staged by LDS-DMA).
 #pragma once
 #include "common.h"
+#include "../../include/cpmrcnn_hip_experimental.h"
 
 namespace cpmconv {
 

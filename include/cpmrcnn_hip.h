@@ -202,26 +202,8 @@ int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, c
                                       int accumulate, const float* in_scale, const float* in_act, void* workspace,
                                       size_t workspace_bytes, void* stream);
 
-/* ---- split-plane ("SP") operands for the CPM_MATH_BF16X3 arithmetic ------------------------------------------------
- * The 3-term split-bf16 product needs hi = bf16(v), lo = bf16(v - hi) of every operand.  The plain entry points above
- * split fp32 operands inside the kernel, for every tile that reads them; the _sp entry points take the operands
- * ALREADY split, as bf16 blocks in memory, and stage them by LDS-DMA through a ring of stages (conv_sp.hip): same
- * arithmetic, same results to rounding of the accumulation order, no conversion work in the loop.
- *   SP of a [rows][C] fp32 matrix (rows = NHWC pixels, or (k, r, s) rows of a KRSC weight) = [rows][C/32][2][32] bf16:
- *   per row and 32-channel block 32 hi values then 32 lo values (128 bytes: one cache line per row and reduction
- *   step) -- 4*C bytes, like the fp32 row.  C % 32 == 0, 128-byte aligned.
- * cpm_split_planes makes one; the convolutions can also emit their result in that form (y_sp / dx_sp, may be NULL)
- * for the convolution that consumes it.  The fp32 tensors stay the interface (x, w are still required): an operand
- * without an SP twin (x_sp / w_sp NULL), or a shape outside the DMA kernel's rules (C/groups % 32, K/groups > 32),
- * takes the in-kernel split path.  Replaces the same ATen/cuDNN calls as cpm_conv2d_* (pet/lib/ops call sites above). */
-int cpm_split_planes(const float* x, int64_t rows, int channels, void* sp, void* stream);
-int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w, const void* w_sp,
-                          const float* scale, const float* shift, const float* residual, int res_mode, int relu,
-                          float* y, void* y_sp, void* stream);
-/* wt / wt_sp: the prepared data-gradient weight image (cpm_weights_to_dgrad_batched) and its SP twin */
-int cpm_conv2d_backward_data_sp(const cpm_conv_desc* d, const float* dy, const void* dy_sp, const float* wt,
-                                const void* wt_sp, float* dx, void* dx_sp, int accumulate, const float* in_scale,
-                                const float* in_act, void* stream);
+/* (The experimental split-plane / LDS-DMA ring entry points live in cpmrcnn_hip_experimental.h: measured, not on the
+ * product path -- DESIGN.md section 8.) */
 
 /* nn.ConvTranspose2d forward (grid_rcnn/outputs.py:24-37,66-71) = the data gradient of the conv
  * described by `d` with a fused bias(+ReLU) epilogue: x [N,P,Q,K] -> y [N,H,W,C], w as for `d`

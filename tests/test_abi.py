@@ -6,10 +6,16 @@ import re
 from conftest import ROOT
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "cpmrcnn_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(cpm_[a-z0-9_]+)\s*\(", text)))
+HEADERS = ("cpmrcnn_hip.h", "cpmrcnn_hip_experimental.h")      # the boundary, and the measured-but-unused experiments
+
+
+def declared_symbols(headers=HEADERS):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(cpm_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -29,6 +35,21 @@ def test_no_undeclared_exports():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _hip.LIB_PATH], text=True)
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T cpm_" in l)
     assert exported == declared_symbols()
+
+
+def test_product_path_does_not_call_the_experimental_entry_points():
+    """include/cpmrcnn_hip_experimental.h (split-plane operands, LDS-DMA ring kernels) is reachable from
+    pet.lib.ops.sp / conv2d_forward(x_sp=...) only: no model, head or optimizer module uses those."""
+    exp = set(declared_symbols(("cpmrcnn_hip_experimental.h",))) - set(declared_symbols(("cpmrcnn_hip.h",)))
+    assert exp == {"cpm_split_planes", "cpm_conv2d_forward_sp", "cpm_conv2d_backward_data_sp"}
+    pkg = os.path.join(ROOT, "cpm-r-cnn_amd", "pet")
+    allowed = {os.path.join(pkg, "lib", "ops", "sp.py"), os.path.join(pkg, "lib", "ops", "conv.py")}
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            path = os.path.join(d, f)
+            if f.endswith(".py") and path not in allowed:
+                src = open(path).read()
+                assert not any(n in src for n in exp) and "ops.sp" not in src and "import sp" not in src, path
 
 
 def test_ops_refuse_cpu_tensors():
