@@ -213,7 +213,7 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; they are
     # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this same command) and committed
     traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round2_pmc.json")
+    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_pmc.json")
     if math == "bf16x3" and os.path.exists(pmc):
         with open(pmc) as f:
             traffic = json.load(f)["kernels"]["igemm_kernel"]["hbm_bytes_per_launch"]

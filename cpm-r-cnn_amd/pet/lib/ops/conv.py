@@ -861,7 +861,8 @@ def layer_chain(x, layers, owner):
         plan = None
     if plan is None:
         specs = []
-        for i, (m, gn, relu) in enumerate(layers):
+        rc, rh, rw = chw                                 # the shape running through the chain: the native table only
+        for i, (m, gn, relu) in enumerate(layers):       # holds pointers, so every layer is checked against it HERE
             w, b = m.weight, m.bias
             if not (_sunk(w) and _sunk(b)) or (gn is not None and not (_sunk(gn.weight) and _sunk(gn.bias))):
                 return None
@@ -872,10 +873,25 @@ def layer_chain(x, layers, owner):
                     return None
                 if not w.is_contiguous(memory_format=CL):
                     return None
+                if w.shape[1] != rc:
+                    return None
+                if not conv_like:
+                    # a windowed Linear (a full-window conv): its window must BE the running map
+                    if getattr(m, "window", None) != (rc, rh, rw) or (w.shape[2], w.shape[3]) != (rh, rw):
+                        return None
+                rh, rw = out_size(rh, w.shape[2], stride, pad), out_size(rw, w.shape[3], stride, pad)
+                if rh < 1 or rw < 1:
+                    return None
+                rc = w.shape[0]
             else:
                 stride, pad = 1, 0
                 if not (w.dim() == 2 and w.is_contiguous()):
                     return None
+                if (rh, rw) != (1, 1) or w.shape[1] != rc:   # a flat Linear behind a map with H, W > 1 is NOT a 1x1 conv
+                    return None
+                rc = w.shape[0]
+            if gn is not None and gn.num_channels != rc:
+                return None
             if gn is None and relu and i == len(layers) - 1:
                 return None                                  # a bare ReLU at the end needs its consumer's gate
             specs.append((w, b, gn.weight if gn is not None else None, gn.bias if gn is not None else None, stride, pad,

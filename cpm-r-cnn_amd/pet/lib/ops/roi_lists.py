@@ -131,6 +131,11 @@ def roi_sample(inp, gt_all, gt_labels, gt_off, high, low, batch, positive_fracti
     int32 [2 * (images + 1) + 1] = sample counts, positives counts, status -- one tensor so that one copy reads it."""
     dev = inp.boxes.device
     n = inp.n_img
+    # An image's rows are bounded by the list's capacity: checked HERE, before anything is queued -- the kernel's own
+    # overflow status is only read back after the cls head has been launched on the sample it would have left unwritten.
+    if inp.capacity > roi_sample_max_rows():
+        raise RuntimeError("a list of capacity %d may hold more rows per image than cpm_roi_sample takes (%d): "
+                           "set CPM_DEVICE_LISTS=0" % (inp.capacity, roi_sample_max_rows()))
     max_pos = int(batch * positive_fraction)
     cap_s = n * int(batch)
     cap_g = n * min(int(max_grid), max_pos) if max_grid > 0 else 0

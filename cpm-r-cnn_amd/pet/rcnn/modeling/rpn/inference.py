@@ -117,9 +117,17 @@ class RPNPostProcessor(torch.nn.Module):
     def can_keep_on_device(self, objectness, targets):
         """training selection (one top-k over the batch, gts appended) as ONE launch with the result left on the
         device as a packed list (pet/lib/ops/roi_lists.py) -- no host round trip in the proposal stage at all"""
-        return (self.device_lists and self.training and targets is not None and self.can_fuse(objectness)
+        if not (self.device_lists and self.training and targets is not None and self.can_fuse(objectness)
                 and (len(objectness) == 1 or self.fpn_post_nms_per_batch)
-                and len(objectness) * objectness[0].shape[0] <= 512)
+                and len(objectness) * objectness[0].shape[0] <= 512):
+            return False
+        # the packed list's capacity bounds every image's rows: it must fit the RoI heads' sampling kernel
+        # (cpm_roi_sample: 4096 rows per image); a non-FPN RPN (no batch-wide top-k) or a huge FPN_POST_NMS_TOP_N
+        # takes the BoxList path instead
+        n_img, n_gt = objectness[0].shape[0], sum(len(t) for t in targets)
+        cap = (self.fpn_post_nms_top_n if len(objectness) > 1 else
+               n_img * (self.post_nms_top_n if self.post_nms_top_n > 0 else self.pre_nms_top_n)) + n_gt
+        return cap <= RL.roi_sample_max_rows()
 
     def finish_device(self, st, targets):
         gt_all, _, gt_off, off_h = RL.gt_pack(targets)

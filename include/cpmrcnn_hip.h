@@ -454,8 +454,9 @@ int cpm_rescore_gather(const float* s_boxes, const float* s_obj, const int64_t* 
                        void* stream);
 
 /* Stream ordering for work the host side forks onto a second stream (the weight-gradient kernels of the backward
- * pass run beside the data-gradient chain): stream `to` waits for everything queued on `from` so far.  Not thread safe
- * (one backward pass per process). */
+ * pass run beside the data-gradient chain): stream `to` waits for everything queued on `from` so far.  The events come
+ * from a ring per device (the current device's: both streams must belong to it); safe to call from the autograd
+ * engine's per-device worker threads. */
 int cpm_stream_fork(void* from, void* to);
 
 /* ---- a chain of RoI-head layers (conv + bias -> [GroupNorm] -> [ReLU]) from one call --------------------------------

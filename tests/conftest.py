@@ -42,3 +42,14 @@ def conv_math(request):
     _hip.set_conv_math(request.param)
     yield request.param
     _hip.set_conv_math(prev)
+
+
+@pytest.fixture()
+def deterministic_reductions():
+    """cpm_set_deterministic(1) for a test: split reductions fold ordered slab planes instead of float atomics, so the
+    distance to the reference is a property of the arithmetic, not of the run (bounds were widened for
+    run-to-run noise that this mode removes)."""
+    from pet.lib.ops import _hip
+    _hip.set_deterministic(True)
+    yield
+    _hip.set_deterministic(False)

@@ -81,7 +81,7 @@ def _same_boxes(got, want, what, tol=0.05, flips_allowed=0):
 
 
 @pytest.mark.parametrize("fused", ["lists", True, False], ids=["device_lists", "fused_glue", "per_image"])
-def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fused):
+def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fused, deterministic_reductions):
     g = golden
     head = model.Grid_Cascade_RCNN
     saved = (head.fused_glue, head.cls_loss_evaluator.fused_glue, head.rescore_loss_evaluator.fused_glue)
@@ -145,6 +145,8 @@ def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fus
             assert e1 < tol and e2 < tol, (k, e1, e2)
             checked += 1
         assert checked >= 150
+        from test_gpu_model import _log
+        _log("cpm_reference[%s, %s, deterministic] flips %d, worst gradient-norm err %.2e" % (conv_math, fused, flips, worst))
     finally:
         for h in hooks:
             h.remove()
