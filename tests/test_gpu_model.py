@@ -115,7 +115,8 @@ def test_backward_matches_reference(model, golden_model, conv_math, deterministi
         # that flips against the reference moves a GroupNorm-parameter gradient's squared norm by up to ~2e-3 (seen:
         # 2.2e-3 once in four runs, a different tensor each time); exact fp32 stays below 2e-4.  The larger fixture
         # (test_backward_big_matches_reference) holds 1e-3 in both arithmetics.
-        tol = 2e-3 if conv_math == "f32" else 5e-3
+        # with ordered reductions (fixture) the distance is reproducible: measured 1e-6 (f32) / 1.3e-3 (bf16x3)
+        tol = 1e-4 if conv_math == "f32" else 2e-3
         assert e1 < tol and e2 < tol, (k, e1, e2)
     _log("backward_small[%s, deterministic] worst norm err %.2e" % (conv_math, worst))
     for key in g.files:

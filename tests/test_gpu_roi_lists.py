@@ -142,7 +142,17 @@ def test_roi_sample_reports_oversized_images():
     props, targets = _proposal_like(rng, 1, [RL.roi_sample_max_rows() + 1], [4])
     inp = RL.from_boxlists(props)
     gt_all, gt_labels, gt_off, _ = RL.gt_pack(targets)
-    _, _, counts = RL.roi_sample(inp, gt_all, gt_labels, gt_off, 0.5, 0.5, 512, 0.25, 1)
+    # the host refuses a list whose capacity could overflow an image's LDS share BEFORE anything is queued (the
+    # kernel's own status word would only be read after the cls head had run on an unwritten sample)
+    with pytest.raises(RuntimeError, match="CPM_DEVICE_LISTS=0"):
+        RL.roi_sample(inp, gt_all, gt_labels, gt_off, 0.5, 0.5, 512, 0.25, 1)
+    # the kernel still reports it for callers of the C ABI that skip the check
+    big = inp.capacity
+    inp.capacity = RL.roi_sample_max_rows()
+    try:
+        _, _, counts = RL.roi_sample(inp, gt_all, gt_labels, gt_off, 0.5, 0.5, 512, 0.25, 1)
+    finally:
+        inp.capacity = big
     assert counts.cpu().tolist()[-1] == 1
 
 
