@@ -110,7 +110,9 @@ __global__ __launch_bounds__(64 * WM * WN)
 
   // two register sets: the loads of tile t+2 are in flight while tile t is multiplied and tile t+1 moves to LDS
   float4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
-  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
+  // (a.dbg, CPM_IGEMM_DBG, timing only: 8 = descriptors of zero records, nothing is fetched; 16 = no epilogue)
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, (a.dbg & 8) ? 0u : a.in_bytes),
+                               rs_wm = make_rsrc(a.wm, (a.dbg & 8) ? 0u : a.wm_bytes);
 
   // position (tap row, tap column, channel block) of the NEXT tile to load, advanced without divisions: the loads of
   // a k-step are then a handful of scalar instructions and sit in the same straight-line block as its MFMAs
@@ -315,6 +317,15 @@ __global__ __launch_bounds__(64 * WM * WN)
   // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
   const bool dense_rows = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
+  if (a.dbg & 16) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) t += acc[i][j][0] + acc[i][j][15];
+    if (t == 12345.678f) a.out[0] = t;
+    return;
+  }
   if ((a.res || a.staged_epi) && !a.atomic_out) {
     // Residual epilogue (bottleneck conv3, FPN laterals): memory bound on thin reductions.  Stage the tile through
     // LDS (the operand buffers are free after the last barrier) and finish it row-wise with 16-byte accesses, so
@@ -1461,8 +1472,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
 // conflict-free for the stores and for the ds_read_b128 operand fetches alike.  The accumulator tile comes out
 // row/column-permuted accordingly; it is un-permuted through LDS at the end so that the float atomics into dw
 // are 256-byte contiguous per wave instruction.
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256)
+// DBG (timing-only ablations, tools/wgrad_dbg.sh; results are wrong): 1 = every load masked (issued, nothing fetched),
+// 2 = also no bf16 split and no LDS stores, 3 = also the operand reads hoisted out of the loop (MFMAs + barriers only)
+// KS = 2: a workgroup of eight waves, waves 0-3 and 4-7 reducing the two halves of the workgroup's pixel range into
+// their own accumulators (own LDS buffers, nothing shared in the loop), folded through LDS before the tile leaves: the
+// same waves per CU as two independent workgroups, half the partial tiles -- the float atomics / slab planes a launch
+// pays for (1.3 TB/s chip-wide: 32 MB for a 512-workgroup launch = 25 us) halve.
+template <int BM, int BN, int WM, int WN, int DBG = 0, int KS = 1>
+__global__ __launch_bounds__(256 * KS)
     __attribute__((amdgpu_waves_per_eu(2, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))) void wgrad_split_kernel(
         WgradArgs a) {
   constexpr int WTM = BM / WM, WTN = BN / WN;
@@ -1471,11 +1488,13 @@ __global__ __launch_bounds__(256)
   constexpr int CP = BN + 4;
   constexpr int LDS_AB = 2 * (BM + BN) * 32, LDS_C = BM * CP;
   static_assert(QA % 16 == 0 && QB % 16 == 0 && QA * 8 <= 256 && QB * 8 <= 256, "tile shape");
-  __shared__ __attribute__((aligned(16))) float smem[LDS_AB > LDS_C ? LDS_AB : LDS_C];
+  __shared__ __attribute__((aligned(16))) float smem_all[KS * LDS_AB > LDS_C ? KS * LDS_AB : LDS_C];
+  const int slice = KS == 1 ? 0 : (int)(threadIdx.x >> 8);
+  float* const smem = smem_all + slice * LDS_AB;
   unsigned* const sm = reinterpret_cast<unsigned*>(smem);
   constexpr int PA_HI = 0, PA_LO = 2 * BM * 16, PB_HI = 4 * BM * 16, PB_LO = 4 * BM * 16 + 2 * BN * 16;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int tiles_n = (a.Cg + BN - 1) / BN;
   // XCD-aware order.  The (channel tile, tap) workgroups of one pixel split all stream the same dy and x chunks; in
@@ -1499,9 +1518,11 @@ __global__ __launch_bounds__(256)
   const int g = bz / a.split_k, split = bz % a.split_k;
   const int oc0 = tile_m * BM, c0 = tile_n * BN;
 
-  const int per = (a.chunks + a.split_k - 1) / a.split_k;
-  const int ch_begin = split * per, ch_end = min(a.chunks, ch_begin + per);
+  // (KS = 2: split_k counts workgroups; the pixel range is cut into KS * split_k runs, two neighbours per workgroup)
+  const int per = (a.chunks + KS * a.split_k - 1) / (KS * a.split_k);
+  const int ch_begin = min(a.chunks, (split * KS + slice) * per), ch_end = min(a.chunks, ch_begin + per);
   const int nk = ch_end - ch_begin;
+  const int nk_loop = KS == 1 ? nk : min(per, a.chunks - min(a.chunks, split * KS * per));   // slice 0's count: the longer one
 
   const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
 
@@ -1552,6 +1573,7 @@ __global__ __launch_bounds__(256)
   float4 ra0[4], rb0[4], ra1[4], rb1[4];
   constexpr bool ALL_A = QA == 32, ALL_B = QB == 32;     // 256 threads = QA/16 x 8 runs: every thread has a slot
   auto load_chunk = [&](bool live, float4 (&ra)[4], float4 (&rb)[4]) {
+    if (DBG >= 1) live = false;
 #pragma unroll
     for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, (live & a_act) ? a_off + i * a_pix : OOB_OFF);   // rows >= M: beyond dy
     a_off += a_step;
@@ -1576,6 +1598,11 @@ __global__ __launch_bounds__(256)
   const int wa_sw = (((pra >> 1) ^ ((qa >> 2) & 3)) << 2) | ((pra & 1) << 1);
   const int wb_sw = (((prb >> 1) ^ ((qb >> 2) & 3)) << 2) | ((prb & 1) << 1);
   auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[4]) {
+    if (DBG >= 2) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].w), "v"(rb[i].x), "v"(rb[i].w));
+      return;
+    }
     if (ALL_A || pra < 8) {
       const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
                             make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
@@ -1640,10 +1667,12 @@ __global__ __launch_bounds__(256)
   auto step = [&](int it, int cur, float4 (&la)[4], float4 (&lb)[4], const float4 (&sa)[4], const float4 (&sb)[4]) {
     load_chunk(it + 2 < nk, la, lb);
     Frag f0, f1;
-    fetch(cur, 0, f0);
+    fetch(DBG >= 3 ? 0 : cur, 0, f0);
+    if (DBG >= 3) asm volatile("" : "+v"(f0.ah[0]), "+v"(f0.bh[0]));
     mfma3(f0);
     store_chunk(cur ^ 1, sa, sb);
-    fetch(cur, 1, f1);
+    fetch(DBG >= 3 ? 0 : cur, 1, f1);
+    if (DBG >= 3) asm volatile("" : "+v"(f1.ah[0]), "+v"(f1.bh[0]));
     mfma3(f1);
     // issue order: the first half's operand reads, then one MFMA per gap with its share of the VALU work (pixel walk,
     // offsets, bf16 split), the loads in the first gaps, the LDS stores spread evenly, and the second half's operand
@@ -1703,33 +1732,43 @@ __global__ __launch_bounds__(256)
   store_chunk(0, ra0, rb0);
   load_chunk(nk > 1, ra1, rb1);
   __syncthreads();
-  for (int it = 0; it < nk; it += 2) {
+  // (a step past the slice's own range multiplies a chunk of zeros: both slices run slice 0's trip count, barriers match)
+  for (int it = 0; it < nk_loop; it += 2) {
     step(it, 0, ra0, rb0, ra1, rb1);
-    if (it + 1 < nk) step(it + 1, 1, ra1, rb1, ra0, rb0);
+    if (it + 1 < nk_loop) step(it + 1, 1, ra1, rb1, ra0, rb0);
   }
 
   // un-permute through LDS: accumulator row R holds output channel (R % QA) * 4 + R / QA, column C input channel
   // (C % QB) * 4 + C / QB
-  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem);
+  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem_all);
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  if (KS > 1) __syncthreads();                    // the tile image overlaps the other slice's operand buffers
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int pass = KS - 1; pass >= 0; --pass) {    // KS = 2: slice 1 lays its tile down, slice 0 adds its own onto it
+    if (slice == pass) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int C = wn * WTN + j * 32 + ecol;
-      const int cl = (C % QB) * 4 + C / QB;
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int R = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
-        Cs[(R % QA) * 4 + R / QA][cl] = acc[i][j][e];
-      }
+        for (int j = 0; j < TN; ++j) {
+          const int C = wn * WTN + j * 32 + ecol;
+          const int cl = (C % QB) * 4 + C / QB;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int R = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+            float* const q = &Cs[(R % QA) * 4 + R / QA][cl];
+            *q = pass == KS - 1 ? acc[i][j][e] : *q + acc[i][j][e];
+          }
+        }
     }
-  __syncthreads();
+    __syncthreads();
+  }
   if (a.debug_nostore) return;
+  constexpr int NT = 256 * KS;
+  const int t_all = threadIdx.x;
   if (a.slab || a.split_k == 1) {
     // plain 16-byte accesses: into this split's slab plane, or (a single split: the tile's only writer) added to dw
     float* const base = a.slab ? a.slab + (size_t)split * a.slab_stride : a.dw;
-    for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+    for (int idx = t_all; idx < BM * (BN / 4); idx += NT) {
       const int row = idx / (BN / 4), col = (idx - row * (BN / 4)) * 4;
       const int ocl = oc0 + row, cl = c0 + col;
       if (ocl >= a.OCg || cl >= a.Cg) continue;
@@ -1743,7 +1782,7 @@ __global__ __launch_bounds__(256)
     }
     return;
   }
-  for (int idx = tid; idx < BM * BN; idx += 256) {
+  for (int idx = t_all; idx < BM * BN; idx += NT) {
     const int row = idx / BN, col = idx - row * BN;
     const int ocl = oc0 + row, cl = c0 + col;
     if (ocl < a.OCg && cl < a.Cg)
@@ -2006,6 +2045,8 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
   const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
                    (((uintptr_t)a.wm & 15) == 0);
   static const int swz = env_int("CPM_IGEMM_XCD", 1);
+  static const int idbg = env_int("CPM_IGEMM_DBG", 0);
+  a.dbg = idbg;
   static const int tail_split = env_int("CPM_IGEMM_TAIL", 1);
   a.xcd_swizzle = swz;
   a.m_base = 0;
@@ -2413,7 +2454,7 @@ CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float*
 }
 
 // tile and reduction split of a weight-gradient problem (shared by the launcher and the workspace query)
-struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; };
+struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; int ks = 1; };   // ks: pixel runs per workgroup (wgrad_split_kernel)
 
 static WgradArgs wgrad_args(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias) {
   WgradArgs a = {};
@@ -2439,17 +2480,18 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   // 0.78 of a full one's time (a workgroup alone on a CU has the MFMA pipes to itself).  The earlier model (rounds / sk,
   // i.e. no fixed cost) split the RoI-head and layer4 gradients 3-4x too deep: 576x576x3x3 over 64 RoIs 155 -> 107 us,
   // 512x512x3x3 88 -> 60 us, fc6 232 -> 169 us.
-  auto split_for = [&](int64_t nb, int per_cu) {
-    const int64_t slots = (int64_t)per_cu * num_cus();
+  auto split_for = [&](int64_t nb, int per_cu, int ks = 1) {
+    static const int fill = env_int("CPM_WGRAD_FILL", 100);      // percent of the chip's slots a launch plans for
+    const int64_t slots = (int64_t)per_cu * num_cus() * fill / 100;
     const int maxs = a.chunks / 8 > 0 ? (a.chunks / 8 > 256 ? 256 : a.chunks / 8) : 1;
-    const double fixed = per_cu == 2 ? 9.0 : 5.0;
+    const double fixed = (per_cu == 2 || ks == 2) ? 9.0 : 5.0;
     int best = 1;
     double best_cost = 1e30;
     for (int sk = 1; sk <= maxs; ++sk) {
       const int64_t nblk = nb * sk;
       const int64_t full = nblk / slots, tail = nblk % slots;
       const double rounds = (double)full + (tail == 0 ? 0.0 : (tail * 2 <= slots ? 0.78 : 1.0));
-      const double cost = rounds * ((double)cpm::cdiv(a.chunks, sk) + fixed);
+      const double cost = rounds * ((double)cpm::cdiv(a.chunks, sk * ks) + fixed);
       if (cost < best_cost - 1e-9) { best_cost = cost; best = sk; }
     }
     return best;
@@ -2469,9 +2511,21 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
     p = {64, 64, 2, 2, 1, false};
   }
   // (64x64 tiles on the 1x1 layers, to quarter the atomic bytes of their 32-way splits: measured 15 % slower)
-  p.split = split_for(blocks(p.bm, p.bn), p.bm * p.bn >= 128 * 128 ? 2 : 4);
-  if (const int forced = env_int("CPM_WGRAD_SPLIT", 0)) p.split = forced < a.chunks ? forced : a.chunks;   // sweeps
   p.bf16 = wvec && g_conv_split && p.bm % 64 == 0 && p.bn % 64 == 0;
+  // Eight waves in two pixel runs per workgroup (KS = 2) where the launch is made of partial tiles: few output tiles,
+  // deep splits.  tools/sweep_wgrad.py on MI355X, best split of either form: 256->1024 1x1 on 50x84 37.8 -> 34.4 us,
+  // 128->512 1x1 on 100x168 43.9 -> 36.2, 512->2048 1x1 on 25x42 36.3 -> 33.5, 256->256 3x3 on 50x84 54.4 -> 49.9;
+  // from ~90 tiles on the two forms tie, from 144 on (512->512 3x3 on 25x42 56.8 vs 64.5; 576->576 3x3 on 105 RoIs
+  // 141 vs 153; fc6 124 vs 147) and on the long 36-tile reductions of P2 (523 vs 529) four-wave workgroups win.
+  static const int env_ks = env_int("CPM_WGRAD_KS", 2);
+  const int64_t nb = blocks(p.bm, p.bn);
+  if (p.bf16 && p.bm == 128 && p.bn == 128 && env_ks == 2 && a.chunks >= 32 && nb <= 64 && !(nb >= 16 && a.chunks >= 2048)) {
+    p.ks = 2;                           // the same waves per CU, half the partial tiles
+    p.split = split_for(nb, 1, 2);
+  } else {
+    p.split = split_for(nb, p.bm * p.bn >= 128 * 128 ? 2 : 4);
+  }
+  if (const int forced = env_int("CPM_WGRAD_SPLIT", 0)) p.split = forced < a.chunks ? forced : a.chunks;   // sweeps
   return p;
 }
 
@@ -2556,9 +2610,16 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
     a.slab_stride = plane;
   }
   dim3 grid((unsigned)(cpm::cdiv(a.OCg, p.bm) * cpm::cdiv(a.Cg, p.bn)), taps, a.groups * a.split_k);
+  static const int wdbg = env_int("CPM_WGRAD_DBG", 0);
 #define WCASE(BM, BN, WM, WN)                                                                        \
   if (p.bm == BM && p.bn == BN) {                                                                    \
-    if (p.bf16)                                                                                      \
+    if (p.bf16 && wdbg && BM == 128 && BN == 128) {                                                  \
+      if (wdbg == 1) hipLaunchKernelGGL((wgrad_split_kernel<128, 128, 2, 2, 1>), grid, dim3(256), 0, s, a);      \
+      else if (wdbg == 2) hipLaunchKernelGGL((wgrad_split_kernel<128, 128, 2, 2, 2>), grid, dim3(256), 0, s, a); \
+      else hipLaunchKernelGGL((wgrad_split_kernel<128, 128, 2, 2, 3>), grid, dim3(256), 0, s, a);                \
+    } else if (p.bf16 && p.ks == 2 && BM == 128 && BN == 128)                                        \
+      hipLaunchKernelGGL((wgrad_split_kernel<128, 128, 2, 2, 0, 2>), grid, dim3(512), 0, s, a);      \
+    else if (p.bf16)                                                                                 \
       hipLaunchKernelGGL((wgrad_split_kernel<(BM) % 64 == 0 ? BM : 64, (BN) % 64 == 0 ? BN : 64, 2, 2>), grid, \
                          dim3(256), 0, s, a);                                                        \
     else if (wvec)                                                                                   \
