@@ -1791,6 +1791,342 @@ __global__ __launch_bounds__(256 * KS)
   }
 }
 
+// ---- weight gradient of a 3x3 / stride-1 / pad-1 convolution: the three taps of one filter row per workgroup ---------
+// wgrad_split_kernel gives every (channel tile, tap) its own workgroup: the nine taps of a tile stream the same dy rows
+// and (shifted) x rows, and split every value they load into bf16 hi/lo again.  Timing-only ablations of that kernel
+// (tools/wgrad_dbg.sh) put 29 % of a long reduction into that traffic and 23 % into the split + LDS stores, with the
+// MFMA-only loop at 0.77 of the bf16x3 peak.  Here a workgroup (128 output channels x 64 input channels) takes the three
+// taps s = 0, 1, 2 of ONE filter row r: per 32-pixel chunk it loads the dy rows once and 32 NEW x pixels (the window of
+// the three taps is 34 pixels; 32 of them were loaded by the previous chunk), for 36 MFMAs per wave instead of 24 --
+// loaded bytes and split work per MFMA halve.
+//   * dy: the channel-major image of wgrad_split_kernel (transposed in registers, ds_read_b128 operands), shared by
+//     the three taps.
+//   * x: a RING of pixel rows in LDS ([pixel][hi 64 ch | lo 64 ch | pad], 320-byte pitch: four consecutive rows x 64 B
+//     fall on disjoint banks, no swizzle, so a row's address is linear and a tap shift is an offset immediate), read as
+//     MFMA B operands by ds_read_b64_tr_b16 (four rows x 16 channels per 16-lane group, delivered channel-major).
+//     The ring holds the PADDED pixel stream: one zero row behind every image row, so that tap s = 0 of a row's first
+//     pixel and tap s = 2 of its last one read zeros without any masking in the loop; x rows that the filter row r
+//     takes outside the image are masked where they are loaded (they are then zero for all three taps).  Rows 128,
+//     129 mirror rows 0, 1 (written twice) so that a read never wraps.
+//   * the accumulators (3 taps x 64 x 32 per wave = 96 registers) leave through LDS one tap after the other.
+// Requires groups == 1 layout rules checked by taps_eligible(); everything else stays on wgrad_split_kernel.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) v4i16_t* lds_v4i16_p;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgrad_taps_kernel(WgradArgs a) {
+  constexpr int BM = 128, BN = 64, WN = 2, WTM = 64, WTN = 32, TM = 2;
+  constexpr int QA = BM / 4;
+  constexpr int NR = 128, ROWB = 320;                     // ring rows, bytes per ring row
+  constexpr int A_BYTES = 4 * BM * 16 * 4;                // hi + lo planes, two buffers: 32 KB
+  constexpr int RING_BYTES = (NR + 2) * ROWB;
+  constexpr int CP = BN + 4;
+  static_assert(A_BYTES + RING_BYTES >= BM * CP * 4, "epilogue staging fits");
+  __shared__ __attribute__((aligned(16))) unsigned char smem_b[A_BYTES + RING_BYTES];
+  unsigned* const sm = reinterpret_cast<unsigned*>(smem_b);
+  unsigned char* const ring = smem_b + A_BYTES;
+  constexpr int PA_HI = 0, PA_LO = 2 * BM * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = a.Cg / BN;
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd_swizzle) {                                     // whole splits per XCD, see wgrad_split_kernel
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int lin = bx + gx * (by + gy * bz), nwg = gx * gy * gridDim.z;
+    const int q = nwg >> 3, rr = nwg & 7, xcd = lin & 7;
+    const int l2 = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (lin >> 3);
+    bx = l2 % gx;
+    by = (l2 / gx) % gy;
+    bz = l2 / (gx * gy);
+  }
+  const int tile_m = bx / tiles_n, tile_n = bx % tiles_n;
+  const int r = by;                                        // filter row of this workgroup
+  const int g = bz / a.split_k, split = bz % a.split_k;
+  const int oc0 = tile_m * BM, c0 = tile_n * BN;
+  const int W = a.OW, H = a.OH;
+
+  const int per = (a.chunks + a.split_k - 1) / a.split_k;
+  const int ch_begin = min(a.chunks, split * per), ch_end = min(a.chunks, ch_begin + per);
+  const int nk = ch_end - ch_begin;
+  const int m_begin = ch_begin * 32;
+
+  const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x, a.x_bytes), rs_dy = make_rsrc(a.dy, a.dy_bytes);
+
+  // ---- dy (A operand): as wgrad_split_kernel -- a thread owns one 4-channel vector x 4 consecutive pixels
+  const int l16 = tid & 15, half_run = (tid >> 4) & 1, hi8 = tid >> 5;
+  const int qa = (hi8 % (QA / 16)) * 16 + l16, pra = (hi8 / (QA / 16)) * 2 + half_run;
+  const bool a_act = oc0 + 4 * qa < a.OCg;
+  unsigned a_off = (unsigned)((m_begin + 4 * pra) * a.OCtot + g * a.OCg + oc0 + 4 * qa) * 4u;
+  const unsigned a_step = (unsigned)(32 * a.OCtot) * 4u, a_pix = (unsigned)a.OCtot * 4u;
+  asm volatile("" : "+v"(a_off));
+  const int wa_sw = (((pra >> 1) ^ ((qa >> 2) & 3)) << 2) | ((pra & 1) << 1);
+
+  // ---- x (B operand): the pixel stream.  Stream index t <-> centre pixel mc = m_begin - 1 + t (an output pixel whose
+  // tap s = 1 reads this x pixel), x pixel f = mc + (r - 1) W, ring row (t + image rows crossed since t = 0) mod NR.
+  // A thread loads pixels t = 2 + prow + 16 i + 32 j (i = 0, 1) of step j, channels 4 cq .. 4 cq + 3.
+  const int dwid = 32 % W, dh = 32 / W;
+  const int b0 = m_begin - 1 + W;                          // (b0 + t) / W - 1 = image row (over all images) of mc
+  const int row0 = b0 / W;
+  const int t_lim = a.M - m_begin + 1;                     // mc < M  <=>  t < t_lim
+  const unsigned x_step = (unsigned)(32 * a.Ctot) * 4u;
+  const int prow = tid >> 4, cq = tid & 15;
+  int l_iw[2], l_oh[2], l_R[2], l_t[2];
+  unsigned l_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int t = 2 + prow + 16 * i, z = b0 + t;
+    const int rowz = z / W;
+    l_t[i] = t;
+    l_iw[i] = z - rowz * W;
+    l_oh[i] = (rowz - 1 + H) % H;                          // rowz - 1 >= 0 here (t >= 2 > ... only t = 0 can be row -1)
+    l_R[i] = (t + rowz - row0) & (NR - 1);
+    l_off[i] = (unsigned)((m_begin - 1 + t + (r - 1) * W) * a.Ctot + g * a.Cg + c0 + 4 * cq) * 4u;
+  }
+  auto x_valid = [&](int t, int oh) {                      // the filter row stays inside the image, the pixel exists
+    return (t < t_lim) & ((unsigned)(oh + r - 1) < (unsigned)H);
+  };
+
+  // register sets: chunk t+2 in flight, chunk t+1 waiting for its LDS store (ring row and last-column flag travel
+  // with the values: the walk has moved on by the time they are stored)
+  float4 ra0[4], ra1[4], rb0[2], rb1[2];
+  int mt0[2], mt1[2];
+  auto load_chunk = [&](bool live, float4 (&ra)[4], float4 (&rb)[2], int (&mt)[2]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, (live & a_act) ? a_off + i * a_pix : OOB_OFF);
+    a_off += a_step;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = live & x_valid(l_t[i], l_oh[i]);
+      unsigned off = ok ? l_off[i] : OOB_OFF;
+      asm volatile("" : "+v"(off));
+      rb[i] = bload4(rs_x, off);
+      mt[i] = l_R[i] | (l_iw[i] == W - 1 ? 256 : 0);
+      l_t[i] += 32;
+      l_off[i] += x_step;
+      l_iw[i] += dwid;
+      const bool cw = l_iw[i] >= W;
+      l_iw[i] -= cw ? W : 0;
+      const int adv = dh + (cw ? 1 : 0);
+      l_oh[i] += adv;
+      l_oh[i] -= l_oh[i] >= H ? H : 0;
+      l_R[i] = (l_R[i] + 32 + adv) & (NR - 1);
+    }
+  };
+  auto store_x = [&](const float4 v, int meta) {           // one pixel's 4 channels -> hi / lo of its ring row
+    uint2 hi, lo;
+    split4(v, hi, lo);
+    const int R = meta & 255;
+    unsigned char* const p = ring + R * ROWB + cq * 8;
+    *(uint2*)p = hi;
+    *(uint2*)(p + 128) = lo;
+    if (R < 2) {
+      *(uint2*)(p + NR * ROWB) = hi;
+      *(uint2*)(p + NR * ROWB + 128) = lo;
+    }
+    if (meta & 256) {                                      // last pixel of an image row: the zero row behind it
+      const int Rz = (R + 1) & (NR - 1);
+      unsigned char* const z = ring + Rz * ROWB + cq * 8;
+      const uint2 zero = make_uint2(0u, 0u);
+      *(uint2*)z = zero;
+      *(uint2*)(z + 128) = zero;
+      if (Rz < 2) {
+        *(uint2*)(z + NR * ROWB) = zero;
+        *(uint2*)(z + NR * ROWB + 128) = zero;
+      }
+    }
+  };
+  auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[2], const int (&mt)[2]) {
+    const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
+                          make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint2 hi, lo;
+      split4(ch[j], hi, lo);
+      const int o = (buf * BM + j * QA + qa) * 16 + wa_sw;
+      *(uint2*)(sm + PA_HI + o) = hi;
+      *(uint2*)(sm + PA_LO + o) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) store_x(rb[i], mt[i]);
+  };
+
+  // ---- MFMA side: a lane's four reduction pixels k = 16 h + 8 (lane >> 5) + 4 rd + q of the chunk (the rows whose
+  // addresses it supplies to the transposed reads), their column in the image row and their ring row minus one
+  const int g16 = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int lanecol = wn * 64 + ((g16 & 1) * 16 + 4 * p4) * 2;
+  int k_iw[2][2], k_Rb[2][2];
+  unsigned k_addr[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+      const int k = 16 * h + 8 * (lane >> 5) + 4 * rd + q4;
+      const int t = k + 1, z = b0 + t, rowz = z / W;
+      k_iw[h][rd] = z - rowz * W;
+      k_Rb[h][rd] = (t - 1 + rowz - row0) & (NR - 1);
+      k_addr[h][rd] = (unsigned)(k_Rb[h][rd] * ROWB + lanecol);
+    }
+  auto advance_k = [&]() {
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int rd = 0; rd < 2; ++rd) {
+        k_iw[h][rd] += dwid;
+        const bool cw = k_iw[h][rd] >= W;
+        k_iw[h][rd] -= cw ? W : 0;
+        k_Rb[h][rd] = (k_Rb[h][rd] + 32 + dh + (cw ? 1 : 0)) & (NR - 1);
+        k_addr[h][rd] = (unsigned)(k_Rb[h][rd] * ROWB + lanecol);
+      }
+  };
+
+  f32x16 acc[3][TM];
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[s3][i][e] = 0.f;
+
+  const int frow = lane & 31;
+  auto fetch_a = [&](int cur, int sub, bf16x8 (&ah)[TM], bf16x8 (&al)[TM]) {
+    const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
+      ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+  };
+  auto fetch_b = [&](int h, int s3, bf16x8& bh, bf16x8& bl) {
+    const unsigned char* const p0 = ring + k_addr[h][0] + s3 * ROWB;
+    const unsigned char* const p1 = ring + k_addr[h][1] + s3 * ROWB;
+    const v4i16_t h0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_p)p0);
+    const v4i16_t h1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_p)p1);
+    const v4i16_t l0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_p)(p0 + 128));
+    const v4i16_t l1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4i16_p)(p1 + 128));
+    typedef short v8i16_t __attribute__((ext_vector_type(8)));
+    const v8i16_t hh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+    const v8i16_t ll = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
+    bh = __builtin_bit_cast(bf16x8, hh);
+    bl = __builtin_bit_cast(bf16x8, ll);
+  };
+  auto half = [&](int cur, int h) {
+    bf16x8 ah[TM], al[TM];
+    fetch_a(cur, h, ah, al);
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+      bf16x8 bh, bl;
+      fetch_b(h, s3, bh, bl);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        acc[s3][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[s3][i], 0, 0, 0);
+        acc[s3][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[s3][i], 0, 0, 0);
+        acc[s3][i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[s3][i], 0, 0, 0);
+      }
+    }
+  };
+  auto step = [&](int it, int cur, float4 (&la)[4], float4 (&lb)[2], int (&lm)[2], const float4 (&sa)[4],
+                  const float4 (&sb)[2], const int (&smt)[2]) {
+    load_chunk(it + 2 < nk, la, lb, lm);
+    half(cur, 0);
+    store_chunk(cur ^ 1, sa, sb, smt);
+    half(cur, 1);
+    advance_k();
+    __syncthreads();
+  };
+
+  // bias gradient: the workgroups of filter row 0 / input-channel tile 0 (every dy element passes exactly one of them)
+  const bool do_bias = a.dshift != nullptr && r == 0 && tile_n == 0;
+  if (do_bias) {
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned o = a_off;
+    for (int it = 0; it < nk; ++it, o += a_step) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = bload4(rs_dy, a_act ? o + i * a_pix : OOB_OFF);
+      bsum.x += (v[0].x + v[1].x) + (v[2].x + v[3].x);
+      bsum.y += (v[0].y + v[1].y) + (v[2].y + v[3].y);
+      bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
+      bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
+    }
+    float* const sb = reinterpret_cast<float*>(smem_b);
+    *(float4*)&sb[pra * BM + 4 * qa] = bsum;
+    __syncthreads();
+    if (tid < BM && oc0 + tid < a.OCg) {
+      float t = 0.f;
+#pragma unroll
+      for (int p = 0; p < 8; ++p) t += sb[p * BM + tid];
+      atomicAdd(a.dshift + g * a.OCg + oc0 + tid, t);
+    }
+    __syncthreads();
+  }
+
+  // prologue: stream pixels t = 0, 1 (32 threads), chunk 0 into buffer 0, chunk 1 into the second register set
+  if (tid < 32) {
+    const int t = tid >> 4, z = b0 + t, rowz = z / W;
+    const int iw = z - rowz * W, mc = m_begin - 1 + t;
+    const int oh = (rowz - 1 + H) % H;
+    const bool ok = nk > 0 && mc >= 0 && x_valid(t, oh);
+    const unsigned off = (unsigned)((mc + (r - 1) * W) * a.Ctot + g * a.Cg + c0 + 4 * cq) * 4u;
+    const float4 v = bload4(rs_x, ok ? off : OOB_OFF);
+    store_x(v, ((t + rowz - row0) & (NR - 1)) | (iw == W - 1 ? 256 : 0));
+  }
+  load_chunk(nk > 0, ra0, rb0, mt0);
+  store_chunk(0, ra0, rb0, mt0);
+  load_chunk(nk > 1, ra1, rb1, mt1);
+  __syncthreads();
+  for (int it = 0; it < nk; it += 2) {
+    step(it, 0, ra0, rb0, mt0, ra1, rb1, mt1);
+    if (it + 1 < nk) step(it + 1, 1, ra1, rb1, mt1, ra0, rb0, mt0);
+  }
+
+  // the three taps' tiles leave through LDS one after the other; accumulator row R holds output channel
+  // (R % QA) * 4 + R / QA (the dy image's row order), columns are input channels in order
+  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem_b);
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  if (a.debug_nostore) {
+    float t = 0.f;
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) t += acc[s3][0][0] + acc[s3][1][15];
+    if (t == 12345.678f) a.dw[0] = t;
+    return;
+  }
+#pragma unroll
+  for (int s3 = 0; s3 < 3; ++s3) {
+    const int tap = r * 3 + s3;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int R = wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+        Cs[(R % QA) * 4 + R / QA][wn * WTN + ecol] = acc[s3][i][e];
+      }
+    __syncthreads();
+    if (a.slab || a.split_k == 1) {
+      float* const base = a.slab ? a.slab + (size_t)split * a.slab_stride : a.dw;
+      for (int idx = tid; idx < BM * (BN / 4); idx += 256) {
+        const int row = idx / (BN / 4), col = (idx - row * (BN / 4)) * 4;
+        const int ocl = oc0 + row, cl = c0 + col;
+        if (ocl >= a.OCg) continue;
+        float* p = base + ((size_t)(g * a.OCg + ocl) * 9 + tap) * a.Cg + cl;
+        float4 v = *(const float4*)&Cs[row][col];
+        if (a.row_scale) { const float rs = a.row_scale[g * a.OCg + ocl]; v.x *= rs; v.y *= rs; v.z *= rs; v.w *= rs; }
+        if (!a.slab) { const float4 o = *(const float4*)p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *(float4*)p = v;
+      }
+    } else {
+      for (int idx = tid; idx < BM * BN; idx += 256) {
+        const int row = idx / BN, col = idx - row * BN;
+        const int ocl = oc0 + row;
+        if (ocl < a.OCg)
+          atomicAdd(a.dw + ((size_t)(g * a.OCg + ocl) * 9 + tap) * a.Cg + c0 + col,
+                    a.row_scale ? Cs[row][col] * a.row_scale[g * a.OCg + ocl] : Cs[row][col]);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // dw += slab[0] + slab[1] + ... in split order (fixed association: bit-reproducible weight gradients)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, size_t stride,
                                                            int64_t n, float* __restrict__ dw) {
@@ -2454,7 +2790,7 @@ CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float*
 }
 
 // tile and reduction split of a weight-gradient problem (shared by the launcher and the workspace query)
-struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; int ks = 1; };   // ks: pixel runs per workgroup (wgrad_split_kernel)
+struct WgradPlan { int bm, bn, wm, wn, split; bool bf16; int ks = 1; bool taps = false; };   // ks: pixel runs per workgroup (wgrad_split_kernel)
 
 static WgradArgs wgrad_args(const cpm_conv_desc* d, const float* x, const float* dy, float* dw, float* dbias) {
   WgradArgs a = {};
@@ -2497,6 +2833,23 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
     return best;
   };
   WgradPlan p;
+  // three taps per workgroup (wgrad_taps_kernel): 3x3 / stride 1 / pad 1, whole 64-channel input tiles
+  static const int env_taps = env_int("CPM_WGRAD_TAPS", 1);
+  if (env_taps && wvec && g_conv_split && a.R == 3 && a.S == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 &&
+      a.groups == 1 && a.Cg % 64 == 0 && a.OCg >= 128 && a.IH == a.OH && a.IW == a.OW && a.OW >= 3 &&
+      a.OH >= 32 / a.OW + 2 && a.chunks >= 8) {
+    // ... where a workgroup keeps a reduction of >= CPM_WGRAD_TAPS_MIN chunks: its three tiles (96 KB of partial sums,
+    // against 64 KB per tap workgroup) make thin launches atomics-bound sooner than wgrad_split_kernel's
+    static const int taps_min = env_int("CPM_WGRAD_TAPS_MIN", 16);
+    const int sk = split_for((int64_t)cpm::cdiv(a.OCg, 128) * (a.Cg / 64) * 3, 2);
+    if (env_taps == 2 || a.chunks / sk >= taps_min) {
+      p = {128, 64, 2, 2, 1, true};
+      p.taps = true;
+      p.split = sk;
+      if (const int forced = env_int("CPM_WGRAD_SPLIT", 0)) p.split = forced < a.chunks ? forced : a.chunks;
+      return p;
+    }
+  }
   if (a.OCg <= 32 || a.Cg <= 32) {
     if (a.OCg <= 32 && a.Cg > 32) p = {32, 128, 1, 4, 1, false};
     else if (a.Cg <= 32 && a.OCg > 32) p = {128, 32, 4, 1, 1, false};
@@ -2608,6 +2961,19 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
       ((uintptr_t)workspace & 15) == 0) {
     a.slab = (float*)workspace;
     a.slab_stride = plane;
+  }
+  if (p.taps) {
+    dim3 tgrid((unsigned)(cpm::cdiv(a.OCg, 128) * (a.Cg / 64)), 3, a.groups * a.split_k);
+    hipLaunchKernelGGL(wgrad_taps_kernel, tgrid, dim3(256), 0, s, a);
+    int rc = cpm::check_launch("conv wgrad (three taps per workgroup)");
+    if (rc == CPM_OK && a.slab) {
+      const int64_t n = (int64_t)dw_elems;
+      int64_t b = (n / 4 + 255) / 256;
+      b = b < 1 ? 1 : (b > 4096 ? 4096 : b);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)b), dim3(256), 0, s, a.slab, a.split_k, a.slab_stride, n, dw);
+      rc = cpm::check_launch("conv wgrad reduce");
+    }
+    return rc;
   }
   dim3 grid((unsigned)(cpm::cdiv(a.OCg, p.bm) * cpm::cdiv(a.Cg, p.bn)), taps, a.groups * a.split_k);
   static const int wdbg = env_int("CPM_WGRAD_DBG", 0);
