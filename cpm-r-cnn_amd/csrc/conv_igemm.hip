@@ -1820,11 +1820,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int A_BYTES = 4 * BM * 16 * 4;                // hi + lo planes, two buffers: 32 KB
   constexpr int RING_BYTES = (NR + 2) * ROWB;
   constexpr int CP = BN + 4;
-  static_assert(A_BYTES + RING_BYTES >= BM * CP * 4, "epilogue staging fits");
-  __shared__ __attribute__((aligned(16))) unsigned char smem_b[A_BYTES + RING_BYTES];
-  unsigned* const sm = reinterpret_cast<unsigned*>(smem_b);
-  unsigned char* const ring = smem_b + A_BYTES;
-  constexpr int PA_HI = 0, PA_LO = 2 * BM * 16;
+  static_assert(RING_BYTES >= BM * CP * 4, "epilogue staging fits into the ring");
+  // three separate objects: the compiler then knows that the stores into the idle dy buffer cannot alias the operand
+  // reads of the live one, and schedules those reads freely around them
+  __shared__ __attribute__((aligned(16))) unsigned smA0[A_BYTES / 8];     // [hi | lo][128 rows][16 dwords]
+  __shared__ __attribute__((aligned(16))) unsigned smA1[A_BYTES / 8];
+  __shared__ __attribute__((aligned(16))) unsigned char ring[RING_BYTES];
+  constexpr int PA_LO = BM * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -1863,91 +1865,100 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
   // ---- x (B operand): the pixel stream.  Stream index t <-> centre pixel mc = m_begin - 1 + t (an output pixel whose
   // tap s = 1 reads this x pixel), x pixel f = mc + (r - 1) W, ring row (t + image rows crossed since t = 0) mod NR.
-  // A thread loads pixels t = 2 + prow + 16 i + 32 j (i = 0, 1) of step j, channels 4 cq .. 4 cq + 3.
+  // A thread loads ONE pixel per step, t = 2 + (tid >> 3) + 32 j, and eight of its channels (two 16-byte loads: one
+  // walk of the pixel's position per 32 bytes).
   const int dwid = 32 % W, dh = 32 / W;
   const int b0 = m_begin - 1 + W;                          // (b0 + t) / W - 1 = image row (over all images) of mc
   const int row0 = b0 / W;
   const int t_lim = a.M - m_begin + 1;                     // mc < M  <=>  t < t_lim
   const unsigned x_step = (unsigned)(32 * a.Ctot) * 4u;
-  const int prow = tid >> 4, cq = tid & 15;
-  int l_iw[2], l_oh[2], l_R[2], l_t[2];
-  unsigned l_off[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int t = 2 + prow + 16 * i, z = b0 + t;
+  const int prow = tid >> 3, cq = tid & 7;                 // channels 8 cq .. 8 cq + 7
+  int l_iw, l_oh, l_R, l_t;
+  unsigned l_off;
+  {
+    const int t = 2 + prow, z = b0 + t;
     const int rowz = z / W;
-    l_t[i] = t;
-    l_iw[i] = z - rowz * W;
-    l_oh[i] = (rowz - 1 + H) % H;                          // rowz - 1 >= 0 here (t >= 2 > ... only t = 0 can be row -1)
-    l_R[i] = (t + rowz - row0) & (NR - 1);
-    l_off[i] = (unsigned)((m_begin - 1 + t + (r - 1) * W) * a.Ctot + g * a.Cg + c0 + 4 * cq) * 4u;
+    l_t = t;
+    l_iw = z - rowz * W;
+    l_oh = (rowz - 1 + H) % H;
+    l_R = (t + rowz - row0) & (NR - 1);
+    l_off = (unsigned)((m_begin - 1 + t + (r - 1) * W) * a.Ctot + g * a.Cg + c0 + 8 * cq) * 4u;
   }
   auto x_valid = [&](int t, int oh) {                      // the filter row stays inside the image, the pixel exists
     return (t < t_lim) & ((unsigned)(oh + r - 1) < (unsigned)H);
   };
+  if (!a_act) a_off = 0x80000000u;                         // beyond dy for the whole walk (dy < 2 GiB: validate())
 
-  // register sets: chunk t+2 in flight, chunk t+1 waiting for its LDS store (ring row and last-column flag travel
-  // with the values: the walk has moved on by the time they are stored)
-  float4 ra0[4], ra1[4], rb0[2], rb1[2];
-  int mt0[2], mt1[2];
-  auto load_chunk = [&](bool live, float4 (&ra)[4], float4 (&rb)[2], int (&mt)[2]) {
+  // two register sets: chunk t+2 in flight, chunk t+1 (loaded a whole step ago) waiting for its LDS store; the ring row
+  // and last-column flag travel with the values (the walk has moved on by the time they are stored).  Loads past the
+  // workgroup's last chunk are not masked: what they fetch (zeros beyond the tensors, other rows inside) is stored but
+  // never multiplied.  (Measured and dropped: one register set re-loaded behind its store, and a sched_group_barrier
+  // issue pattern -- both within 5 % of the compiler's own order, the pattern with two sets 4-10 % slower.)
+  float4 ra[4], rb[2], ra2[4], rb2[2];
+  int mt, mt2;
+  auto load_chunk = [&](float4 (&ra)[4], float4 (&rb)[2], int& mt) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, (live & a_act) ? a_off + i * a_pix : OOB_OFF);
+    for (int i = 0; i < 4; ++i) ra[i] = bload4(rs_dy, a_off + i * a_pix);       // rows >= M: beyond dy
     a_off += a_step;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = live & x_valid(l_t[i], l_oh[i]);
-      unsigned off = ok ? l_off[i] : OOB_OFF;
-      asm volatile("" : "+v"(off));
-      rb[i] = bload4(rs_x, off);
-      mt[i] = l_R[i] | (l_iw[i] == W - 1 ? 256 : 0);
-      l_t[i] += 32;
-      l_off[i] += x_step;
-      l_iw[i] += dwid;
-      const bool cw = l_iw[i] >= W;
-      l_iw[i] -= cw ? W : 0;
-      const int adv = dh + (cw ? 1 : 0);
-      l_oh[i] += adv;
-      l_oh[i] -= l_oh[i] >= H ? H : 0;
-      l_R[i] = (l_R[i] + 32 + adv) & (NR - 1);
-    }
+    unsigned off = x_valid(l_t, l_oh) ? l_off : OOB_OFF - 16u;
+    asm volatile("" : "+v"(off));
+    rb[0] = bload4(rs_x, off);
+    rb[1] = bload4(rs_x, off + 16u);
+    mt = l_R | (l_iw == W - 1 ? 256 : 0);
+    l_t += 32;
+    l_off += x_step;
+    l_iw += dwid;
+    const bool cw = l_iw >= W;
+    l_iw -= cw ? W : 0;
+    const int adv = dh + (cw ? 1 : 0);
+    l_oh += adv;
+    l_oh -= l_oh >= H ? H : 0;
+    l_R = (l_R + 32 + adv) & (NR - 1);
   };
-  auto store_x = [&](const float4 v, int meta) {           // one pixel's 4 channels -> hi / lo of its ring row
-    uint2 hi, lo;
-    split4(v, hi, lo);
+  auto store_x = [&](const float4 v0, const float4 v1, int meta, uint4& hi, uint4& lo) {   // 8 channels -> the ring row
+    uint2 h0, l0, h1, l1;
+    split4(v0, h0, l0);
+    split4(v1, h1, l1);
+    hi = make_uint4(h0.x, h0.y, h1.x, h1.y);
+    lo = make_uint4(l0.x, l0.y, l1.x, l1.y);
+    unsigned char* const p = ring + (meta & 255) * ROWB + cq * 16;
+    *(uint4*)p = hi;
+    *(uint4*)(p + 128) = lo;
+  };
+  // the rare stores of a pixel, kept out of the step's straight-line block (one wave-uniform branch at its end): the
+  // mirror of ring rows 0 / 1 and the zero row behind the last pixel of an image row
+  auto store_x_rare = [&](const uint4 hi, const uint4 lo, int meta) {
     const int R = meta & 255;
-    unsigned char* const p = ring + R * ROWB + cq * 8;
-    *(uint2*)p = hi;
-    *(uint2*)(p + 128) = lo;
+    const bool need = (R < 2) | ((meta & 256) != 0);
+    if (!__any(need)) return;
     if (R < 2) {
-      *(uint2*)(p + NR * ROWB) = hi;
-      *(uint2*)(p + NR * ROWB + 128) = lo;
+      unsigned char* const p = ring + (R + NR) * ROWB + cq * 16;
+      *(uint4*)p = hi;
+      *(uint4*)(p + 128) = lo;
     }
-    if (meta & 256) {                                      // last pixel of an image row: the zero row behind it
+    if (meta & 256) {
       const int Rz = (R + 1) & (NR - 1);
-      unsigned char* const z = ring + Rz * ROWB + cq * 8;
-      const uint2 zero = make_uint2(0u, 0u);
-      *(uint2*)z = zero;
-      *(uint2*)(z + 128) = zero;
+      unsigned char* const z = ring + Rz * ROWB + cq * 16;
+      const uint4 zero = make_uint4(0u, 0u, 0u, 0u);
+      *(uint4*)z = zero;
+      *(uint4*)(z + 128) = zero;
       if (Rz < 2) {
-        *(uint2*)(z + NR * ROWB) = zero;
-        *(uint2*)(z + NR * ROWB + 128) = zero;
+        *(uint4*)(z + NR * ROWB) = zero;
+        *(uint4*)(z + NR * ROWB + 128) = zero;
       }
     }
   };
-  auto store_chunk = [&](int buf, const float4 (&ra)[4], const float4 (&rb)[2], const int (&mt)[2]) {
+  auto store_chunk = [&](int buf, const float4 (&ra)[4]) {
     const float4 ch[4] = {make_float4(ra[0].x, ra[1].x, ra[2].x, ra[3].x), make_float4(ra[0].y, ra[1].y, ra[2].y, ra[3].y),
                           make_float4(ra[0].z, ra[1].z, ra[2].z, ra[3].z), make_float4(ra[0].w, ra[1].w, ra[2].w, ra[3].w)};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       uint2 hi, lo;
       split4(ch[j], hi, lo);
-      const int o = (buf * BM + j * QA + qa) * 16 + wa_sw;
-      *(uint2*)(sm + PA_HI + o) = hi;
-      *(uint2*)(sm + PA_LO + o) = lo;
+      const int o = (j * QA + qa) * 16 + wa_sw;
+      *(uint2*)((buf ? smA1 : smA0) + o) = hi;
+      *(uint2*)((buf ? smA1 : smA0) + PA_LO + o) = lo;
     }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) store_x(rb[i], mt[i]);
   };
 
   // ---- MFMA side: a lane's four reduction pixels k = 16 h + 8 (lane >> 5) + 4 rd + q of the chunk (the rows whose
@@ -1992,9 +2003,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-      const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
-      ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
-      al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+      const int o = (wm * WTM + i * 32 + frow) * 16 + r_sw;
+      ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)((cur ? smA1 : smA0) + o));
+      al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)((cur ? smA1 : smA0) + PA_LO + o));
     }
   };
   auto fetch_b = [&](int h, int s3, bf16x8& bh, bf16x8& bl) {
@@ -2025,13 +2036,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   };
-  auto step = [&](int it, int cur, float4 (&la)[4], float4 (&lb)[2], int (&lm)[2], const float4 (&sa)[4],
-                  const float4 (&sb)[2], const int (&smt)[2]) {
-    load_chunk(it + 2 < nk, la, lb, lm);
+  auto step = [&](int cur, float4 (&la)[4], float4 (&lb)[2], int& lm, const float4 (&sa)[4], const float4 (&sb)[2], int smt) {
+    uint4 khi, klo;
+    load_chunk(la, lb, lm);                        // chunk t+2 goes out first, into the idle set
     half(cur, 0);
-    store_chunk(cur ^ 1, sa, sb, smt);
+    store_x(sb[0], sb[1], smt, khi, klo);          // chunk t+1: its x pixel first (the second half's ring reads must stay
+    store_chunk(cur ^ 1, sa);                      // behind this store), then dy into the idle buffer
     half(cur, 1);
     advance_k();
+    asm volatile("" : "+v"(k_addr[0][0]), "+v"(k_addr[0][1]), "+v"(k_addr[1][0]), "+v"(k_addr[1][1]), "+v"(l_off), "+v"(l_R),
+                 "+v"(l_oh), "+v"(l_iw));          // the walks belong into this block's MFMA gaps, not behind the branch
+    store_x_rare(khi, klo, smt);
     __syncthreads();
   };
 
@@ -2049,7 +2064,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       bsum.z += (v[0].z + v[1].z) + (v[2].z + v[3].z);
       bsum.w += (v[0].w + v[1].w) + (v[2].w + v[3].w);
     }
-    float* const sb = reinterpret_cast<float*>(smem_b);
+    float* const sb = reinterpret_cast<float*>(ring);
     *(float4*)&sb[pra * BM + 4 * qa] = bsum;
     __syncthreads();
     if (tid < BM && oc0 + tid < a.OCg) {
@@ -2061,28 +2076,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __syncthreads();
   }
 
-  // prologue: stream pixels t = 0, 1 (32 threads), chunk 0 into buffer 0, chunk 1 into the second register set
-  if (tid < 32) {
-    const int t = tid >> 4, z = b0 + t, rowz = z / W;
+  // prologue: stream pixels t = 0, 1 (16 threads), chunk 0 into buffer 0, chunk 1 into the second register set
+  if (tid < 16) {
+    const int t = tid >> 3, z = b0 + t, rowz = z / W;
     const int iw = z - rowz * W, mc = m_begin - 1 + t;
     const int oh = (rowz - 1 + H) % H;
-    const bool ok = nk > 0 && mc >= 0 && x_valid(t, oh);
-    const unsigned off = (unsigned)((mc + (r - 1) * W) * a.Ctot + g * a.Cg + c0 + 4 * cq) * 4u;
-    const float4 v = bload4(rs_x, ok ? off : OOB_OFF);
-    store_x(v, ((t + rowz - row0) & (NR - 1)) | (iw == W - 1 ? 256 : 0));
+    const bool ok = mc >= 0 && x_valid(t, oh);
+    const unsigned off = ok ? (unsigned)((mc + (r - 1) * W) * a.Ctot + g * a.Cg + c0 + 8 * cq) * 4u : OOB_OFF - 16u;
+    const float4 v0 = bload4(rs_x, off), v1 = bload4(rs_x, off + 16u);
+    const int meta = ((t + rowz - row0) & (NR - 1)) | (iw == W - 1 ? 256 : 0);
+    uint4 hi, lo;
+    store_x(v0, v1, meta, hi, lo);
+    store_x_rare(hi, lo, meta);
   }
-  load_chunk(nk > 0, ra0, rb0, mt0);
-  store_chunk(0, ra0, rb0, mt0);
-  load_chunk(nk > 1, ra1, rb1, mt1);
+  load_chunk(ra, rb, mt);
+  {
+    uint4 khi, klo;
+    store_x(rb[0], rb[1], mt, khi, klo);
+    store_x_rare(khi, klo, mt);
+    store_chunk(0, ra);
+  }
+  load_chunk(ra2, rb2, mt2);
   __syncthreads();
   for (int it = 0; it < nk; it += 2) {
-    step(it, 0, ra0, rb0, mt0, ra1, rb1, mt1);
-    if (it + 1 < nk) step(it + 1, 1, ra1, rb1, mt1, ra0, rb0, mt0);
+    step(0, ra, rb, mt, ra2, rb2, mt2);             // chunk it in LDS; chunk it+1 waits in set 2, it+2 is loaded into set 1
+    if (it + 1 < nk) step(1, ra2, rb2, mt2, ra, rb, mt);
   }
 
   // the three taps' tiles leave through LDS one after the other; accumulator row R holds output channel
   // (R % QA) * 4 + R / QA (the dy image's row order), columns are input channels in order
-  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(smem_b);
+  float (*Cs)[CP] = reinterpret_cast<float (*)[CP]>(ring);
   const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
   if (a.debug_nostore) {
     float t = 0.f;
@@ -2834,7 +2857,7 @@ static WgradPlan plan_wgrad(const WgradArgs& a, bool wvec) {
   };
   WgradPlan p;
   // three taps per workgroup (wgrad_taps_kernel): 3x3 / stride 1 / pad 1, whole 64-channel input tiles
-  static const int env_taps = env_int("CPM_WGRAD_TAPS", 1);
+  const int env_taps = env_int("CPM_WGRAD_TAPS", 1);          // read per call: 0 off, 1 by the rule below, 2 wherever eligible (tests)
   if (env_taps && wvec && g_conv_split && a.R == 3 && a.S == 3 && a.stride == 1 && a.dil == 1 && a.pad == 1 &&
       a.groups == 1 && a.Cg % 64 == 0 && a.OCg >= 128 && a.IH == a.OH && a.IW == a.OW && a.OW >= 3 &&
       a.OH >= 32 / a.OW + 2 && a.chunks >= 8) {

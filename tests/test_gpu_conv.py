@@ -355,6 +355,53 @@ def test_block_output_gate_applied_by_its_consumers(stride, side, monkeypatch):
     assert relerr(xg.grad, xr.grad) < tol
 
 
+TAP_CASES = [
+    # N, C, H, W, K: 3x3 / stride 1 / pad 1 layers the three-tap weight-gradient kernel is eligible for
+    (40, 64, 7, 7, 128),        # grid-head maps: five image rows per 32-pixel chunk
+    (3, 128, 13, 9, 192),       # ragged output-channel tile, M = 351 (not a multiple of 32)
+    (1, 64, 40, 50, 128),       # chunks straddle image rows
+    (4, 64, 33, 3, 128),        # the narrowest map the kernel takes
+    (2, 192, 21, 34, 320),
+]
+
+
+@pytest.mark.parametrize("case", TAP_CASES, ids=["%dx%dx%dx%d_%d" % c for c in TAP_CASES])
+@pytest.mark.parametrize("split", [0, 1, 3])
+def test_three_tap_weight_gradient(case, split, conv_math, monkeypatch):
+    """wgrad_taps_kernel (three taps of a filter row per workgroup, x as a ring of padded pixel rows) forced onto small
+    layers (CPM_WGRAD_TAPS=2) against torch: plain, with the bias sum, with the frozen row scale, accumulating, and in
+    deterministic mode (slab planes), for the planner's pixel split and forced ones (a split boundary inside an image row)."""
+    if conv_math != "bf16x3":
+        pytest.skip("the three-tap kernel is a bf16x3 kernel")
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    monkeypatch.setenv("CPM_WGRAD_TAPS", "2")
+    if split:
+        monkeypatch.setenv("CPM_WGRAD_SPLIT", str(split))
+    N, Cc, Hh, Ww, K = case
+    x = rnd(N, Cc, Hh, Ww, seed=1)
+    w = rnd(K, Cc, 3, 3, seed=2, scale=0.05)
+    dy = rnd(N, K, Hh, Ww, seed=3)
+    ks = rnd(K, seed=4).abs() + 0.5
+    dw_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy, 1, 1)
+    dws_ref = torch.nn.grad.conv2d_weight(x, w.shape, dy * ks.view(1, -1, 1, 1), 1, 1)
+    xd, dyd, wd = (t.cuda().contiguous(memory_format=CL) for t in (x, dy, w))
+    dw = C.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, 1)
+    assert relerr(dw, dw_ref) < TOL
+    C.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, 1, out=dw)                    # accumulates
+    assert relerr(dw, 2 * dw_ref) < TOL
+    db = torch.zeros(K, device="cuda")
+    dw2 = C.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, 1, dbias=db, k_scale=ks.cuda())
+    assert relerr(dw2, dws_ref) < TOL and relerr(db, dy.sum(dim=(0, 2, 3))) < TOL
+    _hip.set_deterministic(True)
+    try:
+        a = C.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, 1)
+        b = C.conv2d_backward_weight(xd, dyd, wd, 1, 1, 1, 1)
+    finally:
+        _hip.set_deterministic(False)
+    assert torch.equal(a, b) and relerr(a, dw_ref) < TOL
+
+
 def test_fused_dgrad_and_scaled_wgrad_kernels():
     """cpm_conv2d_backward_data_fused / cpm_conv2d_backward_weight_scaled against torch: k_scale inside the reductions,
     accumulate + gate = (acc + dx) * [act > 0], with and without the reduction split (a thin grid forces split-K)."""
