@@ -41,7 +41,10 @@ using namespace cpmconv;
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, bool VEC, bool SPLIT>
+// SPLIT: 0 = exact f32 MFMA, 1 = bf16x3 with both operands split in the kernel, 2 = bf16x3 with the WEIGHT operand given
+// as a pre-split image (a.wm points at it; cpm_split_w4: per four consecutive reduction elements 8 bytes of hi and 8
+// bytes of lo in place of their 16 bytes of f32 -- the same offsets, no conversion work on that side).
+template <int BM, int BN, int WM, int WN, bool VEC, int SPLIT>
 __global__ __launch_bounds__(64 * WM * WN)
     __attribute__((amdgpu_waves_per_eu(2, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))) void igemm_kernel(
         IgemmArgs a) {
@@ -198,7 +201,12 @@ __global__ __launch_bounds__(64 * WM * WN)
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         uint2 hi, lo;
-        split4(rb[i], hi, lo);
+        if (SPLIT == 2) {
+          hi = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+          lo = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
+        } else {
+          split4(rb[i], hi, lo);
+        }
         const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
         *(uint2*)(sm + PB_HI + o) = hi;
         *(uint2*)(sm + PB_LO + o) = lo;
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(64 * WM * WN)
       mfma3(f1);
       constexpr int NM = TM * TN * 3 * 2;                      // MFMAs of the step
       // VALU ops per MFMA gap: 12 per float4 for the split + ~4 per load for its offset and mask
-      constexpr int VPM = ((AP + BP) * 16 + NM - 1) / NM;
+      constexpr int VPM = ((AP + (SPLIT == 2 ? 0 : BP)) * 12 + (AP + BP) * 4 + NM - 1) / NM;
       constexpr int WEVERY = NM / (AP + BP) > 0 ? NM / (AP + BP) : 1;
       __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
 #pragma unroll
@@ -525,7 +533,7 @@ __global__ __launch_bounds__(64 * WM * WN)
 //   loads of tile t+1 into the same registers -> barrier -> all operand reads of tile t -> its 24 MFMAs,
 // which run in the pipe while the wave does the next step's split and stores.  32 KB of LDS and <= 168 VGPRs: three
 // workgroups per CU.  Epilogues that stage the tile through LDS (residual / staged) stay on igemm_kernel.
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool BPRE = false>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_s1_kernel(IgemmArgs a) {
   constexpr bool VEC = true, SPLIT = true;
   constexpr int NT = 64 * WM * WN;              // threads
@@ -675,7 +683,12 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(3,
 #pragma unroll
       for (int i = 0; i < BP; ++i) {
         uint2 hi, lo;
-        split4(rb[i], hi, lo);
+        if (BPRE) {
+          hi = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+          lo = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
+        } else {
+          split4(rb[i], hi, lo);
+        }
         const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
         *(uint2*)(sm + PB_HI + o) = hi;
         *(uint2*)(sm + PB_LO + o) = lo;
@@ -820,7 +833,7 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(3,
 // description supplies dy/dx per tap and the weight tap).  Conditions in halo_eligible().
 constexpr int HT_H = 8, HT_W = 16, HALO_W = HT_W + 2, HALO_ROWS = (HT_H + 2) * (HT_W + 2);     // 180 halo pixels
 
-template <int BN>
+template <int BN, bool BPRE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm3x3_kernel(IgemmArgs a) {
   constexpr int BM = HT_H * HT_W;                 // 128
   constexpr int WM = 2, WN = 2, WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -900,7 +913,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
       uint2 hi, lo;
-      split4(rb[i], hi, lo);
+      if (BPRE) {
+        hi = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+        lo = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
+      } else {
+        split4(rb[i], hi, lo);
+      }
       const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
       *(uint2*)(sm + PB_HI + o) = hi;
       *(uint2*)(sm + PB_LO + o) = lo;
@@ -1171,8 +1189,29 @@ __global__ void __launch_bounds__(256) seed_rows_kernel(float* __restrict__ out,
 // and ran at a fraction of the copy rate on the 12-29 M element FC weights).
 // k_scale ([groups*Kg] or null): the image of diag(k_scale) * W -- a frozen per-output-channel factor behind the conv
 // (AffineChannel2d) is then applied by the data gradient's reduction itself: dx = W^T (scale * g).
+// w4: the image is written pre-split (cpm_split_w4's format along k: Kg % 4 == 0), for the bf16x3 kernels.
+__device__ __forceinline__ void wt_store_tile(const float (&tile)[32][33], float* __restrict__ wt, int g, int Cg, int RS,
+                                              int t, int Kg, int c0, int k0, int w4) {
+  if (w4) {
+    const int cl = threadIdx.x >> 3, kq = (threadIdx.x & 7) * 4;       // one k-quad of one c row per thread
+    const int c = c0 + cl, k = k0 + kq;
+    if (c < Cg && k < Kg) {
+      uint2 hi, lo;
+      split4(make_float4(tile[kq][cl], tile[kq + 1][cl], tile[kq + 2][cl], tile[kq + 3][cl]), hi, lo);
+      *(uint4*)(wt + (((int64_t)(g * Cg + c)) * RS + t) * Kg + k) = make_uint4(hi.x, hi.y, lo.x, lo.y);
+    }
+    return;
+  }
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int j = 0; j < 32; j += 8) {
+    const int c = c0 + ty + j, k = k0 + tx;
+    if (c < Cg && k < Kg) wt[(((int64_t)(g * Cg + c)) * RS + t) * Kg + k] = tile[tx][ty + j];
+  }
+}
+
 __global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__ w, int groups, int Kg, int RS, int Cg,
-                                                       float* __restrict__ wt, const float* __restrict__ k_scale) {
+                                                       float* __restrict__ wt, const float* __restrict__ k_scale, int w4) {
   __shared__ float tile[32][33];
   const int tiles_c = (Cg + 31) / 32, tiles_k = (Kg + 31) / 32;
   const int64_t per_gt = (int64_t)tiles_c * tiles_k;
@@ -1193,11 +1232,7 @@ __global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__
       tile[ty + j][tx] = v;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 32; j += 8) {
-      const int c = c0 + ty + j, k = k0 + tx;
-      if (c < Cg && k < Kg) wt[(((int64_t)(g * Cg + c)) * RS + t) * Kg + k] = tile[tx][ty + j];
-    }
+    wt_store_tile(tile, wt, g, Cg, RS, t, Kg, c0, k0, w4);
     __syncthreads();
   }
 }
@@ -1207,7 +1242,7 @@ __global__ __launch_bounds__(256) void weight_to_dgrad(const float* __restrict__
 // its first 32x32 tile; a workgroup finds its weight by binary search over those tile starts.
 __global__ __launch_bounds__(256) void weights_to_dgrad_batched(const cpm_wt_desc* __restrict__ descs, int n,
                                                                 int64_t total_tiles, const float* __restrict__ src,
-                                                                float* __restrict__ dst) {
+                                                                float* __restrict__ dst, int w4_all) {
   __shared__ float tile[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   for (int64_t b = blockIdx.x; b < total_tiles; b += gridDim.x) {
@@ -1220,6 +1255,7 @@ __global__ __launch_bounds__(256) void weights_to_dgrad_batched(const cpm_wt_des
     const float* w = src + d.src_off;
     float* wt = dst + d.dst_off;
     const int Kg = d.Kg, Cg = d.Cg, RS = d.RS;
+    const int w4 = w4_all && (Kg & 3) == 0;                  // (a weight with Kg % 4 != 0 keeps the f32 image)
     const int tiles_c = (Cg + 31) / 32, tiles_k = (Kg + 31) / 32;
     int64_t r = b - d.tile_start;
     const int tcx = (int)(r % tiles_c); r /= tiles_c;
@@ -1235,11 +1271,7 @@ __global__ __launch_bounds__(256) void weights_to_dgrad_batched(const cpm_wt_des
       tile[ty + j][tx] = v;
     }
     __syncthreads();
-#pragma unroll
-    for (int j = 0; j < 32; j += 8) {
-      const int c = c0 + ty + j, k = k0 + tx;
-      if (c < Cg && k < Kg) wt[(((int64_t)(g * Cg + c)) * RS + t) * Kg + k] = tile[tx][ty + j];
-    }
+    wt_store_tile(tile, wt, g, Cg, RS, t, Kg, c0, k0, w4);
     __syncthreads();
   }
 }
@@ -2376,20 +2408,23 @@ int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t
   if ((s1 == 1 || (s1 == 2 && s1_wgs >= 3ll * num_cus())) && vec && g_conv_split && bm == 128 && bn == 128 && wn == 2 &&
       (a.atomic_out || !(a.res || a.staged_epi))) {
     dim3 grid((unsigned)(cpm::cdiv(rows, 128) * cpm::cdiv(a.OCg, 128)), a.groups, a.split_k);
-    hipLaunchKernelGGL((igemm_s1_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
+    if (a.b_presplit) hipLaunchKernelGGL((igemm_s1_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_s1_kernel<128, 128, 2, 2>), grid, dim3(256), 0, s, a);
     return cpm::check_launch("conv igemm (one LDS stage)");
   }
 #define LAUNCH(BM, BN, WM, WN)                                                                       \
   do {                                                                                               \
     dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);          \
-    if (vec && g_conv_split)                                                                               \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, true>), grid, dim3(64 * WM * WN), 0, s, a);   \
+    if (vec && g_conv_split && a.b_presplit)                                                               \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, 2>), grid, dim3(64 * WM * WN), 0, s, a);      \
+    else if (vec && g_conv_split)                                                                          \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, 1>), grid, dim3(64 * WM * WN), 0, s, a);      \
     else if (vec)                                                                                          \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, false>), grid, dim3(64 * WM * WN), 0, s, a);  \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, 0>), grid, dim3(64 * WM * WN), 0, s, a);      \
     else if (g_conv_split)                                                                                 \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, true>), grid, dim3(64 * WM * WN), 0, s, a);  \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, 1>), grid, dim3(64 * WM * WN), 0, s, a);     \
     else                                                                                                   \
-      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, false>), grid, dim3(64 * WM * WN), 0, s, a); \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, false, 0>), grid, dim3(64 * WM * WN), 0, s, a);     \
   } while (0)
   if (bm == 128 && bn == 128 && wn == 4) LAUNCH(128, 128, 2, 4);
   else if (bm == 128 && bn == 128) LAUNCH(128, 128, 2, 2);
@@ -2403,6 +2438,10 @@ int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t
 int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
   const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
                    (((uintptr_t)a.wm & 15) == 0);
+  if (a.b_presplit && !(vec && g_conv_split)) {
+    cpm::set_error("conv igemm: a pre-split weight image outside the bf16x3 vector path");
+    return CPM_EINVAL;
+  }
   static const int swz = env_int("CPM_IGEMM_XCD", 1);
   static const int idbg = env_int("CPM_IGEMM_DBG", 0);
   a.dbg = idbg;
@@ -2423,7 +2462,8 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
     const int64_t blocks = patches * cpm::cdiv(a.OCg, 128);
     static const int halo_min = env_int("CPM_IGEMM_HALO_MIN", 320);    // below ~1.25 workgroups per CU the generic kernel's finer tiles win (128 ch on 100x168: 64 -> 60 us)
     if (blocks >= halo_min) {
-      hipLaunchKernelGGL((igemm3x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      if (a.b_presplit) hipLaunchKernelGGL((igemm3x3_kernel<128, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((igemm3x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
       return cpm::check_launch("conv igemm 3x3 (halo)");
     }
   }
@@ -2524,8 +2564,10 @@ static float* slab_in(void* workspace, size_t bytes, size_t off, int split, size
 
 static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w, const void* w_sp,
                              const float* scale, const float* shift, const float* residual, int res_mode, int relu,
-                             float* y, void* y_sp, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0) {
+                             float* y, void* y_sp, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0,
+                             int w_presplit = 0) {
   IgemmArgs a = {};
+  a.b_presplit = w_presplit;
   a.in_sp = x_sp; a.wm_sp = w_sp; a.out_sp = y_sp;
   a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
   a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C;
@@ -2601,6 +2643,41 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
                            (hipStream_t)stream, workspace, workspace_bytes);
 }
 
+// y = epilogue(conv(x, W)) with W given as its pre-split image (cpm_split_w4 of the KRSC weight): bf16x3 arithmetic only
+CPM_EXPORT int cpm_conv2d_forward_w4(const cpm_conv_desc* d, const float* x, const void* w4, const float* scale,
+                                     const float* shift, const float* residual, int res_mode, int relu, float* y,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(x && w4 && y, "null pointer");
+  CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
+  CPM_REQUIRE(g_conv_split, "a pre-split weight image serves the bf16x3 arithmetic only (cpm_set_conv_math)");
+  CPM_REQUIRE((d->C / d->groups) % 4 == 0 && d->C % 4 == 0 && (((uintptr_t)x | (uintptr_t)w4) & 15) == 0,
+              "a pre-split weight image needs the vector path: channels per group % 4 == 0, 16-byte aligned operands");
+  return conv_forward_impl(d, x, nullptr, (const float*)w4, nullptr, scale, shift, residual, res_mode, relu, y, nullptr,
+                           (hipStream_t)stream, workspace, workspace_bytes, 1);
+}
+
+// hi / lo image of a float array for the weight side of the bf16x3 kernels: elements 4i .. 4i+3 -> 8 bytes of bf16 hi,
+// 8 bytes of bf16 lo (lo = bf16(x - hi)) at byte offset 16 i -- the offsets of the float array itself.  n % 4 == 0.
+__global__ __launch_bounds__(256) void split_w4_kernel(const float4* __restrict__ src, uint4* __restrict__ dst, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    uint2 hi, lo;
+    split4(src[i], hi, lo);
+    dst[i] = make_uint4(hi.x, hi.y, lo.x, lo.y);
+  }
+}
+
+CPM_EXPORT int cpm_split_w4(const float* src, void* dst, int64_t n, void* stream) {
+  CPM_REQUIRE(src && dst && n >= 0 && n % 4 == 0, "cpm_split_w4: n must be a multiple of 4");
+  CPM_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "cpm_split_w4: 16-byte aligned buffers");
+  if (n == 0) return CPM_OK;
+  const int64_t n4 = n / 4;
+  int64_t b = (n4 + 255) / 256;
+  b = b > 8192 ? 8192 : b;
+  hipLaunchKernelGGL(split_w4_kernel, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, (const float4*)src, (uint4*)dst, n4);
+  return cpm::check_launch("cpm_split_w4");
+}
+
 CPM_EXPORT int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w,
                                      const void* w_sp, const float* scale, const float* shift, const float* residual,
                                      int res_mode, int relu, float* y, void* y_sp, void* stream) {
@@ -2615,7 +2692,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
                      const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr,
                      bool prepared = false, const void* dy_sp = nullptr, const void* wt_sp = nullptr,
-                     void* dx_sp = nullptr, const float* k_scale = nullptr) {
+                     void* dx_sp = nullptr, const float* k_scale = nullptr, int prepared_w4 = 0) {
   const size_t need = dgrad_weight_bytes(d);
   if (!prepared && (!workspace || workspace_bytes < need)) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
@@ -2624,12 +2701,22 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   // prepared: `w` already is the [g][c][tap][k] image (cpm_weights_to_dgrad_batched)
   const float* wt = prepared ? w : (const float*)workspace;
   const int Cg = d->C / d->groups, Kg = d->K / d->groups;
+  // the weight side pre-split (bf16x3, vector path): an image made here is written that way, a prepared one says so
+  const bool vec_ok = Kg % 4 == 0 && d->K % 4 == 0 && (((uintptr_t)dy | (uintptr_t)wt) & 15) == 0;
+  static const int env_w4 = env_int("CPM_W4", 1);
+  const int w4 = prepared ? prepared_w4 : (env_w4 && g_conv_split && vec_ok && !dy_sp ? 1 : 0);
+  if (prepared_w4 && !(g_conv_split && vec_ok)) {
+    cpm::set_error("%s: a pre-split weight image needs the bf16x3 arithmetic and the vector path (K / groups %% 4 == 0, "
+                   "16-byte aligned operands)", who);
+    return CPM_EINVAL;
+  }
   if (!prepared) {
     const int64_t b = (int64_t)cpm::cdiv(Cg, 32) * cpm::cdiv(Kg, 32) * d->R * d->S * d->groups;
     hipLaunchKernelGGL(weight_to_dgrad, dim3((unsigned)(b > 16384 ? 16384 : b)), dim3(256), 0, s, w, d->groups, Kg,
-                       d->R * d->S, Cg, (float*)workspace, k_scale);
+                       d->R * d->S, Cg, (float*)workspace, k_scale, w4);
   }
   IgemmArgs a = {};
+  a.b_presplit = w4;
   if (prepared) { a.in_sp = dy_sp; a.wm_sp = wt_sp; }     // wt_sp: the SP form of the prepared [g][c][tap][k] image
   a.in = dy; a.wm = wt; a.out = dx; a.shift = shift; a.relu = relu;
   a.N = d->N; a.IH = d->P; a.IW = d->Q; a.Ctot = d->K;      // the GEMM's "input" is dy
@@ -2779,6 +2866,18 @@ CPM_EXPORT int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const f
                    "cpm_conv2d_backward_data_prepared", in_scale, in_act, true);
 }
 
+// the same with `wt4` = the pre-split image (cpm_weights_to_dgrad_batched_w4; K / groups % 4 == 0): bf16x3 arithmetic only
+CPM_EXPORT int cpm_conv2d_backward_data_prepared_w4(const cpm_conv_desc* d, const float* dy, const void* wt4, float* dx,
+                                                    int accumulate, const float* in_scale, const float* in_act,
+                                                    void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
+  CPM_REQUIRE(dy && wt4 && dx, "null pointer");
+  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
+  CPM_REQUIRE(!(accumulate && in_scale), "an accumulated data gradient takes a gate only: dx = (dx + W^T dy) * [act > 0]");
+  return run_dgrad(d, dy, (const float*)wt4, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
+                   "cpm_conv2d_backward_data_prepared_w4", in_scale, in_act, true, nullptr, nullptr, nullptr, nullptr, 1);
+}
+
 CPM_EXPORT int cpm_conv2d_backward_data_sp(const cpm_conv_desc* d, const float* dy, const void* dy_sp, const float* wt,
                                            const void* wt_sp, float* dx, void* dx_sp, int accumulate,
                                            const float* in_scale, const float* in_act, void* stream) {
@@ -2798,8 +2897,21 @@ CPM_EXPORT int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs, int n, i
   CPM_REQUIRE(d_descs && src_base && dst_base, "null pointer");
   const int64_t b = total_tiles > 65536 ? 65536 : total_tiles;
   hipLaunchKernelGGL(weights_to_dgrad_batched, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, d_descs, n,
-                     total_tiles, src_base, dst_base);
+                     total_tiles, src_base, dst_base, 0);
   return cpm::check_launch("weights_to_dgrad_batched");
+}
+
+// the same with the images written pre-split (weights with K / groups % 4 == 0; the others keep their f32 image):
+// what cpm_conv2d_backward_data_prepared_w4 takes
+CPM_EXPORT int cpm_weights_to_dgrad_batched_w4(const cpm_wt_desc* d_descs, int n, int64_t total_tiles,
+                                               const float* src_base, float* dst_base, void* stream) {
+  CPM_REQUIRE(n >= 0 && total_tiles >= 0, "bad counts");
+  if (n == 0 || total_tiles == 0) return CPM_OK;
+  CPM_REQUIRE(d_descs && src_base && dst_base && ((uintptr_t)dst_base & 15) == 0, "null / unaligned pointer");
+  const int64_t b = total_tiles > 65536 ? 65536 : total_tiles;
+  hipLaunchKernelGGL(weights_to_dgrad_batched, dim3((unsigned)b), dim3(256), 0, (hipStream_t)stream, d_descs, n,
+                     total_tiles, src_base, dst_base, 1);
+  return cpm::check_launch("weights_to_dgrad_batched_w4");
 }
 
 CPM_EXPORT int cpm_conv_transpose2d_forward(const cpm_conv_desc* d, const float* x, const float* w,

@@ -115,8 +115,12 @@ CPM_EXPORT int cpm_layer_chain_forward(const cpm_chain_layer* layers, int n_laye
     cpm_conv_desc d = L.conv;
     d.N = N;
     float* conv_out = at(fwd_base, off[i].conv_out, y);
-    int rc = cpm_conv2d_forward(&d, in, L.w, nullptr, L.bias, nullptr, 0, L.has_gn ? 0 : L.relu, conv_out, workspace,
-                                workspace_bytes, stream);
+    // (a pre-split image serves the bf16x3 arithmetic only: under the other one the float weights are read)
+    int rc = (L.w4 && cpm_get_conv_math() == CPM_MATH_BF16X3)
+                 ? cpm_conv2d_forward_w4(&d, in, L.w4, nullptr, L.bias, nullptr, 0, L.has_gn ? 0 : L.relu, conv_out, workspace,
+                                         workspace_bytes, stream)
+                 : cpm_conv2d_forward(&d, in, L.w, nullptr, L.bias, nullptr, 0, L.has_gn ? 0 : L.relu, conv_out, workspace,
+                                      workspace_bytes, stream);
     if (rc != CPM_OK) return rc;
     if (L.has_gn) {
       float* gn_out = at(fwd_base, off[i].gn_out, y);
@@ -178,7 +182,9 @@ CPM_EXPORT int cpm_layer_chain_backward(const cpm_chain_layer* layers, int n_lay
     if (d_in) {
       const float* gate = (i > 0 && !layers[i - 1].has_gn && layers[i - 1].relu) ? in : nullptr;
       const cpm_conv_desc dd = L.dgrad_flat ? flat_desc(d) : d;
-      if (L.wt)
+      if (L.wt && L.wt_w4 && cpm_get_conv_math() == CPM_MATH_BF16X3)
+        rc = cpm_conv2d_backward_data_prepared_w4(&dd, gc, L.wt, d_in, 0, nullptr, gate, workspace, workspace_bytes, stream);
+      else if (L.wt && !L.wt_w4)
         rc = cpm_conv2d_backward_data_prepared(&dd, gc, L.wt, d_in, 0, nullptr, gate, workspace, workspace_bytes, stream);
       else if (gate)
         rc = cpm_conv2d_backward_data_gated(&dd, gc, L.w, d_in, nullptr, gate, workspace, workspace_bytes, stream);

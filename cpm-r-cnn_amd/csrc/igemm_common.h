@@ -96,6 +96,7 @@ struct IgemmArgs {
   const void* in_sp;
   const void* wm_sp;
   void* out_sp;        // optional: the output written a second time in that format for the consuming convolution
+  int b_presplit;      // wm is a pre-split weight image (cpm_split_w4): bf16x3 arithmetic, vector path only
   int dbg;             // timing-only experiments (CPM_RING_DBG): 1 no DMA, 2 zero-record descriptors, 4 no operand reads
 };
 

@@ -1,6 +1,7 @@
 // HBM-bound helper kernels of the conv/GN stacks: epilogue backward, im2col for the stem,
 // max-pool, GroupNorm(+ReLU) forward/backward, FPN top-down backward, fused SGD.  NHWC, fp32, gfx950.
 #include "common.h"
+#include "igemm_common.h"
 
 namespace {
 
@@ -526,10 +527,11 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, 
 // the learning rate / weight decay, which travel as kernel arguments (no host->device copy when the schedule moves).
 struct SgdGroups { float lr[8]; float wd[8]; };
 
+// w4 (or null): the pre-split image of the updated parameters (cpm_split_w4's format), written with them
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                            const int32_t* __restrict__ block_seg, const int64_t* __restrict__ seg_end,
                            const int32_t* __restrict__ seg_group, SgdGroups grp, int64_t total, float momentum,
-                           float grad_scale, int first_step) {
+                           float grad_scale, int first_step, uint4* __restrict__ w4) {
   const int64_t nvec = total >> 2;
   for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = v << 2;
@@ -556,6 +558,11 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
       *(float4*)(buf + i) = bv;
     } else {
       for (int k = 0; k < 4 && i + k < end; ++k) { p[i + k] = pp[k]; buf[i + k] = bp[k]; }
+    }
+    if (w4) {                                   // (a tensor's last partial quad: its image is never read as a quad)
+      uint2 hi, lo;
+      cpmconv::split4(pv, hi, lo);
+      w4[v] = make_uint4(hi.x, hi.y, lo.x, lo.y);
     }
   }
 }
@@ -692,16 +699,37 @@ CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q,
   return cpm::check_launch("upsample2x_add_backward");
 }
 
+static int sgd_step_impl(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
+                         const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
+                         const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
+                         int first_step, void* w4_out, void* stream) {
+  CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_group && h_group_lr && h_group_wd,
+              "null pointer");
+  CPM_REQUIRE(ngroups > 0 && ngroups <= 8 && total > 0 && total % 64 == 0, "bad shape (total % 64, <= 8 groups)");
+  CPM_REQUIRE(((uintptr_t)w4_out & 15) == 0, "unaligned image buffer");
+  SgdGroups grp = {};
+  for (int i = 0; i < ngroups; ++i) { grp.lr[i] = h_group_lr[i]; grp.wd[i] = h_group_wd[i]; }
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
+                     grads, momentum_buf, block_seg, seg_end, seg_group, grp, total, momentum, grad_scale, first_step,
+                     (uint4*)w4_out);
+  return cpm::check_launch("sgd_step");
+}
+
 CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
                             const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
                             const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
                             int first_step, void* stream) {
-  CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_group && h_group_lr && h_group_wd,
-              "null pointer");
-  CPM_REQUIRE(ngroups > 0 && ngroups <= 8 && total > 0 && total % 64 == 0, "bad shape (total % 64, <= 8 groups)");
-  SgdGroups grp = {};
-  for (int i = 0; i < ngroups; ++i) { grp.lr[i] = h_group_lr[i]; grp.wd[i] = h_group_wd[i]; }
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
-                     grads, momentum_buf, block_seg, seg_end, seg_group, grp, total, momentum, grad_scale, first_step);
-  return cpm::check_launch("sgd_step");
+  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, total,
+                       momentum, grad_scale, first_step, nullptr, stream);
+}
+
+// the same, and the pre-split image (cpm_split_w4's format, `total` floats' worth of bytes at the parameters' own
+// offsets) of the UPDATED parameters written by the same pass: the weight operand of the next step's forward convs
+CPM_EXPORT int cpm_sgd_step_w4(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
+                               const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
+                               const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
+                               int first_step, void* w4_out, void* stream) {
+  CPM_REQUIRE(w4_out, "null image buffer");
+  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, total,
+                       momentum, grad_scale, first_step, w4_out, stream);
 }

@@ -27,7 +27,8 @@ class ChainLayer(ctypes.Structure):
     """cpm_chain_layer (include/cpmrcnn_hip.h)"""
     _fields_ = [("conv", ConvDesc)] + \
                [(n, c_void_p) for n in ("w", "wt", "bias", "gamma", "beta", "dw", "dbias", "dgamma", "dbeta")] + \
-               [("has_gn", c_int), ("relu", c_int), ("gn_groups", c_int), ("eps", c_float), ("dgrad_flat", c_int)]
+               [("has_gn", c_int), ("relu", c_int), ("gn_groups", c_int), ("eps", c_float), ("dgrad_flat", c_int),
+                ("wt_w4", c_int), ("w4", c_void_p)]
 
 
 def lib():

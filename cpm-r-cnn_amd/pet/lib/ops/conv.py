@@ -61,15 +61,61 @@ def _ws(desc, device):
     return H.workspace(nbytes, device)
 
 
+def split_w4(w, out=None):
+    """The pre-split (bf16 hi / lo) image of a dense float tensor (cpm_split_w4): same shape / strides / bytes."""
+    out = torch.empty_like(w) if out is None else out
+    assert w.numel() % 4 == 0 and out.numel() == w.numel()
+    with H.guard(w.device):
+        rc = H.lib().cpm_split_w4(H.ptr(w), H.ptr(out), H.ctypes.c_int64(w.numel()), H.stream())
+    H.check(rc, "split_w4")
+    return out
+
+
+_W4 = os.environ.get("CPM_W4", "1") != "0"
+
+
+def bf16x3():
+    return H.lib().cpm_get_conv_math() == 1
+
+
+def w4_of(w_in, w, cg):
+    """The pre-split image of a conv / Linear weight for the bf16x3 kernels, or None (other arithmetic, channels per
+    group % 4 != 0, a repacked copy of the parameter).  Cached on the parameter with its `_version`: parameters of the
+    flat optimizer get theirs from the SGD kernel itself (FlatSGD.step: a view of its image buffer, refreshed with
+    every update); anything else -- frozen weights, weights before the first optimizer step, modules outside a
+    trainer -- is split here on first use and again whenever the tensor was modified in place."""
+    if not _W4 or w is not w_in or cg % 4 or not bf16x3():
+        return None
+    own = getattr(w_in, "_cpm_owner", w_in)          # a Linear's per-call [K,C,1,1] view stands for its parameter
+    t = getattr(own, "_cpm_w4", None)
+    if t is not None and own._cpm_w4_version == own._version and own._cpm_w4_ptr == own.data_ptr():
+        return t
+    src = own.detach()
+    if t is None or t.numel() != src.numel() or t.device != src.device:
+        t = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+    split_w4(src if src.dim() != 4 else _wmem(src), out=t)
+    own._cpm_w4, own._cpm_w4_version, own._cpm_w4_ptr = t, own._version, own.data_ptr()
+    return t
+
+
 def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, dil, groups, x_sp=None, w_sp=None,
-                   want_sp=False):
+                   want_sp=False, w4=None):
     """y = epilogue(conv(x, w)).  x_sp / w_sp: split-plane twins of the operands (pet.lib.ops.sp) -- with both, the
-    bf16x3 arithmetic runs on the LDS-DMA kernel; want_sp: also write y's twin and attach it (y._cpm_sp)."""
+    bf16x3 arithmetic runs on the LDS-DMA kernel; want_sp: also write y's twin and attach it (y._cpm_sp).
+    w4: the pre-split image of w (split_w4; bf16x3 arithmetic only), used in place of w."""
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     y = empty_nhwc((n, k, d.P, d.Q), x)
     if y.numel() == 0:
+        return y
+    if w4 is not None:
+        ws = _ws(d, x.device)
+        with H.guard(x.device):
+            rc = H.lib().cpm_conv2d_forward_w4(H.ctypes.byref(d), H.ptr(x), H.ptr(w4), H.ptr(scale), H.ptr(shift),
+                                               H.ptr(residual), int(res_mode), int(bool(relu)), H.ptr(y), H.ptr(ws),
+                                               H.c_size_t(ws.numel()), H.stream())
+        H.check(rc, "conv2d_forward_w4")
         return y
     if x_sp is not None or w_sp is not None or want_sp:
         y_sp = SP.empty_like(y) if (want_sp and k % 32 == 0) else None
@@ -128,6 +174,13 @@ def set_pending_wt_event(ev):
     _pending_wt_event = ev
 
 
+def _prepared_call(wparam):
+    """the data-gradient entry point that reads the prepared image of `wparam` (float or pre-split, FlatSGD decides)"""
+    own = getattr(wparam, "_cpm_owner", wparam)
+    return (H.lib().cpm_conv2d_backward_data_prepared_w4 if getattr(own, "_cpm_wt_fmt", 0)
+            else H.lib().cpm_conv2d_backward_data_prepared)
+
+
 def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
     """The data-gradient image of a weight owned by the flat optimizer, made for ALL such weights in one launch after
     every optimizer step (pet/utils/optimizer.py: FlatSGD._refresh_dgrad_weights) -- or None (transform per call):
@@ -148,6 +201,8 @@ def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
     if wt is None or reg != key or wparam._cpm_wt_version != wparam._version:
         return None
     if k_scale is not None and getattr(wparam, "_cpm_wt_scale_version", None) != k_scale._version:
+        return None
+    if getattr(wparam, "_cpm_wt_fmt", 0) and not bf16x3():      # a pre-split image serves the bf16x3 kernels only
         return None
     global _pending_wt_event
     if _pending_wt_event is not None:                  # first reader after an optimizer step: the transform must be done
@@ -175,9 +230,8 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
         with H.guard(dy.device):
             ws = _ws(d, dy.device)
             if wt is not None:
-                rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(acc), 1,
-                                                               None, H.ptr(gate), H.ptr(ws), H.c_size_t(ws.numel()),
-                                                               H.stream())
+                rc = _prepared_call(wparam)(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(acc), 1,
+                                            None, H.ptr(gate), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
             else:
                 rc = H.lib().cpm_conv2d_backward_data_fused(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(k_scale),
                                                             H.ptr(acc), 1, None, H.ptr(gate), H.ptr(ws),
@@ -202,8 +256,8 @@ def conv2d_backward_data(dy, w, x_shape, stride, pad, dil, groups, accumulate_in
     with H.guard(dy.device):
         ws = _ws(d, dy.device)
         if wt is not None:
-            rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0, None,
-                                                           None, H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+            rc = _prepared_call(wparam)(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0, None,
+                                        None, H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
         elif k_scale is not None:
             rc = H.lib().cpm_conv2d_backward_data_fused(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(k_scale),
                                                         H.ptr(dx), 0, None, None, H.ptr(ws), H.c_size_t(ws.numel()),
@@ -230,9 +284,8 @@ def conv2d_backward_data_gated(dy, w, x, in_scale, stride, pad, dil, groups, wpa
     with H.guard(dy.device):
         ws = _ws(d, dy.device)
         if wt is not None:
-            rc = H.lib().cpm_conv2d_backward_data_prepared(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0,
-                                                           H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()),
-                                                           H.stream())
+            rc = _prepared_call(wparam)(H.ctypes.byref(d), H.ptr(dy), H.ptr(wt), H.ptr(dx), 0,
+                                        H.ptr(in_scale), H.ptr(x), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
         else:
             rc = H.lib().cpm_conv2d_backward_data_fused(H.ctypes.byref(d), H.ptr(dy), H.ptr(w), H.ptr(k_scale),
                                                         H.ptr(dx), 0, H.ptr(in_scale), H.ptr(x), H.ptr(ws),
@@ -402,7 +455,8 @@ class _ConvFn(Function):
         # the parameter itself (not a repacked copy) when `w` aliases it: key of the once-per-step dgrad image
         ctx.wsrc = w_in if (w is w_in and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         ctx.bparam = _sink_of(shift, shift is not None and ctx.needs_input_grad[3])
-        y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups)
+        y = conv2d_forward(x, w, scale, shift, res, res_mode, relu, stride, pad, dil, groups,
+                           w4=w4_of(w_in, w, x.shape[1] // groups))
         # Epilogue-backward folded into the consumers.  y = relu(..) may carry a tag (conv2d: sole_consumer /
         # gate_by_consumers): every consuming _ConvFn then masks its data gradient with (y > 0) in the kernel's epilogue
         # -- the running sum of the shared accumulator when it adds to one: masking is linear and idempotent -- and
@@ -742,6 +796,8 @@ class _ChainPlan(object):
         self.params = tuple(params)
         self.ptrs = self._pointers()
         self.wt_ptrs = None
+        self.w4_ptrs = None
+        self.weights = tuple(sp[0] for sp in specs)
         self.sizes = {}
 
     def _pointers(self):
@@ -769,11 +825,24 @@ class _ChainPlan(object):
         for key in self.dgrad_keys:
             wt = _prepared_wt(*key)
             wts.append(wt.data_ptr() if wt is not None else None)
+            wts.append(int(getattr(key[0], "_cpm_wt_fmt", 0)) if wt is not None else 0)
         wts = tuple(wts)
         if wts != self.wt_ptrs:
-            for i, v in enumerate(wts):
-                self.table[i].wt = v
+            for i in range(self.n):
+                self.table[i].wt, self.table[i].wt_w4 = wts[2 * i], wts[2 * i + 1]
             self.wt_ptrs = wts
+
+    def refresh_w4(self):
+        """pre-split images of the weights for the forward convs (w4_of); the native loop reads them under bf16x3 only"""
+        ptrs = []
+        for w in self.weights:
+            t = w4_of(w, w if w.dim() == 2 else _wmem(w), w.shape[1])
+            ptrs.append(t.data_ptr() if t is not None else None)
+        ptrs = tuple(ptrs)
+        if ptrs != self.w4_ptrs:
+            for i, v in enumerate(ptrs):
+                self.table[i].w4 = v
+            self.w4_ptrs = ptrs
 
 
 class _LayerChainFn(Function):
@@ -794,6 +863,7 @@ class _LayerChainFn(Function):
             y = torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device, memory_format=CL)
         for p_ in plan.params:
             p_._cpm_uses = getattr(p_, "_cpm_uses", 0) + 1
+        plan.refresh_w4()
         ws = H.workspace(ws_bytes, x.device)
         with H.guard(x.device):
             rc = H.lib().cpm_layer_chain_forward(plan.table, plan.n, n, H.ptr(x), H.ptr(fbuf), H.ptr(y), H.ptr(ws),

@@ -154,14 +154,49 @@ class FlatSGD(torch.optim.Optimizer):
         ng = len(self.param_groups)
         lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
         wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
+        from pet.lib.ops import conv as C
+        w4 = C._W4 and C.bf16x3()
         with torch.cuda.device(self.flat_param.device):
-            rc = H.lib().cpm_sgd_step(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
-                                      H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
-                                      H.c_int64(self.total), H.f(self.momentum), H.f(self.grad_scale),
-                                      int(self._steps == 0), H.stream())
+            if w4:
+                # the pre-split image of every parameter (the forward convs' weight operand under bf16x3, conv.w4_of)
+                # leaves the same pass: one more write stream of the SGD kernel instead of a pass per weight
+                if getattr(self, "flat_w4", None) is None:
+                    self.flat_w4 = torch.empty_like(self.flat_param)
+                rc = H.lib().cpm_sgd_step_w4(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
+                                             H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
+                                             H.c_int64(self.total), H.f(self.momentum), H.f(self.grad_scale),
+                                             int(self._steps == 0), H.ptr(self.flat_w4), H.stream())
+            else:
+                rc = H.lib().cpm_sgd_step(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
+                                          H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
+                                          H.c_int64(self.total), H.f(self.momentum), H.f(self.grad_scale),
+                                          int(self._steps == 0), H.stream())
         H.check(rc, "sgd_step")
         self._steps += 1
+        self._mark_w4(w4)
         self._refresh_dgrad_weights()
+
+    def _mark_w4(self, fresh):
+        """Parameters whose pre-split image the SGD kernel has just written: conv / Linear weights (numel % 4 == 0) get
+        the view of the image buffer at their own offset, stamped with their `_version` (conv.w4_of reads it; an
+        in-place modification by anything else moves `_version` and w4_of re-splits into the same view)."""
+        if not fresh:
+            if getattr(self, "_w4_marked", False):
+                for p in self._flat_order:
+                    if hasattr(p, "_cpm_w4"):
+                        p._cpm_w4_version = -1          # the images went stale with this step
+                self._w4_marked = False
+            return
+        if not getattr(self, "_w4_marked", False):
+            begins = self.seg_begin.tolist()
+            for si, p in enumerate(self._flat_order):
+                if p.dim() in (2, 4) and p.numel() % 4 == 0:
+                    p._cpm_w4 = self.flat_w4[begins[si]:begins[si] + p.numel()]
+                    p._cpm_w4_ptr = p.data_ptr()
+            self._w4_marked = True
+        for p in self._flat_order:
+            if hasattr(p, "_cpm_w4"):
+                p._cpm_w4_version = p._version
 
     def _refresh_dgrad_weights(self):
         """Every conv weight that has been used by a data-gradient call (pet.lib.ops.conv._prepared_wt registers it
@@ -200,23 +235,25 @@ class FlatSGD(torch.optim.Optimizer):
         from pet.lib.ops import conv as C
         dev = self.flat_param.device
         side = C.wgrad_stream(dev) if os.environ.get("CPM_WT_ON_SIDE", "1") != "0" else None
+        # under bf16x3 the images are written pre-split (weights with K / groups % 4 == 0; conv._prepared_call)
+        w4 = C._W4 and C.bf16x3()
+        transform = H.lib().cpm_weights_to_dgrad_batched_w4 if w4 else H.lib().cpm_weights_to_dgrad_batched
         with H.guard(dev):
             if side is not None:
                 main_raw = H._raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
                 H.fork(main_raw, side.cuda_stream)
                 with H.use_stream(side.cuda_stream):
-                    rc = H.lib().cpm_weights_to_dgrad_batched(H.ptr(self._wt_table), len(self._wt_params),
-                                                              H.c_int64(self._wt_tiles), H.ptr(self.flat_param),
-                                                              H.ptr(self.flat_wt), H.stream())
+                    rc = transform(H.ptr(self._wt_table), len(self._wt_params), H.c_int64(self._wt_tiles),
+                                   H.ptr(self.flat_param), H.ptr(self.flat_wt), H.stream())
                 ev = torch.cuda.Event()
                 ev.record(side)
                 C.set_pending_wt_event(ev)
             else:
-                rc = H.lib().cpm_weights_to_dgrad_batched(H.ptr(self._wt_table), len(self._wt_params),
-                                                          H.c_int64(self._wt_tiles), H.ptr(self.flat_param),
-                                                          H.ptr(self.flat_wt), H.stream())
+                rc = transform(H.ptr(self._wt_table), len(self._wt_params), H.c_int64(self._wt_tiles),
+                               H.ptr(self.flat_param), H.ptr(self.flat_wt), H.stream())
         H.check(rc, "weights_to_dgrad_batched")
         for p in self._wt_params:
+            p._cpm_wt_fmt = 1 if (w4 and p._cpm_wt_desc[1] % 4 == 0) else 0
             p._cpm_wt_version = p._version
             sc = getattr(p, "_cpm_wt_scale", None)
             if sc is not None:

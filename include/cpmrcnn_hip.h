@@ -150,6 +150,16 @@ size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d);
 int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const float* w, const float* scale,
                        const float* shift, const float* residual, int res_mode, int relu, float* y,
                        void* workspace, size_t workspace_bytes, void* stream);
+/* Pre-split weight images (bf16x3 arithmetic only).  The weight operand of a convolution is the same for every pixel
+ * tile and every step until the optimizer moves it, yet the bf16x3 kernels split it into bf16 hi / lo again in every
+ * workgroup that loads it (a third to a half of their conversion work).  cpm_split_w4 writes the split once: elements
+ * 4i .. 4i+3 of a float array become 8 bytes of bf16 hi and 8 bytes of bf16 lo (lo = bf16(x - hi)) at byte offset 16 i,
+ * i.e. an image of the array's own size and offsets (n % 4 == 0, 16-byte aligned buffers).  cpm_conv2d_forward_w4 is
+ * cpm_conv2d_forward with `w4` = that image of the KRSC weight (C / groups % 4 == 0) and bit-identical results. */
+int cpm_split_w4(const float* src, void* dst, int64_t n, void* stream);
+int cpm_conv2d_forward_w4(const cpm_conv_desc* d, const float* x, const void* w4, const float* scale,
+                          const float* shift, const float* residual, int res_mode, int relu, float* y,
+                          void* workspace, size_t workspace_bytes, void* stream);
 int cpm_conv2d_backward_data(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                              void* workspace, size_t workspace_bytes, void* stream);
 int cpm_conv2d_backward_weight(const cpm_conv_desc* d, const float* x, const float* dy, float* dw,
@@ -201,6 +211,14 @@ int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs /* DEVICE table, sor
 int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
                                       int accumulate, const float* in_scale, const float* in_act, void* workspace,
                                       size_t workspace_bytes, void* stream);
+/* The images written pre-split (see cpm_split_w4: along k, four at a time) for the bf16x3 arithmetic -- entries with
+ * K / groups % 4 != 0 keep their float image -- and the data gradient that reads such an image.  The data-gradient
+ * entry points that build their image per call (cpm_conv2d_backward_data / _gated / _fused) do this by themselves. */
+int cpm_weights_to_dgrad_batched_w4(const cpm_wt_desc* d_descs, int n, int64_t total_tiles, const float* src_base,
+                                    float* dst_base, void* stream);
+int cpm_conv2d_backward_data_prepared_w4(const cpm_conv_desc* d, const float* dy, const void* wt4, float* dx,
+                                         int accumulate, const float* in_scale, const float* in_act, void* workspace,
+                                         size_t workspace_bytes, void* stream);
 
 /* (The experimental split-plane / LDS-DMA ring entry points live in cpmrcnn_hip_experimental.h: measured, not on the
  * product path -- DESIGN.md section 8.) */
@@ -495,6 +513,8 @@ typedef struct {
   int gn_groups;
   float eps;
   int dgrad_flat;   /* full-window layer: data gradient as the [N,K] x [K, R*S*C] GEMM it is (wt = that matrix's image) */
+  int wt_w4;        /* wt is a pre-split image (cpm_weights_to_dgrad_batched_w4): read under the bf16x3 arithmetic only */
+  const void* w4;   /* the pre-split image of w (cpm_split_w4 / cpm_sgd_step_w4) or NULL: forward under bf16x3 reads it */
 } cpm_chain_layer;
 int cpm_layer_chain_sizes(const cpm_chain_layer* layers, int n_layers, int N, size_t* fwd_floats, size_t* bwd_floats,
                           size_t* workspace_bytes);
@@ -528,6 +548,13 @@ int cpm_sgd_step(float* params, const float* grads, float* momentum_buf, const i
                  const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
                  const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
                  int first_step, void* stream);
+/* The same pass also writing the pre-split image (cpm_split_w4's format) of the UPDATED parameters into `w4_out`
+ * (`total` floats' worth of bytes, the parameters' own offsets): the weight operand of the next step's forward convs
+ * (cpm_conv2d_forward_w4) without a pass of its own. */
+int cpm_sgd_step_w4(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
+                    const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
+                    const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
+                    int first_step, void* w4_out, void* stream);
 
 #ifdef __cplusplus
 }

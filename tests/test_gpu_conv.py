@@ -402,6 +402,37 @@ def test_three_tap_weight_gradient(case, split, conv_math, monkeypatch):
     assert torch.equal(a, b) and relerr(a, dw_ref) < TOL
 
 
+@pytest.mark.parametrize("case", [(2, 64, 19, 23, 96, 3, 1, 1, 1), (3, 256, 14, 14, 576, 3, 2, 1, 1), (2, 128, 33, 40, 256, 1, 1, 0, 1),
+                                  (2, 64, 16, 16, 128, 3, 1, 1, 4), (5, 256, 7, 7, 320, 7, 1, 0, 1),
+                                  (2, 256, 60, 72, 256, 3, 1, 1, 1)],
+                         ids=["3x3", "3x3_s2", "1x1", "grouped", "full_window", "3x3_patch_kernel"])
+def test_presplit_weight_images_give_identical_results(case, conv_math):
+    """cpm_split_w4 / cpm_conv2d_forward_w4 and the pre-split data-gradient images: the kernels read the same bf16 hi / lo
+    values they would have formed themselves, so forward and data gradient are BIT-identical to the float-weight
+    entry points (atomics aside: cases here run unsplit or through ordered planes)."""
+    if conv_math != "bf16x3":
+        pytest.skip("pre-split weight images serve the bf16x3 arithmetic")
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    N, Cc, Hh, Ww, K, R, stride, pad, groups = case
+    x = rnd(N, Cc, Hh, Ww, seed=1).cuda().contiguous(memory_format=CL)
+    w = rnd(K, Cc // groups, R, R, seed=2, scale=0.05).cuda().contiguous(memory_format=CL)
+    b = rnd(K, seed=3).cuda()
+    _hip.set_deterministic(True)
+    try:
+        y0 = C.conv2d_forward(x, w, None, b, None, 0, True, stride, pad, 1, groups)
+        y1 = C.conv2d_forward(x, w, None, b, None, 0, True, stride, pad, 1, groups, w4=C.split_w4(w))
+        assert torch.equal(y0, y1)
+        dy = rnd(*y0.shape, seed=4).cuda().contiguous(memory_format=CL)
+    finally:
+        _hip.set_deterministic(False)
+    # the per-call image of the data gradient is pre-split by the library itself: held to torch
+    dx = C.conv2d_backward_data(dy, w, tuple(x.shape), stride, pad, 1, groups)
+    xr = x.cpu().contiguous().requires_grad_(True)
+    F.conv2d(xr, w.cpu().contiguous(), None, stride, pad, 1, groups).backward(dy.cpu().contiguous())
+    assert relerr(dx, xr.grad) < TOL
+
+
 def test_fused_dgrad_and_scaled_wgrad_kernels():
     """cpm_conv2d_backward_data_fused / cpm_conv2d_backward_weight_scaled against torch: k_scale inside the reductions,
     accumulate + gate = (acc + dx) * [act > 0], with and without the reduction split (a thin grid forces split-K)."""

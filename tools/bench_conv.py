@@ -63,13 +63,15 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--epi", default="plain", choices=["plain", "res"], help="res: forward with frozen affine + residual "
                     "+ ReLU (bottleneck conv3), data gradient accumulating into an existing tensor")
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "sp"],
-                    help="sp = bf16x3 arithmetic on pre-split (split-plane) operands, LDS-DMA kernel")
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "sp", "w4"],
+                    help="sp = bf16x3 arithmetic on pre-split (split-plane) operands, LDS-DMA kernel; w4 = bf16x3 with "
+                         "the forward weight given as its pre-split image (cpm_split_w4)")
     a = ap.parse_args()
     from pet.lib.ops import _hip
     from pet.lib.ops import sp as SP
     use_sp = a.math == "sp"
-    if use_sp:
+    use_w4 = a.math == "w4"
+    if use_sp or use_w4:
         a.math = "bf16x3"
     _hip.set_conv_math(a.math)
     tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
@@ -93,6 +95,9 @@ def main():
             acc = torch.zeros_like(x)
             fwd = lambda: ops.conv2d_forward(x, w, sc, sh, res, 0, True, st, pad, 1, g)
             dgr = lambda: ops.conv2d_backward_data(dy, w, (N, C, H, W), st, pad, 1, g, accumulate_into=acc)
+        if use_w4:
+            w4 = ops.split_w4(w)
+            fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g, w4=w4)
         if use_sp:
             x_sp, w_sp, dy_sp = SP.split(x), SP.split(w), SP.split(dy)
             kg, cg = K // g, C // g
