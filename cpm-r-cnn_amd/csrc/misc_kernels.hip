@@ -531,9 +531,10 @@ struct SgdGroups { float lr[8]; float wd[8]; };
 __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                            const int32_t* __restrict__ block_seg, const int64_t* __restrict__ seg_end,
                            const int32_t* __restrict__ seg_group, SgdGroups grp, int64_t total, float momentum,
-                           float grad_scale, int first_step, uint4* __restrict__ w4) {
-  const int64_t nvec = total >> 2;
-  for (int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * blockDim.x) {
+                           float grad_scale, int first_step, uint4* __restrict__ w4, int64_t range_begin) {
+  const int64_t nvec = total >> 2;            // (total = end of the range to update, range_begin its first element)
+  for (int64_t v = (range_begin >> 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
+       v += (int64_t)gridDim.x * blockDim.x) {
     const int64_t i = v << 2;
     const int sidx = block_seg[i >> 6];
     if (sidx < 0) continue;
@@ -701,17 +702,19 @@ CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q,
 
 static int sgd_step_impl(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
                          const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
-                         const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
-                         int first_step, void* w4_out, void* stream) {
+                         const float* h_group_wd, int ngroups, int64_t begin, int64_t end, float momentum,
+                         float grad_scale, int first_step, void* w4_out, void* stream) {
   CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_group && h_group_lr && h_group_wd,
               "null pointer");
-  CPM_REQUIRE(ngroups > 0 && ngroups <= 8 && total > 0 && total % 64 == 0, "bad shape (total % 64, <= 8 groups)");
+  CPM_REQUIRE(ngroups > 0 && ngroups <= 8 && begin >= 0 && end >= begin && end % 64 == 0 && begin % 64 == 0,
+              "bad shape (a range on 64-element boundaries, <= 8 groups)");
   CPM_REQUIRE(((uintptr_t)w4_out & 15) == 0, "unaligned image buffer");
+  if (end == begin) return CPM_OK;
   SgdGroups grp = {};
   for (int i = 0; i < ngroups; ++i) { grp.lr[i] = h_group_lr[i]; grp.wd[i] = h_group_wd[i]; }
-  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(total / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
-                     grads, momentum_buf, block_seg, seg_end, seg_group, grp, total, momentum, grad_scale, first_step,
-                     (uint4*)w4_out);
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for((end - begin) / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
+                     grads, momentum_buf, block_seg, seg_end, seg_group, grp, end, momentum, grad_scale, first_step,
+                     (uint4*)w4_out, begin);
   return cpm::check_launch("sgd_step");
 }
 
@@ -719,7 +722,8 @@ CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_b
                             const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
                             const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
                             int first_step, void* stream) {
-  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, total,
+  CPM_REQUIRE(total > 0, "bad shape (total % 64, <= 8 groups)");
+  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, 0, total,
                        momentum, grad_scale, first_step, nullptr, stream);
 }
 
@@ -729,7 +733,18 @@ CPM_EXPORT int cpm_sgd_step_w4(float* params, const float* grads, float* momentu
                                const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
                                const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
                                int first_step, void* w4_out, void* stream) {
-  CPM_REQUIRE(w4_out, "null image buffer");
-  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, total,
+  CPM_REQUIRE(w4_out && total > 0, "null image buffer");
+  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, 0, total,
                        momentum, grad_scale, first_step, w4_out, stream);
+}
+
+// the update of elements [begin, end) only (both on 64-element boundaries; pointers are those of the WHOLE buffers):
+// a data-parallel trainer updates a chunk of the flat buffer as soon as its gradients are complete (and all-reduced),
+// beside the rest of the backward pass.  w4_out may be NULL.
+CPM_EXPORT int cpm_sgd_step_range(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
+                                  const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
+                                  const float* h_group_wd, int ngroups, int64_t begin, int64_t end, float momentum,
+                                  float grad_scale, int first_step, void* w4_out, void* stream) {
+  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, begin,
+                       end, momentum, grad_scale, first_step, w4_out, stream);
 }

@@ -489,6 +489,10 @@ class _ConvFn(Function):
         want_shift = has_shift and need_shift
         want_res = has_res and need_res
         g, dshift = dy, None
+        # parameters whose gradient this call completes: announced (_sink_done) at the END, when the data gradient -- the
+        # last reader of the weight -- has been queued too: a listener may update the parameter right away
+        # (pet.utils.parallel: the chunk's all-reduce and SGD step on a side stream)
+        done = []
         # a bias gradient alone (no gate to apply) rides on the weight-gradient kernel's dy reads
         fuse_bias = (want_shift and not need_gate and need_w and groups == 1 and x_shape[1] > 1 and x.numel() > 0
                      and dy.numel() > 0)
@@ -499,7 +503,7 @@ class _ConvFn(Function):
                                                dshift_out=bp._cpm_grad_sink if bp is not None else None)
             if bp is not None:
                 dshift = None                   # accumulated in place
-                _sink_done(bp)
+                done.append(bp)
             if need_gate:
                 g = g_k
         # the weight gradient first: forked onto the second stream it starts together with the data gradient below
@@ -523,14 +527,14 @@ class _ConvFn(Function):
                 else:
                     conv2d_backward_weight(x, g, w, stride, pad, dil, groups, out=wp._cpm_grad_sink, dbias=dbias,
                                            k_scale=k_scale)
-                _sink_done(getattr(wp, "_cpm_owner", wp))
+                done.append(getattr(wp, "_cpm_owner", wp))
             else:
                 dw = conv2d_backward_weight(x, g, w, stride, pad, dil, groups, dbias=dbias, k_scale=k_scale)
                 if wp is not None:                      # this use reaches the parameter through autograd's accumulation
                     own = getattr(wp, "_cpm_owner", wp)
                     own._cpm_uses -= 1
             if fuse_bias and ctx.bparam is not None:
-                _sink_done(ctx.bparam)                  # accumulated in place
+                done.append(ctx.bparam)                 # accumulated in place
         gres = None
         if want_res:
             gres = g if res_mode == 0 else upsample2x_add_backward(g, res_shape)
@@ -577,6 +581,8 @@ class _ConvFn(Function):
                         tag["applied"] = False
                 if h is not None:
                     h["acc"] = dx
+        for p_ in done:
+            _sink_done(p_)
         return dx, dw, None, dshift, gres, None, None, None, None, None, None, None
 
 

@@ -96,15 +96,12 @@ class _ColsConvFn(Function):
             dpre = dpre_k if dpre_k is not None else dy
         w1 = _w1x1(w)
         dw = None
+        done_wp = None
         if need_w:
             wp = ctx.wparam
             if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
                 F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups, out=wp._cpm_grad_sink)
-                wp._cpm_uses -= 1
-                if wp._cpm_uses == 0:
-                    ready = getattr(wp, "_cpm_grad_ready", None)
-                    if ready is not None:
-                        ready(wp)
+                done_wp = wp                            # announced at the end: the data gradient below still reads w
             else:
                 if wp is not None:                      # this use reaches the parameter through autograd's accumulation
                     wp._cpm_uses -= 1
@@ -128,6 +125,8 @@ class _ColsConvFn(Function):
                         rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(offset), *args, H.ptr(doff),
                                                            H.stream())
                         H.check(rc, "deform_coord_grad")
+        if done_wp is not None:
+            F._sink_done(done_wp)
         return dx, doff, dw, None, dshift, None, None, None, None, None, None, None
 
 

@@ -50,6 +50,7 @@ class FlatSGD(torch.optim.Optimizer):
             table[b // align:(e + align - 1) // align] = si
         self.block_seg = table.to(device)
         self.total, self.momentum, self._steps, self._last = total, float(momentum), 0, None
+        self._stepped_end, self._w4_fresh = 0, False
         self.grad_scale = 1.0
         groups = []
         for gi, g in enumerate(groups_cfg):
@@ -150,30 +151,39 @@ class FlatSGD(torch.optim.Optimizer):
                     p._cpm_uses = 0
 
     @torch.no_grad()
-    def step(self, closure=None):
+    def step_range(self, begin, end):
+        """SGD update of flat elements [begin, end) (64-element boundaries) on the CURRENT stream: a chunk whose
+        gradients are complete (pet.utils.parallel.FlatGradReducer launches it on its side stream, behind the chunk's
+        all-reduce); `step()` then covers what is left.  Ranges of one step must be issued front to back."""
+        from pet.lib.ops import conv as C
+        assert begin == self._stepped_end and begin % 64 == 0 and end % 64 == 0 and end <= self.total
+        if end == begin:
+            return
         ng = len(self.param_groups)
         lr = (ctypes.c_float * ng)(*[float(g["lr"]) for g in self.param_groups])
         wd = (ctypes.c_float * ng)(*[float(g["weight_decay"]) for g in self.param_groups])
-        from pet.lib.ops import conv as C
         w4 = C._W4 and C.bf16x3()
+        if w4 and getattr(self, "flat_w4", None) is None:
+            self.flat_w4 = torch.empty_like(self.flat_param)
+        self._w4_fresh = w4 if begin == 0 else (self._w4_fresh and w4)
         with torch.cuda.device(self.flat_param.device):
-            if w4:
-                # the pre-split image of every parameter (the forward convs' weight operand under bf16x3, conv.w4_of)
-                # leaves the same pass: one more write stream of the SGD kernel instead of a pass per weight
-                if getattr(self, "flat_w4", None) is None:
-                    self.flat_w4 = torch.empty_like(self.flat_param)
-                rc = H.lib().cpm_sgd_step_w4(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
-                                             H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
-                                             H.c_int64(self.total), H.f(self.momentum), H.f(self.grad_scale),
-                                             int(self._steps == 0), H.ptr(self.flat_w4), H.stream())
-            else:
-                rc = H.lib().cpm_sgd_step(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
-                                          H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
-                                          H.c_int64(self.total), H.f(self.momentum), H.f(self.grad_scale),
-                                          int(self._steps == 0), H.stream())
+            # under bf16x3 the pre-split image of every parameter (the forward convs' weight operand, conv.w4_of) leaves
+            # the same pass: one more write stream of the SGD kernel instead of a pass per weight
+            rc = H.lib().cpm_sgd_step_range(H.ptr(self.flat_param), H.ptr(self.flat_grad), H.ptr(self.flat_mom),
+                                            H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
+                                            H.c_int64(begin), H.c_int64(end), H.f(self.momentum),
+                                            H.f(self.grad_scale), int(self._steps == 0),
+                                            H.ptr(self.flat_w4) if w4 else None, H.stream())
         H.check(rc, "sgd_step")
+        self._stepped_end = end
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self._stepped_end < self.total:
+            self.step_range(self._stepped_end, self.total)
+        self._stepped_end = 0
         self._steps += 1
-        self._mark_w4(w4)
+        self._mark_w4(self._w4_fresh)
         self._refresh_dgrad_weights()
 
     def _mark_w4(self, fresh):

@@ -7,8 +7,12 @@ all_reduce in pet/utils/logger.py:52-53, re-designed for the flat gradient buffe
     the ring's per-link latency); a chunk's all-reduce is launched on a side stream as soon as the autograd
     hooks have seen every tensor in it, overlapping the remaining backward;
   * the 1/world scaling is folded into the SGD kernel (grad_scale) instead of a separate division pass;
+  * optionally (CPM_OVERLAP_SGD=1) the SGD update of a chunk follows its all-reduce on the same side stream
+    (FlatSGD.step_range), beside the rest of the backward pass instead of behind it;
   * the ~9 loss scalars are reduced as ONE tensor for logging.
 Works with any torch.distributed backend (`nccl` == RCCL on ROCm; `gloo` in the CPU tests)."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,11 +43,16 @@ class FlatGradReducer(object):
                 self.chunks.append((start, e, nseg))
                 start, nseg = e, 0
         self.overlap = overlap and self.world > 1 and self.flat.is_cuda
-        self.stream = torch.cuda.Stream(device=self.flat.device) if self.overlap else None
+        # the chunk's SGD update behind its gradients (and all-reduce), beside the backward pass.  Opt-in
+        # (CPM_OVERLAP_SGD=1): on one MI355X it changes nothing -- 20.9 vs 21.1 ms/step alternating on one box; the SGD
+        # kernel's 3.7 GB of traffic takes from the backward kernels what it saves behind them -- and with RCCL it
+        # has not run yet.
+        self.local_sgd = overlap and self.flat.is_cuda and os.environ.get("CPM_OVERLAP_SGD", "0") != "0"
+        self.stream = torch.cuda.Stream(device=self.flat.device) if (self.overlap or self.local_sgd) else None
         self._pending = None
         self._done = set()
         self._handles = []
-        if self.overlap:
+        if self.overlap or self.local_sgd:
             params = [p for g in optimizer.param_groups for p in g["params"]]
             by_id = {id(p): p for p in params}
             order = []
@@ -75,6 +84,8 @@ class FlatGradReducer(object):
             # chunks are reduced strictly in buffer order on every rank -- a collective must be issued in the same
             # order everywhere, and the order in which chunks BECOME ready may differ between ranks (a rank whose
             # batch leaves a head without RoIs never completes that head's chunk until finish())
+            if self.flat.is_cuda and torch.cuda.is_current_stream_capturing():
+                return                      # (a hipGraph capture of the backward pass: finish() launches instead)
             while self._next < len(self.chunks) and self._pending[self._next] == 0:
                 self._launch(self._next)
                 self._next += 1
@@ -93,13 +104,17 @@ class FlatGradReducer(object):
         if side is not None:
             self.stream.wait_stream(side)
         with torch.cuda.stream(self.stream):
-            dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
+            if self.world > 1:
+                dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
+            if self.local_sgd:
+                # (chunks end on tensor ends, tensors start on 64-element boundaries: the gap belongs to nobody)
+                self.opt.step_range((b + 63) // 64 * 64, (e + 63) // 64 * 64)
 
     def finish(self):
         """Call after backward: reduce whatever is left and make the compute stream wait for the reductions."""
-        if self.world == 1:
+        if self.world == 1 and not self.local_sgd:
             return
-        if self.overlap:
+        if self.overlap or self.local_sgd:
             while self._next < len(self.chunks):   # incl. chunks with tensors that got no gradient this step
                 self._launch(self._next)
                 self._next += 1

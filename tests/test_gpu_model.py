@@ -380,6 +380,53 @@ def test_flat_sgd_matches_torch_sgd():
             torch.testing.assert_close(p.detach().cpu().contiguous(), r.detach(), rtol=1e-5, atol=1e-6)
 
 
+def test_flat_sgd_in_ranges_equals_one_pass():
+    """cpm_sgd_step_range: the update issued chunk by chunk (FlatGradReducer launches a chunk's update behind its
+    gradients, beside the backward pass) and finished by step() is BIT-identical to one pass over the buffer --
+    parameters, momentum and, under bf16x3, the pre-split image the same kernel writes."""
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    from pet.utils.optimizer import FlatSGD
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    try:
+        shapes = [(64, 32, 3, 3), (64,), (7, 33), (7,), (36,), (36,), (128, 64, 1, 1), (5, 3, 1, 1), (256, 128)]
+        kinds = [0, 1, 0, 1, 2, 2, 0, 0, 0]
+        groups = [dict(weight_decay=1e-4, lr_scale=1), dict(weight_decay=0.0, lr_scale=2), dict(weight_decay=0.0, lr_scale=1)]
+
+        def build():
+            torch.manual_seed(0)
+            ps = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+            for p in ps:
+                if p.dim() == 4:
+                    p.data = p.data.contiguous(memory_format=CL)
+            return ps, FlatSGD([("p%d" % i, p, k) for i, (p, k) in enumerate(zip(ps, kinds))], groups, 0.9)
+
+        (pa, oa), (pb, ob) = build(), build()
+        ends = [((e + 63) // 64) * 64 for e in oa.seg_end.tolist()]
+        for step in range(3):
+            g = torch.randn(oa.total, device="cuda")
+            for o in (oa, ob):
+                for gr, cfgg in zip(o.param_groups, groups):
+                    gr["lr"] = 0.05 * (step + 1) * cfgg["lr_scale"]
+                o.zero_grad()
+                o.flat_grad.copy_(g)
+            oa.step()
+            ob.step_range(0, ends[1])                     # two tensors, then three, the rest in step()
+            ob.step_range(ends[1], ends[4])
+            ob.step()
+            for b, e in zip(oa.seg_begin.tolist(), oa.seg_end.tolist()):          # (the alignment gaps hold no data)
+                assert torch.equal(oa.flat_param[b:e], ob.flat_param[b:e]) and torch.equal(oa.flat_mom[b:e], ob.flat_mom[b:e])
+                e4 = b + (e - b) // 4 * 4
+                assert torch.equal(oa.flat_w4[b:e4], ob.flat_w4[b:e4])
+            for p in pa:
+                if p.dim() in (2, 4) and p.numel() % 4 == 0:
+                    w = p.detach() if p.dim() == 2 else p.detach().permute(0, 2, 3, 1).contiguous()
+                    assert torch.equal(C.w4_of(p, p, p.shape[1]).view(-1), C.split_w4(w).view(-1))
+    finally:
+        _hip.set_conv_math(prev)
+
+
 def G_of(m):
     return m.Grid_Cascade_RCNN
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""torch.profiler over three default training steps: which ATen ops (not this package's kernels) still run in the step.
+    python tools/torch_prof_step.py > gpurun_out/torch_prof.txt"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "cpm-r-cnn_amd"))
+import torch  # noqa: E402
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    import __graft_entry__ as entry
+    entry.ensure_built()
+    from pet.lib.ops import _hip
+    _hip.set_conv_math("bf16x3")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    tr = bench.Trainer(dev)
+    images, targets = bench.synthetic_batch(2, 800, 1344, 16, 1234, dev)
+    cal, _ = bench.synthetic_batch(2, 800, 1344, 1, 4321, dev)
+    bench.calibrate_frozen_affine(tr.model, cal.tensors)
+    for _ in range(6):
+        tr.step(images, targets)
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+        for _ in range(3):
+            tr.step(images, targets)
+        torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
+    print(prof.key_averages(group_by_stack_n=4).table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=60,
+                                                      max_src_column_width=90))
+
+
+if __name__ == "__main__":
+    main()
