@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """torch.profiler over three default training steps: which ATen ops (not this package's kernels) still run in the step.
-    python tools/torch_prof_step.py > gpurun_out/torch_prof.txt"""
+    python tools/torch_prof_step.py [x101dcn] > gpurun_out/torch_prof.txt"""
 import os
 import sys
 
@@ -20,9 +20,11 @@ def main():
     _hip.set_conv_math("bf16x3")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    tr = bench.Trainer(dev)
-    images, targets = bench.synthetic_batch(2, 800, 1344, 16, 1234, dev)
-    cal, _ = bench.synthetic_batch(2, 800, 1344, 1, 4321, dev)
+    body = sys.argv[1] if len(sys.argv) > 1 else "resnet"          # "x101dcn": config #5 at batch 1
+    bs = 1 if body == "x101dcn" else 2
+    tr = bench.Trainer(dev, body=body)
+    images, targets = bench.synthetic_batch(bs, 800, 1344, 16, 1234, dev)
+    cal, _ = bench.synthetic_batch(bs, 800, 1344, 1, 4321, dev)
     bench.calibrate_frozen_affine(tr.model, cal.tensors)
     for _ in range(6):
         tr.step(images, targets)
