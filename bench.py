@@ -138,6 +138,10 @@ class Trainer(object):
         self.model = model.to(device).to(memory_format=torch.channels_last)
         self.model.train()
         self.optimizer = Optimizer(self.model, self.cfg.SOLVER).build()
+        # this loop zeroes the gradients at the top of every step: let the SGD kernel clear them behind their use (the
+        # 614 MB memset of zero_grad -- 0.3 ms in front of every forward pass -- becomes part of a pass that has the
+        # lines anyway)
+        self.optimizer.clear_grads_in_step = os.environ.get("CPM_CLEAR_GRADS_IN_STEP", "1") != "0"
         self.scheduler = LearningRateScheduler(self.optimizer, self.cfg.SOLVER, start_iter=0)
         self.reducer = FlatGradReducer(self.optimizer, num_chunks=chunks)
         self.last_losses = None

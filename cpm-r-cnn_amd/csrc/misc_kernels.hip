@@ -528,10 +528,11 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int N, int P, 
 struct SgdGroups { float lr[8]; float wd[8]; };
 
 // w4 (or null): the pre-split image of the updated parameters (cpm_split_w4's format), written with them
-__global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+// zero_g: the gradient is cleared behind its use (the next step's zero_grad for free: the kernel has the line anyway)
+__global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ buf,
                            const int32_t* __restrict__ block_seg, const int64_t* __restrict__ seg_end,
                            const int32_t* __restrict__ seg_group, SgdGroups grp, int64_t total, float momentum,
-                           float grad_scale, int first_step, uint4* __restrict__ w4, int64_t range_begin) {
+                           float grad_scale, int first_step, uint4* __restrict__ w4, int64_t range_begin, int zero_g) {
   const int64_t nvec = total >> 2;            // (total = end of the range to update, range_begin its first element)
   for (int64_t v = (range_begin >> 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; v < nvec;
        v += (int64_t)gridDim.x * blockDim.x) {
@@ -557,8 +558,12 @@ __global__ void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, f
     if (i + 4 <= end) {
       *(float4*)(p + i) = pv;
       *(float4*)(buf + i) = bv;
+      if (zero_g) *(float4*)(g + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     } else {
-      for (int k = 0; k < 4 && i + k < end; ++k) { p[i + k] = pp[k]; buf[i + k] = bp[k]; }
+      for (int k = 0; k < 4 && i + k < end; ++k) {
+        p[i + k] = pp[k]; buf[i + k] = bp[k];
+        if (zero_g) g[i + k] = 0.f;
+      }
     }
     if (w4) {                                   // (a tensor's last partial quad: its image is never read as a quad)
       uint2 hi, lo;
@@ -700,10 +705,10 @@ CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q,
   return cpm::check_launch("upsample2x_add_backward");
 }
 
-static int sgd_step_impl(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
+static int sgd_step_impl(float* params, float* grads, float* momentum_buf, const int32_t* block_seg,
                          const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
                          const float* h_group_wd, int ngroups, int64_t begin, int64_t end, float momentum,
-                         float grad_scale, int first_step, void* w4_out, void* stream) {
+                         float grad_scale, int first_step, void* w4_out, void* stream, int zero_g = 0) {
   CPM_REQUIRE(params && grads && momentum_buf && block_seg && seg_end && seg_group && h_group_lr && h_group_wd,
               "null pointer");
   CPM_REQUIRE(ngroups > 0 && ngroups <= 8 && begin >= 0 && end >= begin && end % 64 == 0 && begin % 64 == 0,
@@ -714,7 +719,7 @@ static int sgd_step_impl(float* params, const float* grads, float* momentum_buf,
   for (int i = 0; i < ngroups; ++i) { grp.lr[i] = h_group_lr[i]; grp.wd[i] = h_group_wd[i]; }
   hipLaunchKernelGGL(sgd_kernel, dim3(grid_for((end - begin) / 4, 256, 16384)), dim3(256), 0, (hipStream_t)stream, params,
                      grads, momentum_buf, block_seg, seg_end, seg_group, grp, end, momentum, grad_scale, first_step,
-                     (uint4*)w4_out, begin);
+                     (uint4*)w4_out, begin, zero_g);
   return cpm::check_launch("sgd_step");
 }
 
@@ -723,8 +728,8 @@ CPM_EXPORT int cpm_sgd_step(float* params, const float* grads, float* momentum_b
                             const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
                             int first_step, void* stream) {
   CPM_REQUIRE(total > 0, "bad shape (total % 64, <= 8 groups)");
-  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, 0, total,
-                       momentum, grad_scale, first_step, nullptr, stream);
+  return sgd_step_impl(params, const_cast<float*>(grads), momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd,
+                       ngroups, 0, total, momentum, grad_scale, first_step, nullptr, stream);
 }
 
 // the same, and the pre-split image (cpm_split_w4's format, `total` floats' worth of bytes at the parameters' own
@@ -734,17 +739,18 @@ CPM_EXPORT int cpm_sgd_step_w4(float* params, const float* grads, float* momentu
                                const float* h_group_wd, int ngroups, int64_t total, float momentum, float grad_scale,
                                int first_step, void* w4_out, void* stream) {
   CPM_REQUIRE(w4_out && total > 0, "null image buffer");
-  return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, 0, total,
-                       momentum, grad_scale, first_step, w4_out, stream);
+  return sgd_step_impl(params, const_cast<float*>(grads), momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd,
+                       ngroups, 0, total, momentum, grad_scale, first_step, w4_out, stream);
 }
 
 // the update of elements [begin, end) only (both on 64-element boundaries; pointers are those of the WHOLE buffers):
 // a data-parallel trainer updates a chunk of the flat buffer as soon as its gradients are complete (and all-reduced),
-// beside the rest of the backward pass.  w4_out may be NULL.
-CPM_EXPORT int cpm_sgd_step_range(float* params, const float* grads, float* momentum_buf, const int32_t* block_seg,
+// beside the rest of the backward pass.  w4_out may be NULL.  zero_grads != 0: every gradient element is set to zero
+// behind its use -- the next step's zero_grad without its own pass over the buffer.
+CPM_EXPORT int cpm_sgd_step_range(float* params, float* grads, float* momentum_buf, const int32_t* block_seg,
                                   const int64_t* seg_end, const int32_t* seg_group, const float* h_group_lr,
                                   const float* h_group_wd, int ngroups, int64_t begin, int64_t end, float momentum,
-                                  float grad_scale, int first_step, void* w4_out, void* stream) {
+                                  float grad_scale, int first_step, void* w4_out, int zero_grads, void* stream) {
   return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, begin,
-                       end, momentum, grad_scale, first_step, w4_out, stream);
+                       end, momentum, grad_scale, first_step, w4_out, stream, zero_grads);
 }

@@ -51,6 +51,7 @@ class FlatSGD(torch.optim.Optimizer):
         self.block_seg = table.to(device)
         self.total, self.momentum, self._steps, self._last = total, float(momentum), 0, None
         self._stepped_end, self._w4_fresh = 0, False
+        self.clear_grads_in_step, self._grads_cleared = False, False
         self.grad_scale = 1.0
         groups = []
         for gi, g in enumerate(groups_cfg):
@@ -144,7 +145,11 @@ class FlatSGD(torch.optim.Optimizer):
         self._steps = 1 if loaded else 0
 
     def zero_grad(self, set_to_none=False):
-        self.flat_grad.zero_()                                       # one memset; .grad views stay attached
+        # one memset; .grad views stay attached.  With `clear_grads_in_step` (a trainer's choice: gradients are then zero
+        # after step(), unlike torch.optim's) the SGD kernel has already cleared every element behind its use.
+        if not (self.clear_grads_in_step and self._grads_cleared):
+            self.flat_grad.zero_()
+        self._grads_cleared = False
         for g in self.param_groups:
             for p in g["params"]:
                 if hasattr(p, "_cpm_uses"):
@@ -173,7 +178,8 @@ class FlatSGD(torch.optim.Optimizer):
                                             H.ptr(self.block_seg), H.ptr(self.seg_end), H.ptr(self.seg_pg), lr, wd, ng,
                                             H.c_int64(begin), H.c_int64(end), H.f(self.momentum),
                                             H.f(self.grad_scale), int(self._steps == 0),
-                                            H.ptr(self.flat_w4) if w4 else None, H.stream())
+                                            H.ptr(self.flat_w4) if w4 else None, int(self.clear_grads_in_step),
+                                            H.stream())
         H.check(rc, "sgd_step")
         self._stepped_end = end
 
@@ -183,6 +189,7 @@ class FlatSGD(torch.optim.Optimizer):
             self.step_range(self._stepped_end, self.total)
         self._stepped_end = 0
         self._steps += 1
+        self._grads_cleared = bool(self.clear_grads_in_step)
         self._mark_w4(self._w4_fresh)
         self._refresh_dgrad_weights()
 

@@ -403,6 +403,7 @@ def test_flat_sgd_in_ranges_equals_one_pass():
             return ps, FlatSGD([("p%d" % i, p, k) for i, (p, k) in enumerate(zip(ps, kinds))], groups, 0.9)
 
         (pa, oa), (pb, ob) = build(), build()
+        ob.clear_grads_in_step = True                     # ... and the gradients are zero behind the ranged update
         ends = [((e + 63) // 64) * 64 for e in oa.seg_end.tolist()]
         for step in range(3):
             g = torch.randn(oa.total, device="cuda")
@@ -415,7 +416,9 @@ def test_flat_sgd_in_ranges_equals_one_pass():
             ob.step_range(0, ends[1])                     # two tensors, then three, the rest in step()
             ob.step_range(ends[1], ends[4])
             ob.step()
+            assert float(oa.flat_grad.abs().max()) > 0
             for b, e in zip(oa.seg_begin.tolist(), oa.seg_end.tolist()):          # (the alignment gaps hold no data)
+                assert not ob.flat_grad[b:e].any()
                 assert torch.equal(oa.flat_param[b:e], ob.flat_param[b:e]) and torch.equal(oa.flat_mom[b:e], ob.flat_mom[b:e])
                 e4 = b + (e - b) // 4 * 4
                 assert torch.equal(oa.flat_w4[b:e4], ob.flat_w4[b:e4])

@@ -29,11 +29,24 @@ def main():
     for _ in range(6):
         tr.step(images, targets)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
         for _ in range(3):
             tr.step(images, targets)
         torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=40, max_name_column_width=70))
+    # who zero-fills / copies what: the ATen calls with their shapes and Python callers
+    seen = {}
+    for e in prof.events():
+        if e.name in ("aten::zero_", "aten::fill_", "aten::copy_", "aten::add_", "aten::add", "aten::mul", "aten::sum",
+                      "aten::cat", "aten::index", "aten::index_select", "aten::contiguous", "aten::clone"):
+            shp = str(e.input_shapes[:2])
+            st = " <- ".join(f.split("/")[-1] for f in (e.stack or [])[:4] if "torch/" not in f)
+            k = (e.name, shp, st)
+            a = seen.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total
+    for k, a in sorted(seen.items(), key=lambda kv: -kv[1][1])[:40]:
+        print("%-14s x%-3d %8.1f us  %s  %s" % (k[0], a[0], a[1], k[1], k[2]))
     print(prof.key_averages(group_by_stack_n=4).table(sort_by="cuda_time_total", row_limit=30, max_name_column_width=60,
                                                       max_src_column_width=90))
 
