@@ -1002,22 +1002,34 @@ def mlp_chain(x, linears, owner):
     return x
 
 
-def stem_forward(x, w_pad, scale, shift, r=7, s=7, stride=2, pad=3):
-    """ResNet stem (backbone/ResNet.py:123-136): 7x7/s2 conv on 3 channels as im2col + 1x1 MFMA GEMM with the
-    frozen affine + ReLU fused, then the 3x3/s2 max-pool.  Frozen stage: forward only.
+_STEM_FUSED = os.environ.get("CPM_STEM_FUSED", "1") != "0"
+
+
+def stem_forward(x, w_pad, scale, shift, r=7, s=7, stride=2, pad=3, w=None):
+    """ResNet stem (backbone/ResNet.py:123-136): 7x7/s2 conv on 3 channels with the frozen affine + ReLU fused, then the
+    3x3/s2 max-pool.  Frozen stage: forward only.  Under bf16x3 on an NHWC image the conv is ONE kernel reading the
+    image (cpm_stem7x7_forward, `w` = conv1.weight); otherwise im2col + 1x1 MFMA GEMM on
     w_pad: [K, Kpad, 1, 1] = conv1.weight in (r,s,c) column order, zero padded to a multiple of 32."""
     H.require_gpu(x, w_pad, scale, shift)
-    n, c, h, w = x.shape
+    n, c, h, wd = x.shape
     is_nhwc = x.is_contiguous(memory_format=CL) and not x.is_contiguous()
-    xin = x if (is_nhwc or x.is_contiguous()) else x.contiguous()
-    p, q = out_size(h, r, stride, pad), out_size(w, s, stride, pad)
-    kpad = w_pad.shape[1]
-    cols = torch.empty((n * p * q, kpad), dtype=torch.float32, device=x.device)
-    with H.guard(x.device):
-        rc = H.lib().cpm_im2col(H.ptr(xin), 1 if is_nhwc else 0, n, c, h, w, r, s, stride, pad, p, q, kpad,
-                                H.ptr(cols), H.stream())
-    H.check(rc, "im2col")
-    y = conv2d_forward(cols.view(n, p, q, kpad).permute(0, 3, 1, 2), w_pad, scale, shift, None, 0, True, 1, 0, 1, 1)
+    p, q = out_size(h, r, stride, pad), out_size(wd, s, stride, pad)
+    if (_STEM_FUSED and w is not None and is_nhwc and (c, r, s, stride, pad) == (3, 7, 7, 2, 3) and w.shape[0] == 64
+            and bf16x3() and n * h * wd * 3 < 2 ** 31):
+        y = empty_nhwc((n, 64, p, q), x)
+        with H.guard(x.device):
+            rc = H.lib().cpm_stem7x7_forward(H.ptr(x), H.ptr(_wmem(w.detach())), H.ptr(scale), H.ptr(shift), 1, n, h, wd,
+                                             H.ptr(y), H.stream())
+        H.check(rc, "stem7x7_forward")
+    else:
+        xin = x if (is_nhwc or x.is_contiguous()) else x.contiguous()
+        kpad = w_pad.shape[1]
+        cols = torch.empty((n * p * q, kpad), dtype=torch.float32, device=x.device)
+        with H.guard(x.device):
+            rc = H.lib().cpm_im2col(H.ptr(xin), 1 if is_nhwc else 0, n, c, h, wd, r, s, stride, pad, p, q, kpad,
+                                    H.ptr(cols), H.stream())
+        H.check(rc, "im2col")
+        y = conv2d_forward(cols.view(n, p, q, kpad).permute(0, 3, 1, 2), w_pad, scale, shift, None, 0, True, 1, 0, 1, 1)
     pp, pq = out_size(p, 3, 2, 1), out_size(q, 3, 2, 1)
     out = empty_nhwc((n, y.shape[1], pp, pq), x)
     with H.guard(x.device):

@@ -84,7 +84,7 @@ class ResNet(res.ResNet):
         if self.conv1.weight.requires_grad:
             raise RuntimeError("the stem runs forward-only (BACKBONE.RESNET.FREEZE_AT must be >= 2)")
         s, b = res._affine(self.bn1)
-        x = ops.stem_forward(x, self._stem_weight(), s, b, 7, 7, 2, 3)
+        x = ops.stem_forward(x, self._stem_weight(), s, b, 7, 7, 2, 3, w=self.conv1.weight)
         x2 = self.layer1(x)
         x3 = self.layer2(x2)
         x4 = self.layer3(x3)

@@ -243,6 +243,11 @@ int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, i
 int cpm_im2col(const float* x, int layout, int N, int C, int H, int W, int R, int S, int stride, int pad,
                int P, int Q, int Kpad, float* out, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the stem (backbone/ResNet.py:136), NHWC, forward only (frozen stage) */
+/* The ResNet / ResNeXt stem as one kernel (bf16x3 arithmetic only): y = relu?(conv7x7 / stride 2 / pad 3 (x) * scale +
+ * shift), x NHWC [N][H][W][3], w KRSC [64][7][7][3], y NHWC [N][P][Q][64] -- no column image (pet/models/imagenet/
+ * resnet.py:175-181: conv1 + frozen bn1 + relu; the max-pool follows as cpm_maxpool3x3s2_forward). */
+int cpm_stem7x7_forward(const float* x, const float* w, const float* scale, const float* shift, int relu, int N, int H,
+                        int W, float* y, void* stream);
 int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int C, int P, int Q, float* y, void* stream);
 
 /* ---- Deformable conv v1 / narrow-group 3x3 (ResNeXt-64x4d + DCN body) -------

@@ -218,18 +218,23 @@ def test_group_norm(n, c, hw, g, relu):
     assert relerr(xd.grad, xr.grad) < TOL and relerr(gd.grad, gr.grad) < TOL and relerr(bd.grad, br.grad) < TOL
 
 
-def test_stem():
+@pytest.mark.parametrize("shape", [(2, 64, 96), (1, 65, 199), (3, 33, 400), (1, 7, 7)], ids=lambda s: "%dx%dx%d" % s)
+def test_stem(shape, conv_math):
+    """The stem both ways: im2col + GEMM (either arithmetic, either image layout) and, under bf16x3 on an NHWC image, the
+    one-kernel form reading the image (cpm_stem7x7_forward: ragged last tile, odd sizes, the image borders)."""
     from pet.lib.ops import conv as ops
-    N, H, W = 2, 64, 96
+    N, H, W = shape
     x = rnd(N, 3, H, W, seed=1) * 50
     w = rnd(64, 3, 7, 7, seed=2, scale=0.05)
     sc, sh = torch.rand(64) + 0.5, rnd(64, seed=3)
     yr = F.max_pool2d(F.relu(F.conv2d(x, w, None, 2, 3) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)), 3, 2, 1)
     wp = torch.zeros(64, 160)
     wp[:, :147] = w.permute(0, 2, 3, 1).reshape(64, 147)
+    wd = w.cuda().contiguous(memory_format=CL)
     for xin in (x.cuda(), x.cuda().contiguous(memory_format=CL)):
-        y = ops.stem_forward(xin, wp.cuda().view(64, 160, 1, 1), sc.cuda(), sh.cuda())
-        assert y.shape == yr.shape and relerr(y, yr) < TOL
+        for wk in (None, wd):
+            y = ops.stem_forward(xin, wp.cuda().view(64, 160, 1, 1), sc.cuda(), sh.cuda(), w=wk)
+            assert y.shape == yr.shape and relerr(y, yr) < TOL
 
 
 def test_conv_errors():
