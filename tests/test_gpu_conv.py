@@ -505,6 +505,59 @@ def test_error_bound_of_both_arithmetics_wide_dynamic_range(conv_math):
     assert err < (2e-6 if conv_math == "f32" else 3e-5), (conv_math, err)
 
 
+def test_side_stream_workspace_survives_growth_in_deterministic_mode():
+    """in deterministic mode the weight-gradient slab planes live in the per-stream workspace, and
+    the second stream's workspace grows when the RoI count rises.  A replaced buffer must stay out of the allocator's
+    hands until the compute stream has waited for the second one (H.workspace parks it, conv._join_side releases it):
+    a stack of layers run with a rising number of samples, weight gradients on the second stream, compute stream busy
+    allocating and writing right behind every backward pass -- the weight gradients must equal the one-stream run's
+    bit for bit."""
+    import torch.nn as nn
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    from pet.rcnn.core import config
+    from pet.utils.optimizer import Optimizer
+
+    class Stack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs = nn.ModuleList([ops.Conv2d(64, 64, 3, 1, 1) for _ in range(3)])
+
+        def forward(self, x):
+            for c in self.convs:
+                x = c(x)
+            return x
+
+    config.reset_cfg()
+    prev_side = C._SIDE_WGRAD
+    _hip.set_deterministic(True)
+    try:
+        torch.manual_seed(3)
+        m = Stack().cuda().to(memory_format=CL)
+        opt = Optimizer(m, config.cfg.SOLVER).build()
+        _hip._ws.clear()                                   # start from small workspaces: every size below makes them grow
+        for n in (3, 9, 40, 170):
+            x0 = rnd(n, 64, 14, 14, seed=n).cuda().contiguous(memory_format=CL)
+            dy = rnd(n, 64, 14, 14, seed=n + 1).cuda().contiguous(memory_format=CL)
+            got = {}
+            for side in (True, False):
+                C._SIDE_WGRAD = side
+                opt.zero_grad()
+                m(x0.clone().requires_grad_(True)).backward(dy)
+                # what the allocator would hand out next, overwritten at once on the compute stream
+                junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
+                torch.cuda.synchronize()
+                del junk
+                got[side] = [c.weight.grad.clone() for c in m.convs]     # (bias sums use float atomics: not compared)
+            for a, b in zip(got[True], got[False]):
+                assert torch.isfinite(a).all() and torch.equal(a, b), n
+    finally:
+        C._SIDE_WGRAD = prev_side
+        _hip.set_deterministic(False)
+        config.reset_cfg()
+
+
 def test_conv_gn_stack_equals_layer_by_layer():
     """cpm_layer_chain_forward / _backward (one native call per direction for a stack of conv + bias -> GroupNorm ->
     ReLU layers, the grid head's shape) against the same layers run op by op: the same C-ABI calls in the same order,
