@@ -29,7 +29,8 @@ def _run(body, layers, batch, meta_file, grid_cap):
         meta = json.load(f)
     try:
         tr = Trainer(device, layers=layers, body=body)
-        model = tr.model
+        tr.optimizer.clear_grads_in_step = False       # this test reads the gradients behind the step (bench.py's loop
+        model = tr.model                                # lets the SGD kernel clear them: FlatSGD.clear_grads_in_step)
         assert [[k, list(v.shape)] for k, v in model.state_dict().items()] == meta["state_dict"]
         trainable = [k for k, p in model.named_parameters() if p.requires_grad]
         assert trainable == meta["trainable"]
