@@ -67,6 +67,19 @@ def set_conv_math(mode):
         raise RuntimeError("conv math must be one of %s" % sorted(CONV_MATH))
     rc = lib().cpm_set_conv_math(CONV_MATH[mode])
     check(rc, "set_conv_math")
+    global _is_bf16x3
+    _is_bf16x3 = mode == "bf16x3"
+
+
+_is_bf16x3 = None
+
+
+def bf16x3():
+    """the conv arithmetic is bf16x3 (cached: asked once per conv call; only set_conv_math changes it)"""
+    global _is_bf16x3
+    if _is_bf16x3 is None:
+        _is_bf16x3 = lib().cpm_get_conv_math() == CONV_MATH["bf16x3"]
+    return _is_bf16x3
 
 
 def get_conv_math():

@@ -74,8 +74,7 @@ def split_w4(w, out=None):
 _W4 = os.environ.get("CPM_W4", "1") != "0"
 
 
-def bf16x3():
-    return H.lib().cpm_get_conv_math() == 1
+bf16x3 = H.bf16x3
 
 
 def w4_of(w_in, w, cg):
@@ -803,6 +802,7 @@ class _ChainPlan(object):
         self.ptrs = self._pointers()
         self.wt_ptrs = None
         self.w4_ptrs = None
+        self.w4_key = None
         self.weights = tuple(sp[0] for sp in specs)
         self.sizes = {}
 
@@ -838,8 +838,21 @@ class _ChainPlan(object):
                 self.table[i].wt, self.table[i].wt_w4 = wts[2 * i], wts[2 * i + 1]
             self.wt_ptrs = wts
 
+    def _w4_state(self):
+        """(version, version of the image, address of the image) per weight: equal states mean the table is current"""
+        out = []
+        for w in self.weights:
+            own = getattr(w, "_cpm_owner", w)
+            t = getattr(own, "_cpm_w4", None)
+            out.append((own._version, getattr(own, "_cpm_w4_version", None), t.data_ptr() if t is not None else 0))
+        return tuple(out)
+
     def refresh_w4(self):
         """pre-split images of the weights for the forward convs (w4_of); the native loop reads them under bf16x3 only"""
+        if not bf16x3():
+            return
+        if self.w4_key is not None and self.w4_key == self._w4_state():
+            return                                      # nothing moved since the table was filled
         ptrs = []
         for w in self.weights:
             t = w4_of(w, w if w.dim() == 2 else _wmem(w), w.shape[1])
@@ -849,6 +862,8 @@ class _ChainPlan(object):
             for i, v in enumerate(ptrs):
                 self.table[i].w4 = v
             self.w4_ptrs = ptrs
+        state = self._w4_state()
+        self.w4_key = state if all(v == iv for v, iv, _ in state) else None
 
 
 class _LayerChainFn(Function):
