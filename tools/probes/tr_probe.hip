@@ -1,3 +1,5 @@
+// build: hipcc --offload-arch=gfx950 -O2 -o tools/probes/tr_probe tools/probes/tr_probe.hip ; run on the GPU box: prints, per lane,
+// which (row, column) of a [row][col] 16-bit LDS image each element of ds_read_b64_tr_b16 delivers (used for wgrad_taps_kernel)
 // probe of ds_read_b64_tr_b16 (gfx950): which (row, column) of a [row][col] 16-bit LDS image lands in which lane element
 #include <hip/hip_runtime.h>
 #include <stdio.h>
