@@ -573,6 +573,55 @@ __global__ void sgd_kernel(float* __restrict__ p, float* __restrict__ g, float* 
   }
 }
 
+// ---- data gradient of the RPN's two 1x1 predictors, all levels, one launch -----------------------------------------
+// rpn/rpn.py:24-31: cls_logits (A channels) and bbox_pred (4A channels) read the same ReLU'd map t.  Their data gradients
+// have reductions of 3 and 12: as implicit GEMMs they are two passes over the 137 MB gradient of P2's map at 2-6 TFLOP/s
+// (223 us; the second one adds into the first one's output).  Here: dx = [t > 0] * (dy_cls W_cls + dy_box W_box) for
+// every pixel of every level, one float4 of channels per thread, the 5A x C weights in LDS -- one read of t, one write
+// of dx.
+struct PredLevels {
+  const float* dy_cls[8];
+  const float* dy_box[8];
+  const float* t[8];
+  float* dx[8];
+  int64_t pix_end[8];          // cumulative pixel counts
+  int n;
+};
+
+__global__ __launch_bounds__(256) void rpn_pred_dgrad_kernel(PredLevels L, const float* __restrict__ w_cls,
+                                                             const float* __restrict__ w_box, int A, int C, int gate) {
+  extern __shared__ float pw[];                        // [5A][C]
+  for (int i = threadIdx.x; i < 5 * A * C; i += 256) pw[i] = i < A * C ? w_cls[i] : w_box[i - A * C];
+  __syncthreads();
+  const int q = C >> 2, ppb = 256 / q;
+  const int cq = threadIdx.x % q, pl = threadIdx.x / q;
+  const int64_t total = L.pix_end[L.n - 1];
+  for (int64_t p = (int64_t)blockIdx.x * ppb + pl; p < total; p += (int64_t)gridDim.x * ppb) {
+    int lv = 0;
+    while (p >= L.pix_end[lv]) ++lv;
+    const int64_t pi = p - (lv ? L.pix_end[lv - 1] : 0);
+    const float* dc = L.dy_cls[lv] + pi * A;
+    const float* db = L.dy_box[lv] + pi * 4 * A;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < A; ++k) {
+      const float g = dc[k];
+      const float4 w = *(const float4*)&pw[k * C + 4 * cq];
+      acc.x += g * w.x; acc.y += g * w.y; acc.z += g * w.z; acc.w += g * w.w;
+    }
+    for (int k = 0; k < 4 * A; ++k) {
+      const float g = db[k];
+      const float4 w = *(const float4*)&pw[(A + k) * C + 4 * cq];
+      acc.x += g * w.x; acc.y += g * w.y; acc.z += g * w.z; acc.w += g * w.w;
+    }
+    if (gate) {
+      const float4 tv = *(const float4*)(L.t[lv] + pi * C + 4 * cq);
+      acc.x = tv.x > 0.f ? acc.x : 0.f; acc.y = tv.y > 0.f ? acc.y : 0.f;
+      acc.z = tv.z > 0.f ? acc.z : 0.f; acc.w = tv.w > 0.f ? acc.w : 0.f;
+    }
+    *(float4*)(L.dx[lv] + pi * C + 4 * cq) = acc;
+  }
+}
+
 }  // namespace
 
 CPM_EXPORT int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, int relu, int64_t M,
@@ -753,4 +802,28 @@ CPM_EXPORT int cpm_sgd_step_range(float* params, float* grads, float* momentum_b
                                   float grad_scale, int first_step, void* w4_out, int zero_grads, void* stream) {
   return sgd_step_impl(params, grads, momentum_buf, block_seg, seg_end, seg_group, h_group_lr, h_group_wd, ngroups, begin,
                        end, momentum, grad_scale, first_step, w4_out, stream, zero_grads);
+}
+
+CPM_EXPORT int cpm_rpn_pred_backward_data(const float* const* dy_cls, const float* const* dy_box, const float* const* t,
+                                          float* const* dx, const int64_t* pixels, int n_levels, const float* w_cls,
+                                          const float* w_box, int A, int C, int gate, void* stream) {
+  CPM_REQUIRE(dy_cls && dy_box && dx && pixels && w_cls && w_box && (t || !gate), "null pointer");
+  CPM_REQUIRE(n_levels >= 1 && n_levels <= 8 && A >= 1 && C >= 4 && C % 4 == 0 && 256 % (C / 4) == 0,
+              "1..8 levels, C a multiple of 4 with C / 4 dividing 256");
+  CPM_REQUIRE((size_t)5 * A * C * sizeof(float) <= 64 * 1024, "5 A C floats of weights must fit 64 KB of LDS");
+  PredLevels L = {};
+  L.n = n_levels;
+  int64_t tot = 0;
+  for (int i = 0; i < n_levels; ++i) {
+    CPM_REQUIRE(pixels[i] >= 0 && dy_cls[i] && dy_box[i] && dx[i] && (!gate || t[i]), "null level");
+    CPM_REQUIRE((((uintptr_t)dx[i] | (uintptr_t)(gate ? t[i] : dx[i])) & 15) == 0, "16-byte aligned maps");
+    L.dy_cls[i] = dy_cls[i]; L.dy_box[i] = dy_box[i]; L.t[i] = gate ? t[i] : nullptr; L.dx[i] = dx[i];
+    tot += pixels[i];
+    L.pix_end[i] = tot;
+  }
+  if (tot == 0) return CPM_OK;
+  const int ppb = 256 / (C / 4);
+  hipLaunchKernelGGL(rpn_pred_dgrad_kernel, dim3(grid_for(cpm::cdiv(tot, (int64_t)ppb) * 256, 256, 8192)), dim3(256),
+                     (size_t)5 * A * C * sizeof(float), (hipStream_t)stream, L, w_cls, w_box, A, C, gate);
+  return cpm::check_launch("rpn_pred_backward_data");
 }

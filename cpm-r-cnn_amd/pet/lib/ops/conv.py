@@ -585,6 +585,111 @@ class _ConvFn(Function):
         return dx, dw, None, dshift, gres, None, None, None, None, None, None, None
 
 
+class _RPNPredFn(Function):
+    """The RPN head's two 1x1 predictors on every level as ONE autograd node (rpn/rpn.py:24-31):
+    (cls_logits_l, bbox_pred_l) = (conv1x1(t_l, wc) + bc, conv1x1(t_l, wb) + bb).  Forward and weight / bias gradients
+    are the per-level calls of _ConvFn; the data gradient of all levels and both predictors is one launch
+    (cpm_rpn_pred_backward_data) that also applies the ReLU gate of the producing conv (its `gate_by_consumers` tag),
+    instead of 2 x levels implicit GEMMs with reductions of 3 and 12."""
+
+    @staticmethod
+    def forward(ctx, wc, bc, wb, bb, *ts):
+        H.require_gpu(wc, bc, wb, bb, *ts)
+        xs = [nhwc(t) for t in ts]
+        wcm, wbm = _wmem(wc), _wmem(wb)
+        c = xs[0].shape[1]
+        w4c, w4b = w4_of(wc, wcm, c), w4_of(wb, wbm, c)
+        outs_c = [conv2d_forward(x, wcm, None, bc, None, 0, False, 1, 0, 1, 1, w4=w4c) for x in xs]
+        outs_b = [conv2d_forward(x, wbm, None, bb, None, 0, False, 1, 0, 1, 1, w4=w4b) for x in xs]
+        # parameters owned by the flat optimizer take their gradients in place (see _ConvFn.forward)
+        ctx.sinks = [_sink_of(p, ctx.needs_input_grad[i]) if p.data_ptr() == m.data_ptr() else None
+                     for i, (p, m) in enumerate(((wc, wcm), (bc, bc), (wb, wbm), (bb, bb)))]
+        ctx.tags = [getattr(t, "_cpm_epi", None) for t in ts]
+        ctx.n = len(ts)
+        ctx.save_for_backward(wcm, wbm, *xs)
+        return tuple(outs_c + outs_b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        wcm, wbm = ctx.saved_tensors[:2]
+        xs = ctx.saved_tensors[2:]
+        n = ctx.n
+        a, c = wcm.shape[0], wcm.shape[1]
+        dcs = [nhwc(g) if g is not None else torch.zeros((x.shape[0], a, x.shape[2], x.shape[3]), device=x.device).contiguous(memory_format=CL)
+               for g, x in zip(grads[:n], xs)]
+        dbs = [nhwc(g) if g is not None else torch.zeros((x.shape[0], 4 * a, x.shape[2], x.shape[3]), device=x.device).contiguous(memory_format=CL)
+               for g, x in zip(grads[n:], xs)]
+        need = ctx.needs_input_grad
+        # ---- weight / bias gradients (second stream when the parameters take them in place) ------------------------
+        dw = [None, None, None, None]
+        for wi, (wm, dys) in enumerate(((wcm, dcs), (wbm, dbs))):
+            need_w, need_b = need[2 * wi], need[2 * wi + 1]
+            if not (need_w or need_b):
+                continue
+            wp, bp = ctx.sinks[2 * wi], ctx.sinks[2 * wi + 1]
+            if wp is not None and (bp is not None or not need_b) and need_w:
+                for x, dy in zip(xs, dys):
+                    if x.numel() == 0:
+                        continue
+                    dbias = bp._cpm_grad_sink if bp is not None else None
+                    if _SIDE_WGRAD:
+                        _wgrad_on_side(x, dy, wm, 1, 0, 1, 1, wp._cpm_grad_sink, dbias)
+                    else:
+                        conv2d_backward_weight(x, dy, wm, 1, 0, 1, 1, out=wp._cpm_grad_sink, dbias=dbias)
+            else:
+                # a gradient autograd accumulates: the in-place routes that were counted in forward are released
+                acc_w = torch.zeros_like(wm) if need_w else None
+                acc_b = torch.zeros(wm.shape[0], dtype=torch.float32, device=wm.device) if need_b else None
+                for x, dy in zip(xs, dys):
+                    if x.numel() == 0:
+                        continue
+                    if need_w:
+                        conv2d_backward_weight(x, dy, wm, 1, 0, 1, 1, out=acc_w, dbias=acc_b)
+                    elif need_b:
+                        acc_b += dy.sum(dim=(0, 2, 3))
+                dw[2 * wi], dw[2 * wi + 1] = acc_w, acc_b
+                for p_ in (wp, bp):
+                    if p_ is not None:
+                        p_._cpm_uses -= 1
+                ctx.sinks[2 * wi] = ctx.sinks[2 * wi + 1] = None
+        # ---- data gradient: every level, both predictors, the producer's ReLU gate -- one launch ------------------
+        dts = [None] * n
+        if any(need[4:]):
+            gate = all(tag is not None for tag in ctx.tags)
+            dts = [torch.empty_like(x) for x in xs]
+            P = H.ctypes.c_void_p
+            arr = lambda ts_: (P * n)(*[t.data_ptr() for t in ts_])
+            pix = (H.ctypes.c_int64 * n)(*[x.shape[0] * x.shape[2] * x.shape[3] for x in xs])
+            with H.guard(xs[0].device):
+                rc = H.lib().cpm_rpn_pred_backward_data(arr(dcs), arr(dbs), arr(xs), arr(dts), pix, n, H.ptr(wcm),
+                                                        H.ptr(wbm), int(a), int(c), int(gate), H.stream())
+            H.check(rc, "rpn_pred_backward_data")
+            for tag in ctx.tags:
+                if tag is not None:
+                    tag["applied"] = gate
+        for p_ in ctx.sinks:
+            if p_ is not None:
+                _sink_done(p_)
+        return (dw[0], dw[1], dw[2], dw[3]) + tuple(dts)
+
+
+_RPN_PRED_FUSED = os.environ.get("CPM_RPN_PRED_FUSED", "1") != "0"
+
+
+def rpn_predictors(ts, wc, bc, wb, bb):
+    """([cls_logits(t) for t in ts], [bbox_pred(t) for t in ts]) -- one autograd node, see _RPNPredFn.  None when the
+    shapes are outside the fused data-gradient kernel (the caller then runs the two convs per level)."""
+    c = wc.shape[1]
+    if (not _RPN_PRED_FUSED or len(ts) < 1 or len(ts) > 8 or c % 4 or 256 % (c // 4) or 5 * wc.shape[0] * c * 4 > 65536
+            or wb.shape[0] != 4 * wc.shape[0] or tuple(wc.shape[2:]) != (1, 1) or tuple(wb.shape[2:]) != (1, 1)
+            or bc is None or bb is None or any(t.dim() != 4 or t.shape[1] != c for t in ts)):
+        return None
+    outs = _RPNPredFn.apply(wc, bc, wb, bb, *ts)
+    n = len(ts)
+    return list(outs[:n]), list(outs[n:])
+
+
 def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, groups=1, relu=False, res_mode=0,
            sole_consumer=False, gate_by_consumers=False):
     """sole_consumer / gate_by_consumers: the caller promises that y = relu(..) is consumed ONLY by convolutions of

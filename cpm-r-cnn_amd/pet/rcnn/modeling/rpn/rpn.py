@@ -23,10 +23,16 @@ class RPNHead(nn.Module):
             nn.init.constant_(l.bias, 0)
 
     def forward(self, x):
+        # both predictors on every level as one autograd node: their data gradients (reductions of 3 and 12, two passes
+        # over each level's map) become one launch that also applies this conv's ReLU gate (ops.conv._RPNPredFn)
+        ts = [self.conv(feature, relu=True, gate_by_consumers=True) for feature in x]
+        fused = ops.rpn_predictors(ts, self.cls_logits.weight, self.cls_logits.bias, self.bbox_pred.weight,
+                                   self.bbox_pred.bias) if ts else None
+        if fused is not None:
+            return fused
         logits, bbox_reg = [], []
-        for feature in x:
-            # consumers: the two 1x1 predictors, which also apply this conv's ReLU gate in their data gradients
-            t = ops.mark_shared_grad(self.conv(feature, relu=True, gate_by_consumers=True))
+        for t in ts:
+            t = ops.mark_shared_grad(t)
             logits.append(self.cls_logits(t))
             bbox_reg.append(self.bbox_pred(t))
         return logits, bbox_reg

@@ -243,6 +243,14 @@ int cpm_epilogue_backward(const float* dy, const float* y, const float* scale, i
 int cpm_im2col(const float* x, int layout, int N, int C, int H, int W, int R, int S, int stride, int pad,
                int P, int Q, int Kpad, float* out, void* stream);
 /* nn.MaxPool2d(3, 2, 1) of the stem (backbone/ResNet.py:136), NHWC, forward only (frozen stage) */
+/* Data gradient of the RPN head's two 1x1 predictors (rpn/rpn.py:24-31: cls_logits, A channels, and bbox_pred, 4A
+ * channels, on the same map t) for ALL levels in one launch: dx_l = [t_l > 0] * (dy_cls_l W_cls + dy_box_l W_box) with
+ * gate != 0 (t = relu(..): the predictors apply their producer's ReLU gate), the plain sum otherwise.  Maps NHWC, level
+ * l has pixels[l] = N * H_l * W_l pixels; w_cls [A][C], w_box [4A][C]; C % 4 == 0, C / 4 divides 256.  Replaces 2 x
+ * n_levels implicit-GEMM launches with reductions of 3 and 12 (two passes over the gradient of P2's 137 MB map). */
+int cpm_rpn_pred_backward_data(const float* const* dy_cls, const float* const* dy_box, const float* const* t,
+                               float* const* dx, const int64_t* pixels, int n_levels, const float* w_cls,
+                               const float* w_box, int A, int C, int gate, void* stream);
 /* The ResNet / ResNeXt stem as one kernel (bf16x3 arithmetic only): y = relu?(conv7x7 / stride 2 / pad 3 (x) * scale +
  * shift), x NHWC [N][H][W][3], w KRSC [64][7][7][3], y NHWC [N][P][Q][64] -- no column image (pet/models/imagenet/
  * resnet.py:175-181: conv1 + frozen bn1 + relu; the max-pool follows as cpm_maxpool3x3s2_forward). */

@@ -505,6 +505,53 @@ def test_error_bound_of_both_arithmetics_wide_dynamic_range(conv_math):
     assert err < (2e-6 if conv_math == "f32" else 3e-5), (conv_math, err)
 
 
+@pytest.mark.parametrize("owned", [False, True], ids=["autograd_grads", "flat_optimizer_sinks"])
+def test_rpn_predictors_as_one_node(owned, conv_math):
+    """RPNHead with its two 1x1 predictors as one autograd node (ops.conv._RPNPredFn: the data gradient of all levels
+    and both predictors is one launch, cpm_rpn_pred_backward_data, which also applies the shared conv's ReLU gate)
+    against the same head run as two convs per level: outputs bit-identical, every parameter gradient and the input
+    gradients within 1e-5 of the tensor maximum -- with gradients accumulated by autograd and taken in place by the flat
+    optimizer's sinks (second stream)."""
+    from pet.lib.ops import conv as C
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.rpn.rpn import RPNHead
+    from pet.utils.optimizer import Optimizer
+    config.reset_cfg()
+    prev = C._RPN_PRED_FUSED
+    try:
+        torch.manual_seed(11)
+        head = RPNHead([256], 3).cuda().to(memory_format=CL)
+        with torch.no_grad():
+            for p in head.parameters():
+                p.copy_(torch.randn_like(p) * 0.05)
+        opt = Optimizer(head, config.cfg.SOLVER).build() if owned else None
+        shapes = [(2, 256, 40, 52), (2, 256, 20, 26), (2, 256, 10, 13), (2, 256, 5, 7), (2, 256, 3, 4)]
+        feats0 = [rnd(*sh, seed=30 + i).cuda().contiguous(memory_format=CL) for i, sh in enumerate(shapes)]
+        gl = [rnd(sh[0], 3, sh[2], sh[3], seed=50 + i).cuda().contiguous(memory_format=CL) for i, sh in enumerate(shapes)]
+        gb = [rnd(sh[0], 12, sh[2], sh[3], seed=70 + i).cuda().contiguous(memory_format=CL) for i, sh in enumerate(shapes)]
+        res = {}
+        for fused in (True, False):
+            C._RPN_PRED_FUSED = fused
+            if opt is not None:
+                opt.zero_grad()
+            else:
+                head.zero_grad(set_to_none=True)
+            feats = [f.clone().requires_grad_(True) for f in feats0]
+            logits, boxes = head(feats)
+            assert (logits[0].grad_fn.__class__.__name__ == "_RPNPredFnBackward") == fused
+            torch.autograd.backward(list(logits) + list(boxes), gl + gb)
+            torch.cuda.synchronize()
+            res[fused] = ([t.detach().clone() for t in list(logits) + list(boxes)], [f.grad.clone() for f in feats],
+                          [p.grad.clone() for p in head.parameters()])
+        for a, b in zip(res[True][0], res[False][0]):
+            assert torch.equal(a, b)
+        for a, b in zip(res[True][1] + res[True][2], res[False][1] + res[False][2]):
+            assert relerr(a, b) < 1e-5
+    finally:
+        C._RPN_PRED_FUSED = prev
+        config.reset_cfg()
+
+
 def test_side_stream_workspace_survives_growth_in_deterministic_mode():
     """in deterministic mode the weight-gradient slab planes live in the per-stream workspace, and
     the second stream's workspace grows when the RoI count rises.  A replaced buffer must stay out of the allocator's
