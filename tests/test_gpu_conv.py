@@ -505,6 +505,63 @@ def test_error_bound_of_both_arithmetics_wide_dynamic_range(conv_math):
     assert err < (2e-6 if conv_math == "f32" else 3e-5), (conv_math, err)
 
 
+def test_split_w4_image_format():
+    """cpm_split_w4's format, bit for bit: elements 4i..4i+3 of the float array -> 8 bytes of bf16 hi (round to nearest
+    even of x) and 8 bytes of bf16 lo (round to nearest even of x - hi, an exact f32 difference) at byte offset 16 i."""
+    from pet.lib.ops import conv as C
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4096, generator=g) * torch.logspace(-6, 6, 4096)
+    x[:8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3.0e38, -3.0e38, 1.0e-38, 65280.0])
+    img = C.split_w4(x.cuda()).cpu().numpy().view(np.uint16).reshape(-1, 8)          # per quad: hi0..3, lo0..3
+
+    def bf16_rne(v):
+        u = v.astype(np.float32).view(np.uint32).astype(np.uint64)
+        r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+        return r
+
+    xv = x.numpy().reshape(-1, 4)
+    hi = bf16_rne(xv)
+    hi_f = (hi.astype(np.uint32) << 16).view(np.float32)
+    lo = bf16_rne((xv - hi_f).astype(np.float32))
+    assert np.array_equal(img[:, :4], hi) and np.array_equal(img[:, 4:], lo)
+    # hi + lo carries 16 bits of the value: |x - (hi + lo)| <= 2^-16 |x| (2^-17 typical)
+    lo_f = (lo.astype(np.uint32) << 16).view(np.float32)
+    err = np.abs(xv - (hi_f + lo_f))
+    ok = np.abs(xv) > 1e-30
+    assert np.all(err[ok] <= np.abs(xv[ok]) * 2.0 ** -16)
+
+
+@pytest.mark.parametrize("gate", [0, 1])
+@pytest.mark.parametrize("c", [64, 256])
+def test_rpn_pred_backward_data_kernel(gate, c):
+    """cpm_rpn_pred_backward_data through the C ABI: dx_l = [t_l > 0]? * (dy_cls_l W_cls + dy_box_l W_box) for five
+    levels of odd sizes in one launch vs the matrix products in float64."""
+    import ctypes
+    from pet.lib.ops import _hip as H
+    A = 3
+    sizes = [(2, 9, 13), (2, 5, 7), (1, 3, 4), (2, 1, 1), (1, 17, 2)]
+    g = torch.Generator().manual_seed(9)
+    wc, wb = torch.randn(A, c, generator=g), torch.randn(4 * A, c, generator=g)
+    dcs = [torch.randn(n, h, w, A, generator=g) for n, h, w in sizes]                  # NHWC memory
+    dbs = [torch.randn(n, h, w, 4 * A, generator=g) for n, h, w in sizes]
+    ts = [torch.randn(n, h, w, c, generator=g) for n, h, w in sizes]
+    dev = [[t.cuda() for t in l] for l in (dcs, dbs, ts)]
+    dx = [torch.empty_like(t) for t in dev[2]]
+    P = ctypes.c_void_p
+    arr = lambda l: (P * len(l))(*[t.data_ptr() for t in l])
+    pix = (ctypes.c_int64 * len(sizes))(*[n * h * w for n, h, w in sizes])
+    wcd, wbd = wc.cuda(), wb.cuda()
+    with H.guard(dx[0].device):
+        rc = H.lib().cpm_rpn_pred_backward_data(arr(dev[0]), arr(dev[1]), arr(dev[2]), arr(dx), pix, len(sizes),
+                                                H.ptr(wcd), H.ptr(wbd), A, c, gate, H.stream())
+    H.check(rc, "rpn_pred_backward_data")
+    for dc, db, t, got in zip(dcs, dbs, ts, dx):
+        want = dc.double() @ wc.double() + db.double() @ wb.double()
+        if gate:
+            want = want * (t > 0)
+        assert relerr(got, want) < 1e-6
+
+
 @pytest.mark.parametrize("owned", [False, True], ids=["autograd_grads", "flat_optimizer_sinks"])
 def test_rpn_predictors_as_one_node(owned, conv_math):
     """RPNHead with its two 1x1 predictors as one autograd node (ops.conv._RPNPredFn: the data gradient of all levels
