@@ -1,9 +1,9 @@
-"""GPU: the BASELINE configurations beyond R-50 at FULL depth and FULL size:
+"""GPU: every BASELINE training configuration at FULL depth and FULL size:
 
+  #2  R-50-FPN CPM R-CNN             LAYERS (3, 4, 6, 3), bs = 2, 3 x 800 x 1333 (the headline configuration)
   #4  R-101-FPN CPM R-CNN            LAYERS (3, 4, 23, 3), bs = 2, 3 x 800 x 1333
   #5  X-101-64x4d-FPN + DCN           ResNeXt (3, 4, 23, 3), C = 64, width 4, deformable conv in layer2-4,
                                       MAX_SAMPLE_NUM_GRID 32, bs = 1, 3 x 800 x 1333
-  (#1/#2 R-50 at full size run in test_gpu_train_net.py / bench.py)
 
 One whole training iteration each through the same loop as bench.py (scheduler, zero_grad, forward, backward, SGD):
 state-dict ABI equal to the reference's dump, finite losses, every trainable tensor of the reference's trainable set
@@ -65,6 +65,18 @@ def _run(body, layers, batch, meta_file, grid_cap):
     finally:
         config.reset_cfg()
         torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "f32"])
+def test_r50_full_size_training_step(math):
+    from pet.lib.ops import _hip
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math(math)
+    try:
+        losses, counts = _run("resnet", (3, 4, 6, 3), 2, "model_r50_meta.json", 96)
+    finally:
+        _hip.set_conv_math(prev)
+    assert len(losses) == 2
 
 
 @pytest.mark.parametrize("math", ["bf16x3"])
