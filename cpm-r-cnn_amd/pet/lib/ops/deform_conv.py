@@ -72,7 +72,9 @@ class _ColsConvFn(Function):
         if ctx.wparam is not None:
             w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
         cols = sample_columns(x, offset, geom)
-        y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups)
+        # the parameter's pre-split image (bf16x3) is the image of the [K, R*S*C/g, 1, 1] weight too: the same bytes
+        y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups,
+                             w4=F.w4_of(w_in, w, (w.shape[1] * w.shape[2] * w.shape[3])))
         ctx.geom, ctx.relu = geom, relu
         ctx.out_tag = out_tag                      # see conv._ConvFn: gate + scale applied by the sole consumer's dgrad
         ctx.has = (scale is not None, shift is not None)
