@@ -1,0 +1,8 @@
+#!/bin/bash
+# The same six training steps (same seeds, ordered reductions) with this round's kernel paths on and off: the loss
+# trajectories must agree to the arithmetic's noise.   tools/trajectory_ab.sh OUT
+out=$1
+F="--no-cpu-baseline --no-roofline --no-other-math --no-full-rois --no-other-bodies --steps 4 --warmup 2 --verbose"
+CPM_DETERMINISTIC=1 python bench.py $F 2>/dev/null | grep "^warmup\|^step" > $out.new.txt
+CPM_DETERMINISTIC=1 CPM_WGRAD_TAPS=0 CPM_WGRAD_KS=1 CPM_W4=0 CPM_STEM_FUSED=0 CPM_RPN_PRED_FUSED=0 CPM_CLEAR_GRADS_IN_STEP=0 python bench.py $F 2>/dev/null | grep "^warmup\|^step" > $out.old.txt
+paste -d'\n' $out.new.txt $out.old.txt
