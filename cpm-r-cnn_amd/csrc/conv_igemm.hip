@@ -2262,8 +2262,10 @@ __global__ __launch_bounds__(256) void wgrad_cg1_kernel(WgradArgs a, int pix_per
     for (int t = 0; t < TAPS; ++t) red[wave][t][lane] = acc[t];
     __syncthreads();
     if (wave == 0 && live) {
+      // the frozen per-channel factor behind the conv (cpm_conv2d_backward_weight_scaled) multiplies the finished sum
+      const float rs = a.row_scale ? a.row_scale[g * a.OCg + ocl] : 1.f;
       for (int t = 0; t < taps; ++t) {
-        const float v = red[0][t][lane] + red[1][t][lane] + red[2][t][lane] + red[3][t][lane];
+        const float v = (red[0][t][lane] + red[1][t][lane] + red[2][t][lane] + red[3][t][lane]) * rs;
         const size_t o = (size_t)(g * a.OCg + ocl) * taps + t;
         if (a.slab) a.slab[(size_t)blockIdx.x * a.slab_stride + o] = v;      // this pixel block's plane (deterministic mode)
         else atomicAdd(a.dw + o, v);
@@ -3049,10 +3051,6 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   a.xcd_swizzle = wxcd;
   ProfScope prof_scope(s, 2);
   if (a.Cg == 1 && taps <= 16) {
-    if (row_scale) {
-      cpm::set_error("cpm_conv2d_backward_weight_scaled: one input channel per group is not covered");
-      return CPM_EINVAL;
-    }
     if (dbias) {
       cpm::set_error("cpm_conv2d_backward_weight_bias: one input channel per group is not covered, use cpm_epilogue_backward");
       return CPM_EINVAL;

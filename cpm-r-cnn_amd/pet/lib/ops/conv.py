@@ -163,14 +163,43 @@ _WT_CACHE = os.environ.get("CPM_DGRAD_WT_CACHE", "1") != "0"
 _GATE_BY_CONSUMERS = os.environ.get("CPM_GATE_BY_CONSUMERS", "1") != "0"
 
 
-_pending_wt_event = None
+_pending_wt_events = {}         # device index -> events of weight-image transforms nobody has waited for yet
 
 
-def set_pending_wt_event(ev):
+def set_pending_wt_event(ev, device=None):
     """The optimizer's once-per-step weight-image transform runs on the second stream (FlatSGD._refresh_dgrad_weights):
-    whoever reads an image next makes its stream wait for this event first (_prepared_wt)."""
-    global _pending_wt_event
-    _pending_wt_event = ev
+    whoever reads an image on that DEVICE next makes its stream wait for this event first (wait_pending_wt).  Kept per
+    device, and as a list: a process may drive several devices, and several optimizers (bench.py's other-body legs)
+    may have transforms outstanding on one."""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    _pending_wt_events.setdefault(idx, []).append(ev)
+
+
+def wait_pending_wt(device=None):
+    """make the current stream of `device` wait for every weight-image transform queued on its second stream"""
+    idx = torch.cuda.current_device() if device is None or device.index is None else device.index
+    evs = _pending_wt_events.pop(idx, None)
+    if evs:
+        st = torch.cuda.current_stream(idx)
+        for ev in evs:
+            st.wait_event(ev)
+
+
+# Every backward route that writes into a flat optimizer's gradient buffer starts with a forward call that counts a use
+# of the parameter (_note_use).  FlatSGD.zero_grad skips its memset only when nothing was counted since the SGD kernel
+# cleared the buffer (FlatSGD.clear_grads_in_step): a backward pass run outside a trainer step -- the warm-up
+# iterations of a hipGraph capture, a gradient probe -- makes the next zero_grad clear for real.
+_grad_write_generation = 0
+
+
+def grad_write_generation():
+    return _grad_write_generation
+
+
+def _note_use(p):
+    global _grad_write_generation
+    _grad_write_generation += 1
+    p._cpm_uses = getattr(p, "_cpm_uses", 0) + 1
 
 
 def _prepared_call(wparam):
@@ -203,10 +232,7 @@ def _prepared_wt(wparam, groups, kg, rs, cg, k_scale=None):
         return None
     if getattr(wparam, "_cpm_wt_fmt", 0) and not bf16x3():      # a pre-split image serves the bf16x3 kernels only
         return None
-    global _pending_wt_event
-    if _pending_wt_event is not None:                  # first reader after an optimizer step: the transform must be done
-        torch.cuda.current_stream().wait_event(_pending_wt_event)
-        _pending_wt_event = None
+    wait_pending_wt(wt.device)                         # first reader after an optimizer step: the transform must be done
     return wt
 
 
@@ -344,7 +370,7 @@ def _sink_of(p, needed):
     s = getattr(p, "_cpm_grad_sink", None)
     if s is None or s.data_ptr() == 0 or not s.is_contiguous():
         return None
-    p._cpm_uses = getattr(p, "_cpm_uses", 0) + 1
+    _note_use(p)
     return p
 
 
@@ -450,7 +476,7 @@ class _ConvFn(Function):
         ctx.wparam = w_in if (ctx.needs_input_grad[1] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         if ctx.wparam is not None:
             own = getattr(w_in, "_cpm_owner", w_in)     # a Linear's [K,C,1,1] view counts on the parameter itself
-            own._cpm_uses = getattr(own, "_cpm_uses", 0) + 1
+            _note_use(own)
         # the parameter itself (not a repacked copy) when `w` aliases it: key of the once-per-step dgrad image
         ctx.wsrc = w_in if (w is w_in and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         ctx.bparam = _sink_of(shift, shift is not None and ctx.needs_input_grad[3])
@@ -757,7 +783,7 @@ class _ConvTransposeFn(Function):
         ctx.wparam = w_in if (ctx.needs_input_grad[1] and w is w_in and sink is not None and sink.data_ptr() != 0
                               and sink.stride() == w.stride()) else None
         if ctx.wparam is not None:
-            w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+            _note_use(w_in)
         ctx.bparam = _sink_of(bias, bias is not None and ctx.needs_input_grad[2])
         n, cin, p, q = x.shape
         _, cog, r, s = w.shape
@@ -988,7 +1014,7 @@ class _LayerChainFn(Function):
         else:
             y = torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device, memory_format=CL)
         for p_ in plan.params:
-            p_._cpm_uses = getattr(p_, "_cpm_uses", 0) + 1
+            _note_use(p_)
         plan.refresh_w4()
         ws = H.workspace(ws_bytes, x.device)
         with H.guard(x.device):

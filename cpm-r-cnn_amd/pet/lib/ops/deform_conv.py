@@ -70,7 +70,7 @@ class _ColsConvFn(Function):
             _check_offset(offset, geom)
         ctx.wparam = w_in if (ctx.needs_input_grad[2] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         if ctx.wparam is not None:
-            w_in._cpm_uses = getattr(w_in, "_cpm_uses", 0) + 1
+            F._note_use(w_in)
         cols = sample_columns(x, offset, geom)
         # the parameter's pre-split image (bf16x3) is the image of the [K, R*S*C/g, 1, 1] weight too: the same bytes
         y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups,

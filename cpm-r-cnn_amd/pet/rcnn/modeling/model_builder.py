@@ -98,6 +98,8 @@ class Generalized_RCNN(nn.Module):
         for i, p_ in enumerate(params):
             part.register_parameter("p%d" % i, p_)
         x = sample.detach().clone()
+        from pet.lib.ops import conv as _conv
+        _conv.wait_pending_wt(x.device)          # (the capture must not record a wait for an event of the eager step)
         graphed = torch.cuda.make_graphed_callables(part, (x,), allow_unused_input=True)
         self._graphed = getattr(self, "_graphed", {})
         self._graphed[tuple(sample.shape)] = graphed
@@ -109,6 +111,10 @@ class Generalized_RCNN(nn.Module):
         images = to_image_list(images)
         graphed = getattr(self, "_graphed", {}).get(tuple(images.tensors.shape)) if self.training else None
         if graphed is not None:
+            # a replayed backward pass issues no Python-side waits: the once-per-step weight-image transform on the
+            # second stream (FlatSGD._refresh_dgrad_weights) is ordered in front of the replay here
+            from pet.lib.ops import conv as _conv
+            _conv.wait_pending_wt(images.tensors.device)
             outs = graphed(images.tensors)
             nf = nl = len(outs) // 3                 # feature maps, objectness maps, delta maps: one each per level
             # the replayed outputs are fresh tensor objects: the RoI heads' RoIAlign calls share ONE gradient

@@ -51,7 +51,7 @@ class FlatSGD(torch.optim.Optimizer):
         self.block_seg = table.to(device)
         self.total, self.momentum, self._steps, self._last = total, float(momentum), 0, None
         self._stepped_end, self._w4_fresh = 0, False
-        self.clear_grads_in_step, self._grads_cleared = False, False
+        self.clear_grads_in_step, self._grads_cleared, self._write_gen_at_step = False, False, -1
         self.grad_scale = 1.0
         groups = []
         for gi, g in enumerate(groups_cfg):
@@ -147,7 +147,12 @@ class FlatSGD(torch.optim.Optimizer):
     def zero_grad(self, set_to_none=False):
         # one memset; .grad views stay attached.  With `clear_grads_in_step` (a trainer's choice: gradients are then zero
         # after step(), unlike torch.optim's) the SGD kernel has already cleared every element behind its use.
-        if not (self.clear_grads_in_step and self._grads_cleared):
+        # A backward pass that ran since then outside a trainer step (the warm-up iterations of a hipGraph capture, a
+        # gradient probe) has written gradients again: every in-place route counts a use in its forward
+        # (conv._note_use), and the memset is skipped only when nothing was counted since step().
+        from pet.lib.ops import conv as C
+        if not (self.clear_grads_in_step and self._grads_cleared
+                and C.grad_write_generation() == self._write_gen_at_step):
             self.flat_grad.zero_()
         self._grads_cleared = False
         for g in self.param_groups:
@@ -190,6 +195,8 @@ class FlatSGD(torch.optim.Optimizer):
         self._stepped_end = 0
         self._steps += 1
         self._grads_cleared = bool(self.clear_grads_in_step)
+        from pet.lib.ops import conv as C
+        self._write_gen_at_step = C.grad_write_generation()
         self._mark_w4(self._w4_fresh)
         self._refresh_dgrad_weights()
 
@@ -198,11 +205,13 @@ class FlatSGD(torch.optim.Optimizer):
         the view of the image buffer at their own offset, stamped with their `_version` (conv.w4_of reads it; an
         in-place modification by anything else moves `_version` and w4_of re-splits into the same view)."""
         if not fresh:
-            if getattr(self, "_w4_marked", False):
-                for p in self._flat_order:
-                    if hasattr(p, "_cpm_w4"):
-                        p._cpm_w4_version = -1          # the images went stale with this step
-                self._w4_marked = False
+            # the SGD kernel writes the parameters through raw pointers (no `_version` bump): EVERY cached image is
+            # stale after a step that did not write it -- the ones conv.w4_of split by itself before the first
+            # step or under another arithmetic included, not only the views this method handed out
+            for p in self._flat_order:
+                if hasattr(p, "_cpm_w4"):
+                    p._cpm_w4_version = -1
+            self._w4_marked = False
             return
         if not getattr(self, "_w4_marked", False):
             begins = self.seg_begin.tolist()
@@ -214,6 +223,18 @@ class FlatSGD(torch.optim.Optimizer):
         for p in self._flat_order:
             if hasattr(p, "_cpm_w4"):
                 p._cpm_w4_version = p._version
+
+    def invalidate_images(self):
+        """Call after ANY write to the flat parameter buffer that does not go through the parameters' own tensors
+        (a broadcast or copy into `flat_param`, a raw-pointer kernel): views of one storage keep separate version
+        counters, so neither the pre-split forward images (conv.w4_of, keyed on `_version`) nor the data-gradient
+        images (conv._prepared_wt) notice such a write by themselves.  The images are rebuilt on their next use."""
+        for p in self._flat_order:
+            if hasattr(p, "_cpm_w4"):
+                p._cpm_w4_version = -1
+            if hasattr(p, "_cpm_wt_version"):
+                p._cpm_wt_version = -1
+        self._w4_marked = False
 
     def _refresh_dgrad_weights(self):
         """Every conv weight that has been used by a data-gradient call (pet.lib.ops.conv._prepared_wt registers it
@@ -264,7 +285,7 @@ class FlatSGD(torch.optim.Optimizer):
                                    H.ptr(self.flat_param), H.ptr(self.flat_wt), H.stream())
                 ev = torch.cuda.Event()
                 ev.record(side)
-                C.set_pending_wt_event(ev)
+                C.set_pending_wt_event(ev, dev)
             else:
                 rc = transform(H.ptr(self._wt_table), len(self._wt_params), H.c_int64(self._wt_tiles),
                                H.ptr(self.flat_param), H.ptr(self.flat_wt), H.stream())

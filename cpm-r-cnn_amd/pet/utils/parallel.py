@@ -150,9 +150,9 @@ def broadcast_initial_state(model, optimizer, src=0):
                 buf = t.data.contiguous()
                 dist.broadcast(buf, src=src)
                 t.data.copy_(buf)
-    for p in optimizer._flat_order:                 # cached data-gradient weight images are stale after the broadcast
-        if hasattr(p, "_cpm_wt_version"):
-            p._cpm_wt_version = -1
+    # the broadcast wrote the flat buffer, not the parameter tensors: their `_version` did not move, so every cached
+    # image of the old weights (pre-split forward images, data-gradient images) must be dropped by hand
+    optimizer.invalidate_images()
 
 
 def backward_losses(losses):

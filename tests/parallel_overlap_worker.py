@@ -58,7 +58,27 @@ def main():
         named.reverse()
         opt = FlatSGD(named, [dict(weight_decay=1e-4, lr_scale=1), dict(weight_decay=0.0, lr_scale=2),
                               dict(weight_decay=0.0, lr_scale=1)], 0.9)
+        # a forward pass under bf16x3 BEFORE the broadcast (bench.py's calibration pass does that)
+        # caches a pre-split image of every weight, keyed on the parameter's `_version` -- which a broadcast into the
+        # flat buffer does not move.  The broadcast must drop those images: the forward pass after it has to equal
+        # the one computed from the float weights, bit for bit, on every rank.
+        from pet.lib.ops import _hip
+        from pet.lib.ops import conv as conv_ops
+        torch.manual_seed(5)
+        xq = torch.randn(3, 16, 12, 10, device=dev).contiguous(memory_format=CL)
+        _hip.set_conv_math("bf16x3")
+        with torch.no_grad():
+            net(xq)
+        res["images_cached_before_broadcast"] = sum(1 for p_ in net.parameters() if getattr(p_, "_cpm_w4", None) is not None)
         broadcast_initial_state(net, opt, src=0)
+        with torch.no_grad():
+            y_img = net(xq)
+            conv_ops._W4 = False                           # the kernels split the float weights themselves
+            y_flt = net(xq)
+            conv_ops._W4 = True
+        res["stale_image_err"] = float((y_img - y_flt).abs().max())
+        res["stale_image_ref_max"] = float(y_flt.abs().max())
+        _hip.set_conv_math("f32")
         w0 = [torch.zeros_like(opt.flat_param) for _ in range(world)]
         dist.all_gather(w0, opt.flat_param)
         res["same_start"] = bool(torch.equal(w0[0], w0[1]))
@@ -110,6 +130,8 @@ def main():
             run()
             launched_in_backward = list(order)
             red.finish()
+            if red.local_sgd:
+                opt.step()          # closes the step's ranged updates (learning rate 0 here: the weights stay put)
             torch.cuda.synchronize()
             if step == 0:
                 first = opt.flat_grad.clone()
@@ -126,6 +148,35 @@ def main():
         res["ready_fires_per_param_max"] = max(fired.count(i) for i in set(fired)) if fired else 0
         res["autograd_accumulations"] = [f for f in fired if f.startswith("autograd:")]
         res["fc_uses_after"] = int(net.fc.weight._cpm_uses)
+        # ---- the optimizer step: behind finish() (default) or chunk by chunk on the reducer's stream behind each chunk's
+        # all-reduce (CPM_OVERLAP_SGD=1, FlatSGD.step_range) -- either way the parameters after ONE step are
+        # p - lr * (sum of the ranks' gradients / world + wd * p) (first step: the momentum buffer is the gradient)
+        res["local_sgd"] = bool(red.local_sgd)
+        for g in opt.param_groups:
+            g["lr"] = 0.05 * g["lr_scale"]
+        p0 = opt.flat_param.clone()
+        m0 = opt.flat_mom.clone()
+        first_step = opt._steps == 0
+        opt.zero_grad()
+        red.begin_step()
+        run()
+        red.finish()
+        opt.step()
+        torch.cuda.synchronize()
+        lr = torch.zeros_like(p0)
+        wd = torch.zeros_like(p0)
+        live = torch.zeros_like(p0)
+        for (b, e), gi in zip(zip(opt.seg_begin.tolist(), opt.seg_end.tolist()), opt._seg_pg):
+            lr[b:e] = opt.param_groups[gi]["lr"]
+            wd[b:e] = opt.param_groups[gi]["weight_decay"]
+            live[b:e] = 1.0
+        d = want / world + wd * p0
+        expect = p0 - lr * (d if first_step else opt.momentum * m0 + d) * live
+        res["sgd_err"] = float((opt.flat_param - expect).abs().max() / float(p0.abs().max()))
+        res["sgd_moved"] = float((opt.flat_param - p0).abs().max()) > 0
+        allp = [torch.zeros_like(p0) for _ in range(world)]
+        dist.all_gather(allp, opt.flat_param)
+        res["replicas_equal_after_step"] = float((allp[0] - allp[1]).abs().max())
         res["ok"] = True
     except Exception as e:                                 # surface the failure in the parent
         import traceback

@@ -29,12 +29,13 @@ def _free_port():
     return p
 
 
-def _run_two_ranks(tmp_path, backend):
+def _run_two_ranks(tmp_path, backend, extra_env=None):
     import torch
     if torch.cuda.is_initialized():
         pytest.skip("must start its child ranks before this process touches the GPU (run the file on its own)")
     port = str(_free_port())
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(extra_env or {})
     procs, outs = [], []
     for r in range(2):
         out = str(tmp_path / ("rank%d.json" % r))
@@ -65,13 +66,29 @@ def _check(res):
         assert r["ready_fires_per_param_max"] == 2                    # once per step, two steps (Linear used twice)
         assert r["fc_uses_after"] == 0
         assert r["launched_in_backward"] >= 1                         # at least one chunk went out before finish()
+        # images cached before the broadcast are dropped by it (bit-equal forward on every rank)
+        assert r["images_cached_before_broadcast"] >= 4 and r["stale_image_ref_max"] > 0, r
+        assert r["stale_image_err"] == 0.0, r
+        # one optimizer step behind the reduced gradient: same parameters as the formula, identical replicas
+        assert r["sgd_moved"] and r["sgd_err"] < 1e-5, r
+        assert r["replicas_equal_after_step"] < 1e-6, r
     assert res[0]["order"] == res[1]["order"]
     per_step = res[0]["chunks"]
     assert res[0]["order"] == list(range(per_step)) * 2               # buffer order, every step
 
 
 def test_overlapped_flat_gradient_reduce_two_ranks_one_gpu(tmp_path):
-    _check(_run_two_ranks(tmp_path, "gloo"))
+    res = _run_two_ranks(tmp_path, "gloo")
+    _check(res)
+    assert not any(r["local_sgd"] for r in res)
+
+
+def test_chunkwise_sgd_behind_each_allreduce_two_ranks_one_gpu(tmp_path):
+    """CPM_OVERLAP_SGD=1: every chunk's SGD update is queued on the reducer's stream right behind its
+    all-reduce (FlatSGD.step_range) instead of after the backward pass -- same parameters after the step."""
+    res = _run_two_ranks(tmp_path, "gloo", {"CPM_OVERLAP_SGD": "1"})
+    _check(res)
+    assert all(r["local_sgd"] for r in res)
 
 
 def test_overlapped_flat_gradient_reduce_two_ranks_rccl(tmp_path):

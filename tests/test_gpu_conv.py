@@ -46,6 +46,8 @@ CASES = [
     ("iou_pred", 5, 1024, 1, 1, 2, 1, 1, 0, 1),
     ("grouped", 2, 64, 8, 8, 128, 3, 1, 1, 4),
     ("odd_c", 2, 36, 5, 6, 20, 3, 1, 1, 1),
+    ("depthwise", 2, 32, 9, 11, 64, 3, 1, 1, 32),          # one input channel per group: wgrad_cg1_kernel, incl. the
+                                                             # frozen scale at its stores (epi affine_res_relu)
     ("7x7_s2", 1, 32, 20, 24, 64, 7, 2, 3, 1),
     ("3x3_patch", 2, 256, 101, 115, 192, 3, 1, 1, 1),      # large enough for the 3x3 patch kernel (bf16x3), ragged edges
 ]

@@ -1,0 +1,69 @@
+"""GPU: the static part of the training step as hipGraphs (Generalized_RCNN.capture_static_part) next to the flat
+optimizer's "gradients cleared by the SGD kernel" mode: the warm-up iterations of a capture run
+real backward passes between step() and the next zero_grad(), so that zero_grad must clear for real."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_zero_grad_skips_its_memset_only_when_nothing_was_written_since_the_step():
+    from pet.lib.ops import conv as C
+    from pet.utils.optimizer import FlatSGD
+    ps = [torch.nn.Parameter(torch.randn(64, 32, device="cuda")), torch.nn.Parameter(torch.randn(64, device="cuda"))]
+    opt = FlatSGD([("w", ps[0], 0), ("b", ps[1], 1)], [dict(weight_decay=0.0, lr_scale=1), dict(weight_decay=0.0, lr_scale=2),
+                                                       dict(weight_decay=0.0, lr_scale=1)], 0.9)
+    opt.clear_grads_in_step = True
+    for g in opt.param_groups:
+        g["lr"] = 0.1
+    opt.flat_grad.fill_(1.0)
+    opt.step()                                       # the kernel clears every gradient element behind its use
+    torch.cuda.synchronize()
+    for b, e in zip(opt.seg_begin.tolist(), opt.seg_end.tolist()):
+        assert not opt.flat_grad[b:e].any()
+    # nothing ran since: zero_grad trusts the kernel and skips its memset
+    opt.flat_grad[0] = 3.0                           # a write the optimizer cannot know about ...
+    opt.zero_grad()
+    assert float(opt.flat_grad[0]) == 3.0            # ... survives the skipped memset (that is the fast path)
+    # a backward route announced itself (every in-place sink counts a use in its forward): the memset runs
+    opt.step()
+    opt.flat_grad[0] = 3.0
+    C._note_use(ps[0])
+    opt.zero_grad()
+    assert not opt.flat_grad.any()
+    assert ps[0]._cpm_uses == 0
+
+
+def test_gradients_left_by_a_capture_are_cleared_by_the_next_zero_grad():
+    import __graft_entry__ as entry
+    entry.ensure_built()
+    from bench import Trainer, calibrate_frozen_affine, synthetic_batch
+    from pet.lib.ops import _hip
+    device = torch.device("cuda", 0)
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    try:
+        tr = Trainer(device)
+        tr.optimizer.clear_grads_in_step = True
+        images, targets = synthetic_batch(2, 192, 256, 5, 11, device)
+        calibrate_frozen_affine(tr.model, images.tensors)
+        tr.step(images, targets)                     # the data-gradient weight images exist from the first step on
+        tr.model.capture_static_part(images.tensors)
+        torch.cuda.synchronize()
+        opt = tr.optimizer
+        assert float(opt.flat_grad.abs().max()) > 0, "warm-up and capture leave gradients in the parameters' sinks"
+        opt.zero_grad()
+        torch.cuda.synchronize()
+        assert not opt.flat_grad.any(), "zero_grad after a capture must clear what the capture's backward passes left"
+        for _ in range(2):                           # replayed steps train on
+            tr.step(images, targets)
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v.detach()).all()) for v in tr.last_losses.values())
+        assert bool(torch.isfinite(opt.flat_param).all())
+    finally:
+        _hip.set_conv_math(prev)
