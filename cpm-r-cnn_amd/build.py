@@ -26,7 +26,6 @@ def sources():
 def newest_header():
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hs.append(os.path.join(HERE, "..", "include", "cpmrcnn_hip.h"))
-    hs.append(os.path.join(HERE, "..", "include", "cpmrcnn_hip_experimental.h"))
     return max(os.path.getmtime(h) for h in hs)
 
 

@@ -2401,7 +2401,6 @@ Plan plan_igemm(const IgemmArgs& a) {
 
 int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t s) {
   const int rows = a.M - a.m_base;
-  if (g_conv_split && bn >= 64 && sp_eligible(a)) return launch_igemm_sp(a, bm, bn, s);
   // one-LDS-stage variant (three workgroups per CU): pays once the grid holds three rounds' worth of workgroups per CU
   // (256->256 1x1 on 200x336: 125 -> 109 us; 576x576x3x3 on 192 RoIs 209 -> 200 us), loses 5-10 % on grids that do not
   // even fill two per CU (its workgroups are slower one by one).  CPM_IGEMM_S1: 0 off, 1 always (tests), 2 by grid size.
@@ -2454,7 +2453,7 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
   a.staged_epi = staged;
   ProfScope prof_scope(s, prof_kind);
   static const int use_halo = env_int("CPM_IGEMM_HALO", 1);
-  if (use_halo && !(g_conv_split && sp_eligible(a)) && g_conv_split && vec && a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 &&
+  if (use_halo && g_conv_split && vec && a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 &&
       a.ihmul == 1 && a.iwmul == 1 && (a.hstep == 1 || a.hstep == -1) && (a.wstep == 1 || a.wstep == -1) &&
       a.osh == 1 && a.osw == 1 && a.oah == 0 && a.oaw == 0 && a.groups == 1 && a.CgR == a.Ctot && a.Ctot % 32 == 0 &&
       a.OHp == a.OH && a.OWp == a.OW && a.IH == a.OH && a.IW == a.OW && a.split_k == 1 && !a.atomic_out &&
@@ -2542,10 +2541,6 @@ CPM_EXPORT size_t cpm_conv2d_workspace_bytes(const cpm_conv_desc* d) {
   return m + 256;
 }
 
-static int split_into(const float* x, int64_t rows, int channels, void* sp, hipStream_t s) {
-  return cpm_split_planes(x, rows, channels, sp, (void*)s);
-}
-
 // a split-K slab of `split` planes fits the workspace region [off, bytes)?
 static float* slab_in(void* workspace, size_t bytes, size_t off, int split, size_t plane_floats, int oc_tot,
                       bool needs_pass = false) {
@@ -2564,13 +2559,12 @@ static float* slab_in(void* workspace, size_t bytes, size_t off, int split, size
   return (float*)((char*)workspace + off);
 }
 
-static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w, const void* w_sp,
+static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const float* w,
                              const float* scale, const float* shift, const float* residual, int res_mode, int relu,
-                             float* y, void* y_sp, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0,
+                             float* y, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0,
                              int w_presplit = 0) {
   IgemmArgs a = {};
   a.b_presplit = w_presplit;
-  a.in_sp = x_sp; a.wm_sp = w_sp; a.out_sp = y_sp;
   a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
   a.N = d->N; a.IH = d->H; a.IW = d->W; a.Ctot = d->C;
   a.OH = d->P; a.OW = d->Q; a.OCtot = d->K; a.OHp = d->P; a.OWp = d->Q;
@@ -2629,9 +2623,6 @@ static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const void*
                        residual, (int64_t)a.M, a.OCtot, a.OH, a.OW, res_mode, relu);
     rc = cpm::check_launch("conv epilogue");
   }
-  // an SP copy the kernel's own epilogue could not write (split-K partial sums, a kernel without the SP store)
-  if (rc == CPM_OK && y_sp && !(a.split_k == 1 && g_conv_split && sp_eligible(a)))
-    rc = split_into(y, (int64_t)a.M, a.OCtot, y_sp, s);
   return rc;
 }
 
@@ -2641,8 +2632,8 @@ CPM_EXPORT int cpm_conv2d_forward(const cpm_conv_desc* d, const float* x, const 
   CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
   CPM_REQUIRE(x && w && y, "null pointer");
   CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
-  return conv_forward_impl(d, x, nullptr, w, nullptr, scale, shift, residual, res_mode, relu, y, nullptr,
-                           (hipStream_t)stream, workspace, workspace_bytes);
+  return conv_forward_impl(d, x, w, scale, shift, residual, res_mode, relu, y, (hipStream_t)stream, workspace,
+                           workspace_bytes);
 }
 
 // y = epilogue(conv(x, W)) with W given as its pre-split image (cpm_split_w4 of the KRSC weight): bf16x3 arithmetic only
@@ -2655,8 +2646,8 @@ CPM_EXPORT int cpm_conv2d_forward_w4(const cpm_conv_desc* d, const float* x, con
   CPM_REQUIRE(g_conv_split, "a pre-split weight image serves the bf16x3 arithmetic only (cpm_set_conv_math)");
   CPM_REQUIRE((d->C / d->groups) % 4 == 0 && d->C % 4 == 0 && (((uintptr_t)x | (uintptr_t)w4) & 15) == 0,
               "a pre-split weight image needs the vector path: channels per group % 4 == 0, 16-byte aligned operands");
-  return conv_forward_impl(d, x, nullptr, (const float*)w4, nullptr, scale, shift, residual, res_mode, relu, y, nullptr,
-                           (hipStream_t)stream, workspace, workspace_bytes, 1);
+  return conv_forward_impl(d, x, (const float*)w4, scale, shift, residual, res_mode, relu, y, (hipStream_t)stream,
+                           workspace, workspace_bytes, 1);
 }
 
 // hi / lo image of a float array for the weight side of the bf16x3 kernels: elements 4i .. 4i+3 -> 8 bytes of bf16 hi,
@@ -2680,21 +2671,10 @@ CPM_EXPORT int cpm_split_w4(const float* src, void* dst, int64_t n, void* stream
   return cpm::check_launch("cpm_split_w4");
 }
 
-CPM_EXPORT int cpm_conv2d_forward_sp(const cpm_conv_desc* d, const float* x, const void* x_sp, const float* w,
-                                     const void* w_sp, const float* scale, const float* shift, const float* residual,
-                                     int res_mode, int relu, float* y, void* y_sp, void* stream) {
-  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
-  CPM_REQUIRE(x && w && y, "null pointer");
-  CPM_REQUIRE(res_mode == 0 || res_mode == 1, "bad res_mode");
-  CPM_REQUIRE(!y_sp || d->K % 32 == 0, "an SP output needs a multiple of 32 output channels");
-  return conv_forward_impl(d, x, x_sp, w, w_sp, scale, shift, residual, res_mode, relu, y, y_sp, (hipStream_t)stream);
-}
-
 static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, float* dx, int accumulate,
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
                      const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr,
-                     bool prepared = false, const void* dy_sp = nullptr, const void* wt_sp = nullptr,
-                     void* dx_sp = nullptr, const float* k_scale = nullptr, int prepared_w4 = 0) {
+                     bool prepared = false, const float* k_scale = nullptr, int prepared_w4 = 0) {
   const size_t need = dgrad_weight_bytes(d);
   if (!prepared && (!workspace || workspace_bytes < need)) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
@@ -2706,7 +2686,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   // the weight side pre-split (bf16x3, vector path): an image made here is written that way, a prepared one says so
   const bool vec_ok = Kg % 4 == 0 && d->K % 4 == 0 && (((uintptr_t)dy | (uintptr_t)wt) & 15) == 0;
   static const int env_w4 = env_int("CPM_W4", 1);
-  const int w4 = prepared ? prepared_w4 : (env_w4 && g_conv_split && vec_ok && !dy_sp ? 1 : 0);
+  const int w4 = prepared ? prepared_w4 : (env_w4 && g_conv_split && vec_ok ? 1 : 0);
   if (prepared_w4 && !(g_conv_split && vec_ok)) {
     cpm::set_error("%s: a pre-split weight image needs the bf16x3 arithmetic and the vector path (K / groups %% 4 == 0, "
                    "16-byte aligned operands)", who);
@@ -2719,7 +2699,6 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   }
   IgemmArgs a = {};
   a.b_presplit = w4;
-  if (prepared) { a.in_sp = dy_sp; a.wm_sp = wt_sp; }     // wt_sp: the SP form of the prepared [g][c][tap][k] image
   a.in = dy; a.wm = wt; a.out = dx; a.shift = shift; a.relu = relu;
   a.N = d->N; a.IH = d->P; a.IW = d->Q; a.Ctot = d->K;      // the GEMM's "input" is dy
   a.OH = d->H; a.OW = d->W; a.OCtot = d->C;                 // its "output" is dx
@@ -2769,9 +2748,6 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
   if (a.atomic_out && !accumulate && !a.slab) {
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
-  // the kernel's own epilogue writes the SP copy unless the sums are partial (atomics) or a phase has no taps
-  bool sp_in_kernel = dx_sp && !a.atomic_out && g_conv_split;
-  if (sp_in_kernel) a.out_sp = dx_sp;
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = CPM_OK;
@@ -2791,9 +2767,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
       a.M = d->N * a.OHp * a.OWp;
       a.ksteps = a.nr * a.ns * a.ksteps_per_tap;
       if (a.ksteps == 0 && (a.atomic_out || acc_via_res)) continue;      // nothing to add
-      if (sp_in_kernel && !sp_eligible(a)) { sp_in_kernel = false; a.out_sp = nullptr; }
       Plan pp = plan_igemm(a);
-      if (pp.bn < 64 && sp_in_kernel) { sp_in_kernel = false; a.out_sp = nullptr; }
       pp.split = a.split_k;
       if (a.ksteps < a.split_k) { a.split_k = 1; pp.split = 1; }
       rc = launch_igemm(a, pp, s, 1);
@@ -2822,7 +2796,6 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
                        relu, out_mask);
     rc = cpm::check_launch("dgrad epilogue");
   }
-  if (rc == CPM_OK && dx_sp && !sp_in_kernel) rc = split_into(dx, (int64_t)whole.M, a.OCtot, dx_sp, s);
   return rc;
 }
 
@@ -2854,7 +2827,7 @@ CPM_EXPORT int cpm_conv2d_backward_data_fused(const cpm_conv_desc* d, const floa
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
   CPM_REQUIRE(!(accumulate && in_scale), "an accumulated data gradient takes a gate only: dx = (dx + W^T dy) * [act > 0]");
   return run_dgrad(d, dy, w, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
-                   "cpm_conv2d_backward_data_fused", in_scale, in_act, false, nullptr, nullptr, nullptr, k_scale);
+                   "cpm_conv2d_backward_data_fused", in_scale, in_act, false, k_scale);
 }
 
 CPM_EXPORT int cpm_conv2d_backward_data_prepared(const cpm_conv_desc* d, const float* dy, const float* wt, float* dx,
@@ -2877,19 +2850,7 @@ CPM_EXPORT int cpm_conv2d_backward_data_prepared_w4(const cpm_conv_desc* d, cons
   CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
   CPM_REQUIRE(!(accumulate && in_scale), "an accumulated data gradient takes a gate only: dx = (dx + W^T dy) * [act > 0]");
   return run_dgrad(d, dy, (const float*)wt4, dx, accumulate, nullptr, 0, workspace, workspace_bytes, (hipStream_t)stream,
-                   "cpm_conv2d_backward_data_prepared_w4", in_scale, in_act, true, nullptr, nullptr, nullptr, nullptr, 1);
-}
-
-CPM_EXPORT int cpm_conv2d_backward_data_sp(const cpm_conv_desc* d, const float* dy, const void* dy_sp, const float* wt,
-                                           const void* wt_sp, float* dx, void* dx_sp, int accumulate,
-                                           const float* in_scale, const float* in_act, void* stream) {
-  CPM_REQUIRE(validate(d) == CPM_OK, "bad conv descriptor");
-  CPM_REQUIRE(dy && wt && dx, "null pointer");
-  CPM_REQUIRE(d->dilation == 1, "dilated dgrad not implemented");
-  CPM_REQUIRE(!(accumulate && (in_scale || in_act)), "a gated data gradient is not accumulated");
-  CPM_REQUIRE(!dx_sp || d->C % 32 == 0, "an SP output needs a multiple of 32 channels");
-  return run_dgrad(d, dy, wt, dx, accumulate, nullptr, 0, nullptr, 0, (hipStream_t)stream,
-                   "cpm_conv2d_backward_data_sp", in_scale, in_act, true, dy_sp, wt_sp, dx_sp);
+                   "cpm_conv2d_backward_data_prepared_w4", in_scale, in_act, true, nullptr, 1);
 }
 
 CPM_EXPORT int cpm_weights_to_dgrad_batched(const cpm_wt_desc* d_descs, int n, int64_t total_tiles, const float* src_base,

@@ -1,8 +1,7 @@
-// Pieces shared by the implicit-GEMM convolution kernels (conv_igemm.hip: fp32 operands split in flight;
-// conv_sp.hip: operands already stored as bf16 hi/lo planes, staged by LDS-DMA).
+// Pieces shared by the implicit-GEMM convolution kernels (conv_igemm.hip: fp32 operands split in flight, the weight
+// side optionally given as a pre-split image).
 #pragma once
 #include "common.h"
-#include "../../include/cpmrcnn_hip_experimental.h"
 
 namespace cpmconv {
 
@@ -91,19 +90,10 @@ struct IgemmArgs {
   size_t slab_stride;  //   (floats per plane) and splitk_reduce_kernel folds the planes in split order + runs the epilogue;
                        //   null: float atomics into the zeroed output (no workspace)
   int staged_epi;      // finish every non-atomic epilogue row-wise through LDS (16-byte accesses), not only residual ones
-  // split-plane operands (conv_sp.hip): the same tensors stored as bf16 hi / lo planes, [row][2][C] -- per pixel (or per
-  // weight row (oc, tap)) C hi values then C lo values, 4*C bytes like the fp32 row.  Null: fp32 operands only.
-  const void* in_sp;
-  const void* wm_sp;
-  void* out_sp;        // optional: the output written a second time in that format for the consuming convolution
   int b_presplit;      // wm is a pre-split weight image (cpm_split_w4): bf16x3 arithmetic, vector path only
-  int dbg;             // timing-only experiments (CPM_RING_DBG): 1 no DMA, 2 zero-record descriptors, 4 no operand reads
+  int dbg;             // timing-only experiments (CPM_IGEMM_DBG): 8 zero-record descriptors (nothing fetched), 16 no epilogue
 };
 
 struct Plan { int bm, bn, wm, wn, split; };
-
-// conv_sp.hip: the LDS-DMA kernel for split-plane operands; false when the problem is outside its shape rules
-bool sp_eligible(const IgemmArgs& a);
-int launch_igemm_sp(const IgemmArgs& a, int bm, int bn, hipStream_t s);
 
 }  // namespace cpmconv

@@ -13,7 +13,6 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from . import _hip as H
-from . import sp as SP
 
 CL = torch.channels_last
 
@@ -97,64 +96,26 @@ def w4_of(w_in, w, cg):
     return t
 
 
-def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, dil, groups, x_sp=None, w_sp=None,
-                   want_sp=False, w4=None):
-    """y = epilogue(conv(x, w)).  x_sp / w_sp: split-plane twins of the operands (pet.lib.ops.sp) -- with both, the
-    bf16x3 arithmetic runs on the LDS-DMA kernel; want_sp: also write y's twin and attach it (y._cpm_sp).
-    w4: the pre-split image of w (split_w4; bf16x3 arithmetic only), used in place of w."""
+def conv2d_forward(x, w, scale, shift, residual, res_mode, relu, stride, pad, dil, groups, w4=None):
+    """y = epilogue(conv(x, w)).  w4: the pre-split image of w (split_w4; bf16x3 arithmetic only), used in place of w."""
     n, c, h, wd = x.shape
     k, _, r, s = w.shape
     d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
     y = empty_nhwc((n, k, d.P, d.Q), x)
     if y.numel() == 0:
         return y
-    if w4 is not None:
-        ws = _ws(d, x.device)
-        with H.guard(x.device):
+    ws = _ws(d, x.device)
+    with H.guard(x.device):
+        if w4 is not None:
             rc = H.lib().cpm_conv2d_forward_w4(H.ctypes.byref(d), H.ptr(x), H.ptr(w4), H.ptr(scale), H.ptr(shift),
                                                H.ptr(residual), int(res_mode), int(bool(relu)), H.ptr(y), H.ptr(ws),
                                                H.c_size_t(ws.numel()), H.stream())
-        H.check(rc, "conv2d_forward_w4")
-        return y
-    if x_sp is not None or w_sp is not None or want_sp:
-        y_sp = SP.empty_like(y) if (want_sp and k % 32 == 0) else None
-        with H.guard(x.device):
-            rc = H.lib().cpm_conv2d_forward_sp(H.ctypes.byref(d), H.ptr(x), H.ptr(x_sp), H.ptr(w), H.ptr(w_sp),
-                                               H.ptr(scale), H.ptr(shift), H.ptr(residual), int(res_mode),
-                                               int(bool(relu)), H.ptr(y), H.ptr(y_sp), H.stream())
-        H.check(rc, "conv2d_forward_sp")
-        if y_sp is not None:
-            SP.attach(y, y_sp)
-        return y
-    ws = _ws(d, x.device)
-    with H.guard(x.device):
-        rc = H.lib().cpm_conv2d_forward(H.ctypes.byref(d), H.ptr(x), H.ptr(w), H.ptr(scale), H.ptr(shift),
-                                        H.ptr(residual), int(res_mode), int(bool(relu)), H.ptr(y), H.ptr(ws),
-                                        H.c_size_t(ws.numel()), H.stream())
+        else:
+            rc = H.lib().cpm_conv2d_forward(H.ctypes.byref(d), H.ptr(x), H.ptr(w), H.ptr(scale), H.ptr(shift),
+                                            H.ptr(residual), int(res_mode), int(bool(relu)), H.ptr(y), H.ptr(ws),
+                                            H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "conv2d_forward")
     return y
-
-
-def conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, x_shape, w_shape, stride, pad, dil, groups, accumulate_into=None,
-                            in_scale=None, in_act=None, want_sp=False):
-    """Data gradient on split-plane operands: wt / wt_sp = the prepared [g][c][tap][k] weight image and its twin."""
-    n, c, h, wd = x_shape
-    k, _, r, s = w_shape
-    d = make_desc(n, c, h, wd, k, r, s, stride, pad, dil, groups)
-    dx = accumulate_into if accumulate_into is not None else empty_nhwc((n, c, h, wd), dy)
-    if dx.numel() == 0:
-        return dx
-    if dy.numel() == 0:
-        return dx if accumulate_into is not None else dx.zero_()
-    dx_sp = SP.empty_like(dx) if (want_sp and c % 32 == 0 and accumulate_into is None) else None
-    with H.guard(dy.device):
-        rc = H.lib().cpm_conv2d_backward_data_sp(H.ctypes.byref(d), H.ptr(dy), H.ptr(dy_sp), H.ptr(wt), H.ptr(wt_sp),
-                                                 H.ptr(dx), H.ptr(dx_sp), 1 if accumulate_into is not None else 0,
-                                                 H.ptr(in_scale), H.ptr(in_act), H.stream())
-    H.check(rc, "conv2d_backward_data_sp")
-    if dx_sp is not None:
-        SP.attach(dx, dx_sp)
-    return dx
 
 
 _WT_CACHE = os.environ.get("CPM_DGRAD_WT_CACHE", "1") != "0"

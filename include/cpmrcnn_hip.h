@@ -220,9 +220,6 @@ int cpm_conv2d_backward_data_prepared_w4(const cpm_conv_desc* d, const float* dy
                                          int accumulate, const float* in_scale, const float* in_act, void* workspace,
                                          size_t workspace_bytes, void* stream);
 
-/* (The experimental split-plane / LDS-DMA ring entry points live in cpmrcnn_hip_experimental.h: measured, not on the
- * product path -- DESIGN.md section 8.) */
-
 /* nn.ConvTranspose2d forward (grid_rcnn/outputs.py:24-37,66-71) = the data gradient of the conv
  * described by `d` with a fused bias(+ReLU) epilogue: x [N,P,Q,K] -> y [N,H,W,C], w as for `d`
  * (torch's ConvTranspose2d weight [Cin=K][Cout/groups=C/g][R][S] permuted to KRSC).  Its own

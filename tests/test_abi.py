@@ -6,7 +6,7 @@ import re
 from conftest import ROOT
 
 
-HEADERS = ("cpmrcnn_hip.h", "cpmrcnn_hip_experimental.h")      # the boundary, and the measured-but-unused experiments
+HEADERS = ("cpmrcnn_hip.h",)      # the boundary
 
 
 def declared_symbols(headers=HEADERS):
@@ -35,21 +35,6 @@ def test_no_undeclared_exports():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _hip.LIB_PATH], text=True)
     exported = sorted(l.split()[-1] for l in out.splitlines() if " T cpm_" in l)
     assert exported == declared_symbols()
-
-
-def test_product_path_does_not_call_the_experimental_entry_points():
-    """include/cpmrcnn_hip_experimental.h (split-plane operands, LDS-DMA ring kernels) is reachable from
-    pet.lib.ops.sp / conv2d_forward(x_sp=...) only: no model, head or optimizer module uses those."""
-    exp = set(declared_symbols(("cpmrcnn_hip_experimental.h",))) - set(declared_symbols(("cpmrcnn_hip.h",)))
-    assert exp == {"cpm_split_planes", "cpm_conv2d_forward_sp", "cpm_conv2d_backward_data_sp"}
-    pkg = os.path.join(ROOT, "cpm-r-cnn_amd", "pet")
-    allowed = {os.path.join(pkg, "lib", "ops", "sp.py"), os.path.join(pkg, "lib", "ops", "conv.py")}
-    for d, _, files in os.walk(pkg):
-        for f in files:
-            path = os.path.join(d, f)
-            if f.endswith(".py") and path not in allowed:
-                src = open(path).read()
-                assert not any(n in src for n in exp) and "ops.sp" not in src and "import sp" not in src, path
 
 
 def test_ops_refuse_cpu_tensors():

@@ -63,15 +63,12 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--epi", default="plain", choices=["plain", "res"], help="res: forward with frozen affine + residual "
                     "+ ReLU (bottleneck conv3), data gradient accumulating into an existing tensor")
-    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "sp", "w4"],
-                    help="sp = bf16x3 arithmetic on pre-split (split-plane) operands, LDS-DMA kernel; w4 = bf16x3 with "
-                         "the forward weight given as its pre-split image (cpm_split_w4)")
+    ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "w4"],
+                    help="w4 = bf16x3 with the forward weight given as its pre-split image (cpm_split_w4)")
     a = ap.parse_args()
     from pet.lib.ops import _hip
-    from pet.lib.ops import sp as SP
-    use_sp = a.math == "sp"
     use_w4 = a.math == "w4"
-    if use_sp or use_w4:
+    if use_w4:
         a.math = "bf16x3"
     _hip.set_conv_math(a.math)
     tot = {"fwd": [0, 0], "dgrad": [0, 0], "wgrad": [0, 0]}
@@ -98,15 +95,6 @@ def main():
         if use_w4:
             w4 = ops.split_w4(w)
             fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g, w4=w4)
-        if use_sp:
-            x_sp, w_sp, dy_sp = SP.split(x), SP.split(w), SP.split(dy)
-            kg, cg = K // g, C // g
-            wt = w.reshape(g, kg, cg, R * R).permute(0, 2, 3, 1).contiguous().reshape(g * cg * R * R, kg)
-            wt_sp = SP.split(wt)
-            fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g, x_sp=x_sp, w_sp=w_sp,
-                                             want_sp=True)
-            dgr = lambda: ops.conv2d_backward_data_sp(dy, dy_sp, wt, wt_sp, (N, C, H, W), tuple(w.shape), st, pad, 1, g,
-                                                      want_sp=True)
         if a.math != "f32" and a.epi == "plain":
             y1 = fwd()
             d1 = dgr()
@@ -118,9 +106,6 @@ def main():
                                                float((d1 - d0).abs().max() / d0.abs().max()))
         t_f = timeit(fwd, a.iters)
         t_d = timeit(dgr, a.iters)
-        if use_sp:
-            err += "  split x %.1f us dy %.1f us" % (timeit(lambda: SP.split(x), a.iters) * 1e3,
-                                                     timeit(lambda: SP.split(dy), a.iters) * 1e3)
         t_w = timeit(lambda: ops.conv2d_backward_weight(x, dy, w, st, pad, 1, g, out=dw), a.iters)
         print("%-20s %9.1f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (
             name, gf, t_f * 1e3, gf / t_f, t_d * 1e3, gf / t_d, t_w * 1e3, gf / t_w) + err)
