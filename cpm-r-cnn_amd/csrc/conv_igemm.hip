@@ -824,6 +824,312 @@ __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(3,
   }
 }
 
+// ---- persistent tiles: the bf16x3 / vector / pre-split-weight kernel as ONE pipeline over a run of output tiles ---------
+// The thin layers of the step (1x1 convolutions of layer2-4 and their data gradients, 3x3 convolutions on the stride-16 /
+// stride-32 maps, the RoI heads' small GEMMs) give a workgroup 2-16 k-steps between a prologue (address arithmetic with
+// integer divisions, the first operand fetch: one exposed memory round trip) and an epilogue (residual / gate reads:
+// another one, then the stores), and the grid arrives in two or three residency rounds that each pay both again.  Here a
+// workgroup owns a contiguous RUN of tiles (tile order: output-channel tile fastest, so a run re-reads the same input
+// rows out of L2) and treats (tile, k-step) as one sequence: the operand loads run two steps ahead ACROSS tile
+// boundaries (the load cursor carries its own tile geometry), so a tile's epilogue executes with the next tile's first
+// two operand tiles already in flight, and nothing is re-launched.  The epilogue goes straight from the accumulators
+// (no LDS staging: the operand buffers are live): per 32-row slab every residual / gate value is requested first, then
+// the slab is finished and stored.  Arithmetic and reduction order are those of igemm_kernel<.., true, 2>: results are
+// bit-identical (tests/test_gpu_conv.py::test_persistent_tiles_equal_one_tile_per_workgroup).
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN)
+    __attribute__((amdgpu_waves_per_eu(2, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))) void igemm_pt_kernel(
+        IgemmArgs a, int ntiles, int run) {
+  constexpr int NT = 64 * WM * WN;              // threads
+  constexpr int RPP = NT / 8;                   // rows per load pass (8 threads x float4 cover a 32-float row)
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+  constexpr int TM = WTM / 32, TN = WTN / 32;   // MFMA tiles per wave
+  constexpr int AP = BM / RPP, BP = BN / RPP;   // load passes
+  static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile shape");
+
+  // hi / lo planes of A and B, two stages each: [plane][stage][row][32 bf16], 16-byte chunks XOR-swizzled (igemm_kernel)
+  __shared__ __attribute__((aligned(16))) unsigned sm[2 * (BM + BN) * 32];
+  constexpr int PA_HI = 0, PA_LO = 2 * BM * 16, PB_HI = 4 * BM * 16, PB_LO = 4 * BM * 16 + 2 * BN * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.OCg + BN - 1) / BN;
+  const int tiles_m = (a.M - a.m_base + BM - 1) / BM;
+  const int tpg = tiles_m * tiles_n;            // tiles per group
+  // workgroups on one XCD (ids b, b + 8, ..) take neighbouring runs: the weight tiles and halo rows they share hit one L2
+  int wg = blockIdx.x;
+  if (a.xcd_swizzle) {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
+    wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
+  }
+  const int t_begin = wg * run, t_end = min(ntiles, t_begin + run);
+  if (t_begin >= t_end) return;
+  const int nk = a.ksteps;
+
+  // rows of this launch are the input pixels themselves (1x1, stride 1, no padding: forward and data gradient): no
+  // division anywhere in the tile geometry
+  const bool pw = a.nr == 1 && a.ns == 1 && a.ihmul == 1 && a.iwmul == 1 && a.ihadd == 0 && a.iwadd == 0 &&
+                  a.OHp == a.IH && a.OWp == a.IW;
+
+  // ---- the load cursor: tile, k-step inside it, tap position, per-thread row geometry of THAT tile -----------------
+  const int lrow = tid >> 3;        // 0..RPP-1
+  const int lcol = (tid & 7) * 4;   // 0,4,..,28
+  unsigned a_off[AP], b_off[BP];
+  int a_h[AP], a_w[AP];
+  int lt = t_begin, lstep = 0, l_tr = 0, l_ts = 0, l_cb = 0;
+  const int cb_end = a.ksteps_per_tap * BK;
+  auto geom = [&](int t) {
+    const int g = t / tpg, r = t - g * tpg, tm = r / tiles_n, tn = r - tm * tiles_n;
+    const int m0 = a.m_base + tm * BM, n0 = tn * BN;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int m = m0 + i * RPP + lrow;
+      const bool ok = m < a.M;
+      const int mm = ok ? m : 0;
+      if (pw) {
+        a_h[i] = ok ? 0 : -(1 << 28);                          // a row past M never passes the range check
+        a_w[i] = 0;
+        a_off[i] = (unsigned)(mm * a.Ctot + g * a.CgR + lcol) * 4u;
+      } else {
+        const int jj = mm % a.OWp, t2 = mm / a.OWp;
+        const int ii = t2 % a.OHp, n = t2 / a.OHp;
+        a_h[i] = ok ? ii * a.ihmul + a.ihadd : -(1 << 28);
+        a_w[i] = jj * a.iwmul + a.iwadd;
+        a_off[i] = (unsigned)(((n * a.IH + (ok ? a_h[i] : 0)) * a.IW + a_w[i]) * a.Ctot + g * a.CgR + lcol) * 4u;
+      }
+      asm volatile("" : "+v"(a_off[i]), "+v"(a_h[i]), "+v"(a_w[i]));
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int oc = n0 + i * RPP + lrow;
+      b_off[i] = oc < a.OCg ? (unsigned)((g * a.OCg + oc) * a.R * a.S * a.CgR + lcol) * 4u : B_INVALID;
+      asm volatile("" : "+v"(b_off[i]));
+    }
+    l_tr = 0; l_ts = 0; l_cb = 0;
+  };
+
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
+  auto load_tile = [&](float4 (&ra)[AP], float4 (&rb)[BP]) {
+    const bool live = lt < t_end;                            // the cursor ran past the run: every lane masked
+    const int cb = l_cb;                                     // first reduction channel of this k-step (uniform)
+    const int dh = l_tr * a.hstep, dw = l_ts * a.wstep;
+    const unsigned wtap = (unsigned)(((a.r0 + l_tr * a.rstep) * a.S + a.s0 + l_ts * a.sstep) * a.CgR + cb) * 4u;
+    const unsigned aoff = (unsigned)((dh * a.IW + dw) * a.Ctot + cb) * 4u;
+    const bool c_ok = live & (cb + lcol < a.CgR);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const bool ok = c_ok & ((unsigned)(a_h[i] + dh) < (unsigned)a.IH) & ((unsigned)(a_w[i] + dw) < (unsigned)a.IW);
+      ra[i] = bload4(rs_in, ok ? a_off[i] + aoff : OOB_OFF);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = bload4(rs_wm, c_ok ? b_off[i] + wtap : OOB_OFF);
+    // advance: channel block, tap column, tap row, and -- behind the tile's last k-step -- the next tile of the run
+    {
+      const int ncb = l_cb + BK;
+      const bool wrap_c = ncb >= cb_end;
+      const int nts = l_ts + (wrap_c ? 1 : 0);
+      const bool wrap_s = nts == a.ns;
+      l_cb = wrap_c ? 0 : ncb;
+      l_ts = wrap_s ? 0 : nts;
+      l_tr += wrap_s ? 1 : 0;
+    }
+    if (++lstep == nk) {
+      lstep = 0;
+      ++lt;
+      if (lt < t_end) geom(lt);
+    }
+  };
+  const int w_sw = ((((lcol >> 3) ^ ((lrow >> 2) & 3)) << 2) | ((lcol >> 1) & 2));   // dword offset inside the row
+  auto store_tile = [&](int buf, const float4 (&ra)[AP], const float4 (&rb)[BP]) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      uint2 hi, lo;
+      split4(ra[i], hi, lo);
+      const int o = (buf * BM + i * RPP + lrow) * 16 + w_sw;
+      *(uint2*)(sm + PA_HI + o) = hi;
+      *(uint2*)(sm + PA_LO + o) = lo;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
+      *(uint2*)(sm + PB_HI + o) = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+      *(uint2*)(sm + PB_LO + o) = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  };
+  zero_acc();
+
+  const int frow = lane & 31;
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto fetch = [&](int cur, int sub, Frag& f) {
+    const int r_sw = (((sub * 2 + (lane >> 5)) ^ ((frow >> 2) & 3)) << 2);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int o = (cur * BM + wm * WTM + i * 32 + frow) * 16 + r_sw;
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = (cur * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+    }
+  };
+  auto mfma3 = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  // ---- epilogue of one tile, straight from the accumulators --------------------------------------------------------
+  // C/D map of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  const bool dense_rows = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
+  const bool need_pos = !dense_rows || (a.res && a.res_mode == 1);
+  // Branch-free: every access goes through a buffer descriptor and a lane outside the tensor (row past M, channel past
+  // the group) gets an out-of-range offset -- its loads return zeros and its store is dropped.
+  const unsigned out_bytes = (unsigned)((size_t)a.N * a.OH * a.OW * a.OCtot * 4);
+  const unsigned res_bytes = a.res_mode == 0 ? out_bytes
+                                             : (unsigned)((size_t)a.N * ((a.OH + 1) / 2) * ((a.OW + 1) / 2) * a.OCtot * 4);
+  const __amdgpu_buffer_rsrc_t rs_out = make_rsrc(a.out, out_bytes), rs_res = make_rsrc(a.res, a.res ? res_bytes : 0u),
+                               rs_mask = make_rsrc(a.mask, a.mask ? out_bytes : 0u);
+  auto epilogue = [&](int t) {
+    const int g = t / tpg, r = t - g * tpg, tm = r / tiles_n, tn = r - tm * tiles_n;
+    const int m0 = a.m_base + tm * BM + wm * WTM, n0 = tn * BN + wn * WTN;
+    int oc[TN];
+    bool okc[TN];
+    float e_sc[TN], e_sh[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int ocl = n0 + j * 32 + ecol;
+      okc[j] = ocl < a.OCg;
+      oc[j] = g * a.OCg + ocl;
+      e_sc[j] = (a.scale && okc[j]) ? a.scale[oc[j]] : 1.f;
+      e_sh[j] = (a.shift && okc[j]) ? a.shift[oc[j]] : 0.f;
+    }
+    // groups of 8 accumulator rows (half a 32-row slab): every residual / gate value of a group is requested before its
+    // first store -- the compiler cannot move a load above a store that may alias it (in the accumulating data gradient
+    // the residual IS the output) -- and a group's temporaries (8 x TN offsets, residuals, gates) stay small enough to
+    // live beside the accumulators AND both operand register sets, whose loads are in flight right now
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned bo[8][TN];                    // byte offset of the output element, OOB_OFF outside the tensor
+        float rv[8][TN], gv[8][TN];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int e = h * 8 + q;
+          const int m = m0 + i * 32 + (e & 3) + 8 * (e >> 2) + erow0;
+          const bool ok = m < a.M;
+          int orow = m, rrow = 0;
+          if (need_pos) {
+            const int mm = ok ? m : a.m_base;
+            const int jj = mm % a.OWp, t2 = mm / a.OWp;
+            const int ii = t2 % a.OHp, n = t2 / a.OHp;
+            const int oh = ii * a.osh + a.oah, ow = jj * a.osw + a.oaw;
+            orow = (n * a.OH + oh) * a.OW + ow;
+            rrow = (n * ((a.OH + 1) / 2) + oh / 2) * ((a.OW + 1) / 2) + ow / 2;
+          }
+          const int rbase = a.res_mode == 0 ? orow * a.OCtot : rrow * a.OCtot;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const bool live = ok & okc[j];
+            bo[q][j] = live ? (unsigned)(orow * a.OCtot + oc[j]) * 4u : OOB_OFF;
+            if (a.res)
+              rv[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                  rs_res, (int)(live ? (unsigned)(rbase + oc[j]) * 4u : OOB_OFF), 0, 0));
+          }
+        }
+        if (a.mask) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              gv[q][j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs_mask, (int)bo[q][j], 0, 0));
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            float v = acc[i][j][h * 8 + q];
+            // (the two forms round like igemm_kernel's two epilogues: its residual path contracts scale and shift
+            // into one fma, its direct path applies them under their flags)
+            if (a.res) {
+              v = __builtin_fmaf(v, e_sc[j], e_sh[j]) + rv[q][j];
+            } else {
+              if (a.scale) v *= e_sc[j];
+              if (a.shift) v += e_sh[j];
+            }
+            if (a.relu) v = fmaxf(v, 0.f);
+            if (a.mask) v = gv[q][j] > 0.f ? v : 0.f;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rs_out, (int)bo[q][j], 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- the pipeline ---------------------------------------------------------------------------------------------
+  // One step: issue the loads of the tile two steps ahead, multiply the first half of the current one, move the tile one
+  // step ahead (loaded a whole step ago) from registers to the other LDS stage, multiply the second half, barrier; behind
+  // a tile's last k-step its epilogue runs -- the operand tiles of the next tile's first two steps are in flight or in LDS.
+  int ct = t_begin, cstep = 0;
+  auto step = [&](int cur, float4 (&la)[AP], float4 (&lb)[BP], const float4 (&sa)[AP], const float4 (&sb)[BP]) {
+    load_tile(la, lb);
+    Frag f0, f1;
+    fetch(cur, 0, f0);
+    fetch(cur, 1, f1);
+    mfma3(f0);
+    store_tile(cur ^ 1, sa, sb);          // unconditional (the last step re-stores a stale tile into the idle stage)
+    mfma3(f1);
+    constexpr int NM = TM * TN * 3 * 2;                      // MFMAs of the step
+    constexpr int VPM = (AP * 12 + (AP + BP) * 4 + NM - 1) / NM;
+    constexpr int WEVERY = NM / (AP + BP) > 0 ? NM / (AP + BP) : 1;
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, VPM, 0);
+      if (m % WEVERY == WEVERY - 1) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __syncthreads();
+    if (++cstep == nk) {
+      epilogue(ct);
+      zero_acc();
+      ++ct;
+      cstep = 0;
+    }
+  };
+
+  float4 ra0[AP], rb0[BP], ra1[AP], rb1[BP];
+  geom(t_begin);
+  load_tile(ra0, rb0);
+  store_tile(0, ra0, rb0);
+  load_tile(ra1, rb1);
+  __syncthreads();
+  const int total_steps = (t_end - t_begin) * nk;
+  for (int s = 0; s < total_steps; s += 2) {
+    step(0, ra0, rb0, ra1, rb1);                         // tile s in stage 0; tile s + 1 waits in register set 1
+    if (s + 1 < total_steps) step(1, ra1, rb1, ra0, rb0);
+  }
+}
+
 // ---- 3x3 stride-1 convolution with the input patch staged ONCE per channel block (bf16x3 arithmetic) ----------
 // The generic kernel gathers (and splits, and stores to LDS) an A tile per tap: a 3x3 layer moves every input
 // element 9 x (K / BN) times through that path.  Here a workgroup owns an 8 x 16 patch of output pixels (128 GEMM
@@ -2399,8 +2705,40 @@ Plan plan_igemm(const IgemmArgs& a) {
   return p;
 }
 
+// igemm_pt_kernel: a run of tiles per workgroup, as many workgroups as the chip holds at once (or fewer)
+template <int BM, int BN, int WM, int WN>
+int launch_pt(const IgemmArgs& a, int per_cu, hipStream_t s) {
+  const int64_t tiles = (int64_t)cpm::cdiv(a.M - a.m_base, BM) * cpm::cdiv(a.OCg, BN) * a.groups;
+  const int cap = env_int("CPM_IGEMM_PT_WGS", 0);              // tests: a small grid, so that small problems get runs too
+  const int64_t slots = cap > 0 ? cap : (int64_t)per_cu * num_cus();
+  const int run = (int)((tiles + slots - 1) / slots);
+  const int64_t wgs = (tiles + run - 1) / run;
+  hipLaunchKernelGGL((igemm_pt_kernel<BM, BN, WM, WN>), dim3((unsigned)wgs), dim3(64 * WM * WN), 0, s, a, (int)tiles, run);
+  return cpm::check_launch("conv igemm (persistent tiles)");
+}
+
 int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t s) {
   const int rows = a.M - a.m_base;
+  // persistent tiles (igemm_pt_kernel): whenever the grid would not fit the chip at once.  CPM_IGEMM_PT: 0 off, 1 wherever
+  // the kernel applies (tests), 2 by grid size.  Read per call: the tests switch it.
+  const int pt = env_int("CPM_IGEMM_PT", 2);
+  if (pt && vec && g_conv_split && a.b_presplit && a.split_k == 1 && !a.atomic_out && !a.slab && a.ksteps >= 1 &&
+      bn >= 64 && (wn == 2)) {
+    const int per_cu = bm * bn >= 128 * 128 ? 2 : (bm * bn >= 128 * 64 ? 3 : 4);
+    const int64_t tiles = (int64_t)cpm::cdiv(rows, bm) * cpm::cdiv(a.OCg, bn) * a.groups;
+    // by grid size (2): grids of several residency rounds on dense output rows.  Measured per layer (MI355X, tools/
+    // bench_conv.py): the 1x1 layers of layer1 / layer2 and the P2 lateral (8-16 tiles per workgroup) 10-20 % faster
+    // forward and in the plain data gradient (64->256 on 200x336: 64.6 -> 52.7 us, 256->64: 41.1 -> 35.6, lateral 98.8 ->
+    // 90.5); NO change on the 2-3-tile runs of layer3 / layer4 (30 us either way, whatever the tile: those are not bound
+    // by their prologues); the accumulating data gradient (residual == output) and strided output rows are faster
+    // through igemm_kernel's LDS-staged row-wise epilogue (256->128 stride 2: 30 vs 41 us) and stay there.
+    const bool dense_out = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
+    if (pt == 1 || (tiles > (int64_t)per_cu * num_cus() && dense_out && !(a.res && a.res == a.out))) {
+      if (bm == 128 && bn == 128) return launch_pt<128, 128, 2, 2>(a, per_cu, s);
+      if (bm == 128 && bn == 64) return launch_pt<128, 64, 2, 2>(a, per_cu, s);
+      if (bm == 64 && bn == 64) return launch_pt<64, 64, 2, 2>(a, per_cu, s);
+    }
+  }
   // one-LDS-stage variant (three workgroups per CU): pays once the grid holds three rounds' worth of workgroups per CU
   // (256->256 1x1 on 200x336: 125 -> 109 us; 576x576x3x3 on 192 RoIs 209 -> 200 us), loses 5-10 % on grids that do not
   // even fill two per CU (its workgroups are slower one by one).  CPM_IGEMM_S1: 0 off, 1 always (tests), 2 by grid size.

@@ -142,7 +142,7 @@ def main():
         res["err"] = float((opt.flat_grad - want).abs().max() / scale)
         res["err_first"] = float((first - want).abs().max() / scale)
         res["nonzero"] = float(want.abs().max()) > 0
-        res["order"] = order
+        res["order"] = list(order)                 # (of the two steps above; the list keeps growing below)
         res["chunks"] = len(red.chunks)
         res["launched_in_backward"] = len(launched_in_backward) - len(red.chunks)    # of the 2nd step
         res["ready_fires_per_param_max"] = max(fired.count(i) for i in set(fired)) if fired else 0

@@ -823,3 +823,73 @@ def test_one_stage_igemm_equals_two_stage(case, monkeypatch):
     finally:
         _hip.set_deterministic(False)
         _hip.set_conv_math(prev)
+
+
+PT_CASES = [
+    # N, C, H, W, K, R, stride, pad, groups, res_mode (None: no residual)
+    (3, 256, 20, 27, 320, 1, 1, 0, 1, 0),        # 1x1 on dense rows, ragged row and channel tiles, residual + affine + ReLU
+    (2, 64, 31, 17, 256, 1, 1, 0, 1, None),      # two k-steps per tile: a run is mostly tile boundaries
+    (2, 256, 22, 30, 128, 1, 2, 0, 1, None),     # strided 1x1: row gather forward, one live stride phase backward
+    (2, 128, 13, 19, 128, 3, 1, 1, 1, 0),        # 3x3 with padding: the divisions of the tile geometry, nine taps
+    (5, 256, 14, 14, 576, 3, 2, 1, 1, None),     # grid head conv0 (stride 2): four stride phases backward
+    (2, 512, 12, 10, 256, 1, 1, 0, 1, 1),        # FPN lateral: residual = nearest-2x of the coarser map
+    (2, 128, 9, 11, 256, 3, 1, 1, 4, None),      # grouped (32 channels per group)
+    (40, 1024, 1, 1, 1024, 1, 1, 0, 1, None),    # a Linear layer
+]
+
+
+@pytest.mark.parametrize("case", PT_CASES, ids=["%dx%dx%dx%d_k%d_r%d_s%d_p%d_g%d_res%s" % c for c in PT_CASES])
+@pytest.mark.parametrize("wgs", [0, 3])
+def test_persistent_tiles_equal_one_tile_per_workgroup(case, wgs, conv_math, monkeypatch, deterministic_reductions):
+    """igemm_pt_kernel (a run of output tiles per workgroup, operand loads running ahead across tile boundaries,
+    epilogue straight from the accumulators) against igemm_kernel (one tile per workgroup): the same arithmetic in the
+    same order -- forward, data gradient (plain, accumulating, gated) BIT-identical.  wgs = 3: the grid is capped at
+    three workgroups, so that these small problems run as long runs of tiles.  (Ordered reductions: a split-K launch --
+    both sides run igemm_kernel for those -- is then reproducible too.)"""
+    if conv_math != "bf16x3":
+        pytest.skip("the persistent kernel serves the bf16x3 arithmetic (pre-split weight images)")
+    from pet.lib.ops import conv as ops
+    N, C, H, W, K, R, stride, pad, groups, res_mode = case
+    P, Q = ops.out_size(H, R, stride, pad), ops.out_size(W, R, stride, pad)
+    x = rnd(N, C, H, W, seed=1).cuda().contiguous(memory_format=CL)
+    w = rnd(K, C // groups, R, R, seed=2, scale=1.0 / np.sqrt(C // groups * R * R)).cuda().contiguous(memory_format=CL)
+    dy = rnd(N, K, P, Q, seed=3).cuda().contiguous(memory_format=CL)
+    scale = (torch.rand(K, generator=torch.Generator().manual_seed(4)) + 0.5).cuda()
+    shift = rnd(K, seed=5, scale=0.1).cuda()
+    res = None
+    if res_mode == 0:
+        res = rnd(N, K, P, Q, seed=6).cuda().contiguous(memory_format=CL)
+    elif res_mode == 1:
+        res = rnd(N, K, (P + 1) // 2, (Q + 1) // 2, seed=6).cuda().contiguous(memory_format=CL)
+    gate = rnd(N, C, H, W, seed=7).cuda().contiguous(memory_format=CL)
+    acc0 = rnd(N, C, H, W, seed=8).cuda().contiguous(memory_format=CL)
+    w4 = ops.split_w4(w)
+
+    def run_all():
+        out = {}
+        out["fwd_plain"] = ops.conv2d_forward(x, w, None, None, None, 0, False, stride, pad, 1, groups, w4=w4)
+        out["fwd_bias_relu"] = ops.conv2d_forward(x, w, None, shift, None, 0, True, stride, pad, 1, groups, w4=w4)
+        if res is not None:
+            out["fwd_affine_res_relu"] = ops.conv2d_forward(x, w, scale, shift, res, res_mode, True, stride, pad, 1,
+                                                            groups, w4=w4)
+        out["dgrad"] = ops.conv2d_backward_data(dy, w, (N, C, H, W), stride, pad, 1, groups)
+        out["dgrad_scaled"] = ops.conv2d_backward_data(dy, w, (N, C, H, W), stride, pad, 1, groups, k_scale=scale)
+        out["dgrad_gated"] = ops.conv2d_backward_data_gated(dy, w, gate, None, stride, pad, 1, groups)
+        out["dgrad_acc"] = ops.conv2d_backward_data(dy, w, (N, C, H, W), stride, pad, 1, groups,
+                                                    accumulate_into=acc0.clone())
+        out["dgrad_acc_gate"] = ops.conv2d_backward_data(dy, w, (N, C, H, W), stride, pad, 1, groups,
+                                                         accumulate_into=acc0.clone(), gate=gate)
+        torch.cuda.synchronize()
+        return out
+
+    monkeypatch.setenv("CPM_IGEMM_PT", "0")
+    want = run_all()
+    monkeypatch.setenv("CPM_IGEMM_PT", "1")
+    if wgs:
+        monkeypatch.setenv("CPM_IGEMM_PT_WGS", str(wgs))
+    got = run_all()
+    for k in want:
+        assert torch.equal(want[k], got[k]), "%s differs: max |d| %g" % (k, float((want[k] - got[k]).abs().max()))
+    # and both are the convolution (forward against torch on the CPU)
+    yr = F.conv2d(x.cpu().contiguous(), w.cpu().contiguous(), None, stride, pad, 1, groups)
+    assert relerr(got["fwd_plain"], yr) < TOL
