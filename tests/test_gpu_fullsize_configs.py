@@ -8,8 +8,9 @@
 One whole training iteration each through the same loop as bench.py (scheduler, zero_grad, forward, backward, SGD):
 state-dict ABI equal to the reference's dump, finite losses, every trainable tensor of the reference's trainable set
 receives a finite, non-zero gradient, RoI counts inside the configuration's caps, and the step is repeatable.
-Numerical parity of these block types is held at small sizes elsewhere (test_gpu_model.py: R-50 blocks vs the
-reference; test_gpu_deform.py: the ResNeXt-DCN body vs the CPU oracle) -- a CPU reference at this size takes minutes."""
+Numerical parity at this size: tests/test_gpu_fullsize_oracle.py (config #2 against the CPU oracle); the block types of
+#4 / #5 are held at small sizes (test_gpu_model.py: R-50 blocks vs the reference; test_gpu_deform.py: the ResNeXt-DCN
+body vs the CPU oracle)."""
 import json
 import os
 
