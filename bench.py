@@ -160,6 +160,40 @@ class Trainer(object):
         self.last_losses = out["losses"]
 
 
+def csrc_digest():
+    """sha256 over the kernel sources (cpm-r-cnn_amd/csrc, file names and contents in sorted order): what a committed
+    PMC profile is stamped with (tools/pmc_summary.py) and what this run compares it to"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "cpm-r-cnn_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_traffic():
+    """(HBM bytes per igemm launch, where from) out of the newest profiles/round*_pmc.json whose `csrc_sha256` equals
+    this tree's kernel sources; (None, why) otherwise -- the line never quotes counters of another build."""
+    import glob
+    digest = csrc_digest()
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_pmc.json")), reverse=True)
+    for path in found:
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if d.get("csrc_sha256") == digest and "igemm_kernel" in d.get("kernels", {}):
+            k = d["kernels"]["igemm_kernel"]
+            return k.get("hbm_bytes_per_launch"), "%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench on csrc %s)" % (
+                os.path.relpath(path, ROOT), digest[:12])
+    return None, "stale: no profiles/round*_pmc.json was measured on these kernel sources (csrc %s; have %s)" % (
+        digest[:12], ", ".join(os.path.basename(p) for p in found) or "none")
+
+
 def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     """HIP-event time of every conv launch (events recorded on the launch stream inside the library) over
     `steps` extra iterations; algorithmic flops = 2*N*P*Q*K*R*S*C/g per launch."""
@@ -188,21 +222,25 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     # algorithmic HBM bytes of the average igemm call: input + output + weight, each once (fp32)
     import csv
     import tempfile
-    alg_bytes = per_call_frac = None
+    alg_bytes = alg_core = per_call_frac = None
     with tempfile.NamedTemporaryFile("r", suffix=".csv") as tf:
         if L.cpm_prof_dump(tf.name.encode()) == 0:
-            nb, nl, bound_ms, meas_ms = 0.0, 0, 0.0, 0.0
+            nb, nb_core, nl, bound_ms, meas_ms = 0.0, 0.0, 0, 0.0, 0.0
             for r in csv.DictReader(open(tf.name)):
                 if r["kind"] in ("0", "1"):
                     N, Hh, W, C, K, R, g, P, Q = (int(r[k]) for k in ("N", "H", "W", "C", "K", "R", "groups", "P", "Q"))
-                    by = 4.0 * (N * Hh * W * C + N * P * Q * K + K * R * R * (C // g))
+                    # input + output + weight, each once, + the operands of the fused epilogue (the residual of a
+                    # bottleneck's last conv / an FPN lateral, the gate and the running sum of a data gradient)
+                    by = 4.0 * (N * Hh * W * C + N * P * Q * K + K * R * R * (C // g)) + float(r.get("epi_bytes") or 0)
                     nb += by
+                    nb_core += 4.0 * (N * Hh * W * C + N * P * Q * K + K * R * R * (C // g))
                     nl += 1
                     # the launch's own roofline: MFMA peak of the arithmetic or 8 TB/s on its algorithmic bytes
                     peak = MFMA_BF16_PEAK_TFLOPS / 3 if math == "bf16x3" else MFMA_F32_PEAK_TFLOPS
                     bound_ms += max(float(r["gflop"]) / peak, by / 8e9)
                     meas_ms += float(r["ms"])
             alg_bytes = int(nb / nl) if nl else None
+            alg_core = int(nb_core / nl) if nl else None
             per_call_frac = round(bound_ms / meas_ms, 4) if meas_ms else None
     L.cpm_prof_enable(0)
     # dominant kernel = igemm_kernel<...> (forward-gather + data-gradient-gather instantiations of one template)
@@ -215,12 +253,11 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
                 for k, v in kinds.items()}
     allc = {"ms_per_step": round(allms, 3), "tflops": round(allgf / allms, 2) if allms else 0.0}
     # HBM-side bytes per launch of the dominant kernel: PMC counters cannot be read from inside this process; they are
-    # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this same command) and committed
-    traffic = None
-    pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round3_pmc.json")
-    if math == "bf16x3" and os.path.exists(pmc):
-        with open(pmc) as f:
-            traffic = json.load(f)["kernels"]["igemm_kernel"]["hbm_bytes_per_launch"]
+    # collected with rocprofv3 (separate FETCH_SIZE / WRITE_SIZE passes of this same command: tools/pmc_run.sh) and
+    # committed with a digest of the kernel sources they were measured on.  A profile of OTHER sources is not quoted.
+    traffic, traffic_source = None, "no PMC profile of this build under profiles/ (tools/pmc_run.sh makes one)"
+    if math == "bf16x3":
+        traffic, traffic_source = committed_traffic()
     if math == "f32":
         return {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad, v_mfma_f32_32x32x2_f32)",
                 "achieved": round(achieved, 2), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -231,7 +268,10 @@ def conv_roofline(trainer, images, targets, steps=2, math="bf16x3"):
     return {"bound": "mfma", "kernel": "igemm_kernel (conv fwd + dgrad, 3 x v_mfma_f32_32x32x16_bf16 per product)",
             "achieved": round(achieved, 2), "peak": round(MFMA_BF16_PEAK_TFLOPS / 3, 1), "unit": "TFLOP/s",
             "frac": round(3 * achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_source,
             "algorithmic_bytes_per_call": alg_bytes,
+            "algorithmic_bytes_note": "input + output + weight once each (%s B) + the fused epilogue's operands: residual "
+                                      "/ gate / running-sum reads" % alg_core,
             "frac_vs_per_call_bound": per_call_frac,
             "per_call_bound_note": "sum over the family's launches of max(flops / MFMA peak, algorithmic bytes / 8 TB/s) "
                                    "divided by their measured time: many of the step's 1x1 layers are HBM-bound by shape",
@@ -387,8 +427,11 @@ def main():
                     "bs=2, the RoI counts BASELINE.md's 6.3 TFLOP/step model assumes); reported as config.full_rois")
     ap.add_argument("--no-other-bodies", action="store_true", help="skip the legs of the other BASELINE configs "
                     "(R-101-FPN bs=2, X-101-64x4d-FPN-DCN bs=1; N=1 only; reported as config.other_bodies)")
-    ap.add_argument("--chunks", type=int, default=8, help="number of contiguous pieces the flat gradient is all-reduced "
-                    "in (pet/utils/parallel.py: default 8 x ~77 MB; sweep it on the 8-GPU node)")
+    ap.add_argument("--chunks", type=str, default=os.environ.get("CPM_CHUNKS", "8"),
+                    help="number of contiguous pieces the flat gradient is all-reduced in (pet/utils/parallel.py: "
+                         "default 8 x ~77 MB).  A comma list (e.g. 8,2,4,16,32) times the headline with the FIRST value "
+                         "and, on N > 1 ranks, a short leg with each of the others: config.chunk_sweep -- one invocation "
+                         "on the 8-GPU node yields the sweep (env CPM_CHUNKS sets the default)")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("CPM_GRAPH_STATIC", "0")),
                     help="1: backbone + FPN + RPN-head convolutions (static shapes) run as captured hipGraphs, forward "
                          "and backward (Generalized_RCNN.capture_static_part), after the eager warm-up steps")
@@ -415,6 +458,8 @@ def main():
     from pet.lib.ops import _hip
     _hip.set_conv_math(a.conv_math)
     layers = tuple(int(x) for x in a.layers.split(","))
+    chunk_list = [max(1, int(c)) for c in str(a.chunks).split(",") if c.strip()]
+    a.chunks = chunk_list[0]
     trainer = Trainer(device, layers=layers, body=a.body, chunks=a.chunks)
     images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
     cal_img, _ = synthetic_batch(a.batch, a.height, a.width, 1, 4321, device)     # same on every rank
@@ -481,6 +526,28 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_other = float(t.item())
         _hip.set_conv_math(a.conv_math)
+    chunk_sweep = None
+    if world > 1 and len(chunk_list) > 1:
+        # the same step with the flat gradient cut into other numbers of all-reduce pieces (all ranks: collective)
+        from pet.utils.parallel import FlatGradReducer
+        chunk_sweep = {str(a.chunks): round(a.batch * world * a.steps / elapsed, 3)}
+        k_c = max(1, min(a.steps, 10))
+        for c in chunk_list[1:]:
+            trainer.reducer.close()
+            trainer.reducer = FlatGradReducer(trainer.optimizer, num_chunks=c)
+            for _ in range(2):
+                trainer.step(images, targets)
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(k_c):
+                trainer.step(images, targets)
+            sync()
+            el_c = time.perf_counter() - t1
+            t = torch.tensor([el_c], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            chunk_sweep[str(c)] = round(a.batch * world * k_c / float(t.item()), 3)
+        trainer.reducer.close()
+        trainer.reducer = FlatGradReducer(trainer.optimizer, num_chunks=a.chunks)
     full_rois = None
     if not a.no_full_rois and a.body == "resnet":
         # every rank takes part (the gradient all-reduce is collective)
@@ -596,7 +663,9 @@ def main():
                        **({"host_input": host_input} if host_input else {}),
                        **({"full_rois": full_rois} if full_rois else {}),
                        **({"other_bodies": other_bodies} if other_bodies else {}),
-                       "grad_allreduce_chunks": a.chunks, "static_part_as_hipgraph": bool(a.graph),
+                       "grad_allreduce_chunks": a.chunks, **({"chunk_sweep": chunk_sweep} if chunk_sweep else {}),
+                       "overlap_sgd": os.environ.get("CPM_OVERLAP_SGD", "0") != "0",
+                       "static_part_as_hipgraph": bool(a.graph),
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,

@@ -2586,17 +2586,22 @@ int num_cus() { return 256; }
 
 // Optional per-launch timing with HIP events on the launch stream (bench.py's roofline leg).  Off by default:
 // the hot path pays one predictable branch.
-struct ProfRec { hipEvent_t a, b; double flops; int kind; int dims[10]; };
+struct ProfRec { hipEvent_t a, b; double flops; int kind; int dims[10]; double epi_bytes; int split; };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof;
 static double g_flops_next = 0.0;
 static int g_dims_next[10] = {0};
+// operand bytes of the call's EPILOGUE (residual / gate / accumulator reads): algorithmic traffic that the in + out +
+// weight count of a convolution leaves out; and the reduction split of the launch (its partial sums are not)
+static double g_epi_bytes_next = 0.0;
+static int g_split_next = 1;
 
 struct ProfScope {
   hipStream_t s; int kind; bool on; ProfRec r;
   ProfScope(hipStream_t s_, int kind_) : s(s_), kind(kind_), on(g_prof_on) {
     if (on) {
       r.kind = kind; r.flops = g_flops_next;
+      r.epi_bytes = g_epi_bytes_next; r.split = g_split_next;
       for (int i = 0; i < 10; ++i) r.dims[i] = g_dims_next[i];
       on = hipEventCreate(&r.a) == hipSuccess && hipEventCreate(&r.b) == hipSuccess &&
            hipEventRecord(r.a, s) == hipSuccess;
@@ -2941,6 +2946,10 @@ static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const float
     }
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  g_epi_bytes_next = !residual ? 0.0
+                     : 4.0 * d->K * (res_mode == 0 ? (double)d->N * d->P * d->Q
+                                                   : (double)d->N * ((d->P + 1) / 2) * ((d->Q + 1) / 2));
+  g_split_next = a.split_k;
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = launch_igemm(a, p, s, 0);
   if (rc != CPM_OK) return rc;
@@ -3087,6 +3096,9 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  // the gate (the conv's own input, read where the gradient is masked) and the running sum of an accumulating call
+  g_epi_bytes_next = 4.0 * d->N * d->H * d->W * (double)d->C * ((out_mask ? 1 : 0) + (accumulate ? 1 : 0));
+  g_split_next = a.split_k;
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   int rc = CPM_OK;
   for (int pa = 0; pa < st && rc == CPM_OK; ++pa) {
@@ -3111,6 +3123,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
       rc = launch_igemm(a, pp, s, 1);
       a.split_k = p.split;
       g_flops_next = 0.0;                               // the call's flops are booked on its first launch
+      g_epi_bytes_next = 0.0;
     }
   }
   if (rc != CPM_OK) return rc;
@@ -3343,6 +3356,7 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
   a.row_scale = row_scale;
   const int taps = d->R * d->S;
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);
+  g_epi_bytes_next = 0.0; g_split_next = 1;
   { const int dd[10] = {d->N, d->H, d->W, d->C, d->K, d->R, d->stride, d->groups, d->P, d->Q}; for (int i = 0; i < 10; ++i) g_dims_next[i] = dd[i]; }
   static const int nostore = env_int("CPM_WGRAD_NOSTORE", 0);
   a.debug_nostore = nostore;
@@ -3502,14 +3516,14 @@ CPM_EXPORT int cpm_prof_dump(const char* path) {
   CPM_REQUIRE(path, "null path");
   FILE* f = fopen(path, "w");
   CPM_REQUIRE(f, "cannot open file");
-  fprintf(f, "kind,N,H,W,C,K,R,stride,groups,P,Q,gflop,ms\n");
+  fprintf(f, "kind,N,H,W,C,K,R,stride,groups,P,Q,gflop,ms,epi_bytes,split\n");
   for (auto& r : g_prof) {
     if (hipEventSynchronize(r.b) != hipSuccess) { fclose(f); return CPM_ELAUNCH; }
     float t = 0.f;
     (void)hipEventElapsedTime(&t, r.a, r.b);
     fprintf(f, "%d", r.kind);
     for (int i = 0; i < 10; ++i) fprintf(f, ",%d", r.dims[i]);
-    fprintf(f, ",%.4f,%.5f\n", r.flops / 1e9, t);
+    fprintf(f, ",%.4f,%.5f,%.0f,%d\n", r.flops / 1e9, t, r.epi_bytes, r.split);
   }
   fclose(f);
   return CPM_OK;

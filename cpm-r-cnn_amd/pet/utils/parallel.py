@@ -52,6 +52,7 @@ class FlatGradReducer(object):
         self._pending = None
         self._done = set()
         self._handles = []
+        self._hook_handles, self._hooked = [], []
         if self.overlap or self.local_sgd:
             params = [p for g in optimizer.param_groups for p in g["params"]]
             by_id = {id(p): p for p in params}
@@ -64,9 +65,21 @@ class FlatGradReducer(object):
                 off = (p.grad.data_ptr() - base) // 4
                 ci = next(i for i, (b, e, _) in enumerate(self.chunks) if b <= off < e)
                 hook = self._make_hook(ci, p)
-                p.register_post_accumulate_grad_hook(hook)
+                self._hook_handles.append(p.register_post_accumulate_grad_hook(hook))
                 if hasattr(p, "_cpm_grad_sink"):
                     p._cpm_grad_ready = hook        # conv weights bypass autograd's accumulation (pet.lib.ops.conv)
+                    self._hooked.append((p, hook))
+
+    def close(self):
+        """Detach from the parameters (a trainer that re-cuts its gradient buffer into another number of chunks --
+        bench.py's --chunks sweep -- builds a new reducer): this one's hooks are removed and it ignores late calls."""
+        for h in self._hook_handles:
+            h.remove()
+        for p, hook in self._hooked:
+            if getattr(p, "_cpm_grad_ready", None) is hook:
+                del p._cpm_grad_ready
+        self._hook_handles, self._hooked = [], []
+        self._pending = None
 
     def _make_hook(self, ci, p):
         """A parameter's gradient is complete either when autograd has accumulated it (post-accumulate hook) or when

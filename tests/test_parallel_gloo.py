@@ -57,6 +57,14 @@ def _worker(rank, world, port, q):
         gathered = [torch.zeros_like(local) for _ in range(world)]
         dist.all_gather(gathered, local)
         assert torch.allclose(opt.flat_grad, sum(gathered), rtol=1e-6, atol=1e-7)
+        # another cut of the same buffer (bench.py --chunks a,b,c): the first reducer is detached, the new one reduces
+        red.close()
+        red2 = FlatGradReducer(opt, num_chunks=2, overlap=True)
+        assert 1 <= len(red2.chunks) <= 2 and red2.chunks[0][0] == 0 and red2.chunks[-1][1] == opt.seg_end.tolist()[-1]
+        opt.flat_grad.copy_(local)
+        red2.begin_step()
+        red2.finish()
+        assert torch.allclose(opt.flat_grad, sum(gathered), rtol=1e-6, atol=1e-7)
         out = reduce_losses({"loss_b": torch.tensor(float(rank + 1)), "loss_a": torch.tensor(10.0 * (rank + 1))})
         assert abs(out["loss_a"] - 15.0) < 1e-6 and abs(out["loss_b"] - 1.5) < 1e-6
         q.put((rank, "ok"))

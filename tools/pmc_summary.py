@@ -14,7 +14,7 @@ import json
 import re
 import sys
 
-FAMILIES = [("igemm_kernel", r"igemm(_s1)?_kernel<"), ("igemm3x3_kernel", r"igemm3x3_kernel<"), ("igemm_sp_kernel", r"igemm_sp_kernel<"),
+FAMILIES = [("igemm_kernel", r"igemm(_s1|_pt)?_kernel<"), ("igemm3x3_kernel", r"igemm3x3_kernel<"),
             ("wgrad", r"wgrad_(split_)?kernel<"), ("wgrad_reduce_kernel", r"wgrad_reduce_kernel"),
             ("roi_align_fwd", r"roi_align_fwd"), ("roi_align_bwd_gather", r"roi_align_bwd_gather"),
             ("sgd_kernel", r"sgd_kernel")]
@@ -43,7 +43,10 @@ def load(path):
 def main():
     out_path = sys.argv[1]
     passes = dict(a.split("=", 1) for a in sys.argv[2:])
-    out = {"units": "bytes per launch; FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE "
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import csrc_digest
+    out = {"csrc_sha256": csrc_digest(), "units": "bytes per launch; FETCH_SIZE (KiB) x 1024 x 2 (gfx950 tallies 128-byte requests at 64 B), WRITE_SIZE "
                     "(KiB) x 1024; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x seconds x clock)", "kernels": {}}
     fam = collections.defaultdict(dict)
     if "FETCH" in passes:
