@@ -7,6 +7,7 @@ from .affine import AffineChannel2d
 from .losses import smooth_l1_loss, l2_loss, l2_loss_nosync, l2_loss_fused
 from .modules import Conv2d, Linear, ConvTranspose2d, GroupNorm, ReLU
 from .conv import conv2d, linear, conv_transpose2d, group_norm, stem_forward, mark_shared_grad, rpn_predictors
+from .conv import fwd_fork, fwd_side, fwd_join, rpn_head, set_rpn_sample, mask_compact
 from .pool_points_interp import pool_points_interp, PoolPointsInterp
 from .boxes import box_iou, box_voting, box_ml_voting
 from .deform_conv import deform_conv, cols_conv, DeformConv, DeformConvPack

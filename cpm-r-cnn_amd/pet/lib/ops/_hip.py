@@ -87,9 +87,20 @@ def get_conv_math():
     return [k for k, c in CONV_MATH.items() if c == v][0]
 
 
+_deterministic = os.environ.get("CPM_DETERMINISTIC", "0") not in ("", "0")
+
+
 def set_deterministic(on):
     """Split-K partial sums through ordered slab planes instead of float atomics (cpmrcnn_hip.h)."""
+    global _deterministic
     check(lib().cpm_set_deterministic(int(bool(on))), "set_deterministic")
+    _deterministic = bool(on)
+
+
+def deterministic():
+    """ordered reductions were asked for (set_deterministic / CPM_DETERMINISTIC): host-side choices between an
+    atomic-scatter formulation and an ordered one follow it too"""
+    return _deterministic
 
 
 def check(rc, what):

@@ -374,6 +374,43 @@ def wgrad_stream(device):
     return st[0]
 
 
+# ---- a second queue in the FORWARD pass ---------------------------------------------------------------------------
+# Independent branches of the forward pass -- a stage's downsample conv beside conv1 -> conv2, an FPN level's 3x3 output
+# conv beside the lateral chain below it, the RPN's shared conv on P3..P6 beside P2's -- each fill a fraction of the chip
+# (30-60 us kernels on 30-130 workgroups).  `fwd_fork(t)` marks the point in the compute stream a branch may start behind
+# (everything queued so far: its inputs); the ops inside `with fwd_side(t):` are then queued on the package's second
+# stream (the one the weight gradients use in backward, idle in forward); `fwd_join(t)` makes the compute stream wait
+# for them before their consumer is queued.  Only the KERNELS move: torch's current stream is untouched, so the autograd
+# nodes belong to the compute stream and the backward pass is what it was (in-place gradient accumulators, gradient
+# sinks and the weight-gradient fork / join assume one compute stream there); tensors allocated inside a side section
+# are compute-stream blocks that stay referenced past the join.  Results are bit-identical with the switch on or off.
+_FWD_SIDE = os.environ.get("CPM_FWD_SIDE", "1") != "0"
+
+
+def fwd_fork(t):
+    """the second stream waits for everything queued on the compute stream so far; False when the switch is off"""
+    if not (_FWD_SIDE and _SIDE_WGRAD and t.is_cuda):
+        return False
+    idx = t.device.index
+    st = _side.get(idx)
+    if st is None:
+        wgrad_stream(t.device)
+        st = _side[idx]
+    H.fork(H._raw_stream(idx), st[1])
+    return True
+
+
+def fwd_side(t):
+    """`with fwd_side(t):` -- ops inside are queued on the second stream (call fwd_fork first, fwd_join afterwards)"""
+    return H.use_stream(_side[t.device.index][1])
+
+
+def fwd_join(t):
+    """the compute stream waits for the second stream"""
+    idx = t.device.index
+    H.fork(_side[idx][1], H._raw_stream(idx))
+
+
 def _join_side():
     """end of the backward pass: the compute stream waits for the weight gradients"""
     for idx, main_raw in list(_side_armed.items()):
@@ -659,6 +696,241 @@ class _RPNPredFn(Function):
             if p_ is not None:
                 _sink_done(p_)
         return (dw[0], dw[1], dw[2], dw[3]) + tuple(dts)
+
+
+# ---- the whole RPN head as ONE autograd node whose backward pass touches the sampled anchors only ---------------------
+# rpn/rpn.py:34-41 under rpn/loss.py:88-126.  The RPN loss sums over the 256 anchors per image the sampler drew, so the
+# gradient that enters the head is EXACTLY zero at every other one of its 2 x 268 569 anchors: the dense backward of the
+# shared 3x3 conv (data + weight gradient over every pixel of P2..P6: ~1.4 ms of MFMA kernels per step) multiplies
+# zeros.  csrc/rpn_sparse.hip has the algebra: the sampled anchors become the <= images x 256 rows of small dense
+# matrices, the products run on this package's own weight- / data-gradient kernels, and the feature gradients are
+# scattered into the shared accumulators.  The loss announces its sample (set_rpn_sample: an index list built on the
+# device, no host round trip); without one -- another loss, a test feeding its own gradients, deterministic mode (the
+# scatter uses float atomics) -- backward() runs the dense formulation.
+_RPN_SPARSE = int(os.environ.get("CPM_RPN_SPARSE", "1"))
+_rpn_sample = None
+
+
+def set_rpn_sample(out_ptrs, idx, cap, n_img):
+    """the loss over the head outputs at `out_ptrs` (data_ptr of every level's objectness map) is a sum over the anchors
+    listed in idx (int32 [cap], ascending flat positions, -1 behind the last): what _RPNHeadFn.backward may rely on"""
+    global _rpn_sample
+    _rpn_sample = (tuple(out_ptrs), idx, int(cap), int(n_img))
+
+
+def _take_rpn_sample(out_ptrs):
+    global _rpn_sample
+    s, _rpn_sample = _rpn_sample, None
+    return s if (s is not None and s[0] == tuple(out_ptrs)) else None
+
+
+def mask_compact(pos, neg, cap):
+    """ascending positions of pos | neg (bool [T]) as int32 [cap] (-1 behind the last) + their number (int32 [1]), on the
+    device (cpm_mask_compact)"""
+    idx = torch.empty((cap,), dtype=torch.int32, device=pos.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=pos.device)
+    with H.guard(pos.device):
+        rc = H.lib().cpm_mask_compact(H.ptr(pos), H.ptr(neg), H.c_int64(pos.numel()), int(cap), H.ptr(idx), H.ptr(cnt),
+                                      H.stream())
+    H.check(rc, "mask_compact")
+    return idx, cnt
+
+
+def _krsc_matrix(t):
+    """a [K, C, R, S] weight (or gradient buffer) in KRSC memory as the [K, R*S*C, 1, 1] matrix it is (a view)"""
+    k, c, r, s = t.shape
+    v = t.permute(0, 2, 3, 1)
+    assert v.is_contiguous()
+    return v.reshape(k, r * s * c, 1, 1)
+
+
+class _RPNHeadFn(Function):
+    """(objectness_l, deltas_l for every level l) = RPNHead(features): shared 3x3 conv + ReLU, the two 1x1 predictors."""
+
+    @staticmethod
+    def forward(ctx, w, b, wc, bc, wb, bb, *feats):
+        H.require_gpu(w, b, wc, bc, wb, bb, *feats)
+        xs = [nhwc(f) for f in feats]
+        wm, wcm, wbm = _wmem(w), _wmem(wc), _wmem(wb)
+        c = xs[0].shape[1]
+        w4, w4c, w4b = w4_of(w, wm, c), w4_of(wc, wcm, c), w4_of(wb, wbm, c)
+        # the shared conv on the coarser levels runs on the second stream beside the finest level's (fwd_fork)
+        forked = len(xs) > 1 and fwd_fork(xs[0])
+        ts = []
+        for li, x in enumerate(xs):
+            if forked and li > 0:
+                with fwd_side(x):
+                    ts.append(conv2d_forward(x, wm, None, b, None, 0, True, 1, 1, 1, 1, w4=w4))
+            else:
+                ts.append(conv2d_forward(x, wm, None, b, None, 0, True, 1, 1, 1, 1, w4=w4))
+        if forked:
+            fwd_join(xs[0])
+        outs_c = [conv2d_forward(t, wcm, None, bc, None, 0, False, 1, 0, 1, 1, w4=w4c) for t in ts]
+        outs_b = [conv2d_forward(t, wbm, None, bb, None, 0, False, 1, 0, 1, 1, w4=w4b) for t in ts]
+        # parameters owned by the flat optimizer take their gradients in place (see _ConvFn.forward)
+        ctx.sinks = [_sink_of(p, ctx.needs_input_grad[i]) if (p.data_ptr() == m.data_ptr() and getattr(
+            p, "_cpm_grad_sink", None) is not None and p._cpm_grad_sink.stride() == p.stride()) else None
+            for i, (p, m) in enumerate(((w, wm), (b, b), (wc, wcm), (bc, bc), (wb, wbm), (bb, bb)))]
+        ctx.holders = [getattr(f, "_cpm_gacc", None) for f in feats]
+        ctx.n = len(xs)
+        ctx.out_ptrs = tuple(o.data_ptr() for o in outs_c)
+        ctx.save_for_backward(wm, wcm, wbm, *xs, *ts)
+        return tuple(outs_c + outs_b)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *grads):
+        n = ctx.n
+        wm, wcm, wbm = ctx.saved_tensors[:3]
+        xs, ts = ctx.saved_tensors[3:3 + n], ctx.saved_tensors[3 + n:3 + 2 * n]
+        a, c, k = wcm.shape[0], wcm.shape[1], wm.shape[0]
+        dev = xs[0].device
+        need = ctx.needs_input_grad
+
+        def zmap(x, ch):
+            return torch.zeros((x.shape[0], ch, x.shape[2], x.shape[3]), device=dev).contiguous(memory_format=CL)
+        dcs = [nhwc(g) if g is not None else zmap(x, a) for g, x in zip(grads[:n], xs)]
+        dbs = [nhwc(g) if g is not None else zmap(x, 4 * a) for g, x in zip(grads[n:], xs)]
+        # gradient buffers of the six parameters: the flat optimizer's slice (accumulated in place) or a fresh one
+        bufs, rets = [], []
+        for i, like in enumerate((wm, None, wcm, None, wbm, None)):
+            p = ctx.sinks[i]
+            if not need[i]:
+                bufs.append(None); rets.append(None)
+            elif p is not None:
+                bufs.append(p._cpm_grad_sink); rets.append(None)
+            else:
+                z = torch.zeros_like(like) if like is not None else torch.zeros((k, a, 4 * a)[i // 2], device=dev)
+                bufs.append(z); rets.append(z)
+        # gradient tensors of the feature maps: the shared accumulator when another consumer already made one
+        dfe, dret = [], []
+        for i, (x, h) in enumerate(zip(xs, ctx.holders)):
+            if not need[6 + i]:
+                dfe.append(None); dret.append(None)
+            elif h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(x.shape):
+                _wait_readers(h)
+                dfe.append(h["acc"]); dret.append(None)
+            else:
+                dfe.append(False); dret.append(None)        # made below (zero-filled / fresh), the two paths differ
+        sample = _take_rpn_sample(ctx.out_ptrs)
+        # (_RPN_SPARSE == 2: also under deterministic mode -- the tests compare the two formulations there, where
+        # everything else of a step is reproducible)
+        if sample is not None and _RPN_SPARSE and (_RPN_SPARSE == 2 or not H.deterministic()):
+            _RPNHeadFn._backward_sparse(ctx, sample, dcs, dbs, xs, ts, wm, wcm, wbm, bufs, dfe, dret)
+        else:
+            _RPNHeadFn._backward_dense(ctx, dcs, dbs, xs, ts, wm, wcm, wbm, bufs, dfe, dret)
+        for p_ in ctx.sinks:
+            if p_ is not None:
+                _sink_done(p_)
+        return tuple(rets) + tuple(dret)
+
+    @staticmethod
+    def _own(ctx, i, x, dfe, dret, zero):
+        """a gradient tensor of feature map i that this node makes itself (nobody accumulated into one yet)"""
+        t = torch.zeros_like(x) if zero else torch.empty_like(x)
+        h = ctx.holders[i]
+        if h is not None:
+            h["acc"] = t
+        dfe[i], dret[i] = t, t
+        return t
+
+    @staticmethod
+    def _backward_sparse(ctx, sample, dcs, dbs, xs, ts, wm, wcm, wbm, bufs, dfe, dret):
+        _, idx, cap, n_img = sample
+        n, dev = ctx.n, xs[0].device
+        a, c, k = wcm.shape[0], wcm.shape[1], wm.shape[0]
+        DT = torch.empty((cap, k), dtype=torch.float32, device=dev)
+        Gc = torch.empty((cap, a), dtype=torch.float32, device=dev)
+        Gb = torch.empty((cap, 4 * a), dtype=torch.float32, device=dev)
+        T = torch.empty((cap, c), dtype=torch.float32, device=dev)
+        X = torch.empty((cap, 9 * c), dtype=torch.float32, device=dev)
+        pix = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+        P_ = H.ctypes.c_void_p
+        arr = lambda ts_: (P_ * n)(*[t.data_ptr() if t is not None else None for t in ts_])
+        hs = (H.ctypes.c_int * n)(*[int(x.shape[2]) for x in xs])
+        ws = (H.ctypes.c_int * n)(*[int(x.shape[3]) for x in xs])
+        with H.guard(dev):
+            rc = H.lib().cpm_rpn_sparse_rows(H.ptr(idx), cap, n_img, n, hs, ws, int(a), int(c), arr(dcs), arr(dbs),
+                                             arr(ts), arr(xs), H.ptr(wcm), H.ptr(wbm), H.ptr(DT), H.ptr(Gc), H.ptr(Gb),
+                                             H.ptr(T), H.ptr(X), H.ptr(pix), H.stream())
+        H.check(rc, "rpn_sparse_rows")
+        img = lambda m: m.view(1, cap, 1, m.shape[1]).permute(0, 3, 1, 2)       # [1, channels, rows, 1], NHWC memory
+        # the 3x3 conv: dW = DT^T X (+ the bias sum), the predictors: dWcls = Gc^T T, dWbox = Gb^T T
+        for wi, (xm, gm, wlike) in enumerate(((X, DT, wm), (T, Gc, wcm), (T, Gb, wbm))):
+            dwb, dbb = bufs[2 * wi], bufs[2 * wi + 1]
+            if dwb is not None:
+                out = _krsc_matrix(dwb)
+                conv2d_backward_weight(img(xm), img(gm), out, 1, 0, 1, 1, out=out, dbias=dbb)
+            elif dbb is not None:
+                dbb += gm.sum(0)
+        # the feature maps: dX = DT W, scattered to the nine input pixels of every row
+        if any(d is not None for d in dfe):
+            for i, x in enumerate(xs):
+                if dfe[i] is False:
+                    _RPNHeadFn._own(ctx, i, x, dfe, dret, zero=True)
+            dX = conv2d_backward_data(img(DT), _krsc_matrix(wm), (1, 9 * c, cap, 1), 1, 0, 1, 1)
+            with H.guard(dev):
+                rc = H.lib().cpm_rpn_sparse_scatter(H.ptr(pix), cap, n, hs, ws, int(c), H.ptr(dX), arr(dfe), H.stream())
+            H.check(rc, "rpn_sparse_scatter")
+
+    @staticmethod
+    def _backward_dense(ctx, dcs, dbs, xs, ts, wm, wcm, wbm, bufs, dfe, dret):
+        """every pixel of every level (what autograd would do through the three convolutions)"""
+        n, dev = ctx.n, xs[0].device
+        a, c = wcm.shape[0], wcm.shape[1]
+        # predictors: weight / bias gradients per level, then their data gradient with the conv's ReLU gate
+        for wi, (wlike, dys) in enumerate(((wcm, dcs), (wbm, dbs))):
+            dwb, dbb = bufs[2 + 2 * wi], bufs[3 + 2 * wi]
+            for t, dy in zip(ts, dys):
+                if t.numel() == 0:
+                    continue
+                if dwb is not None:
+                    conv2d_backward_weight(t, dy, wlike, 1, 0, 1, 1, out=dwb, dbias=dbb)
+                elif dbb is not None:
+                    dbb += dy.sum(dim=(0, 2, 3))
+        dts = [torch.empty_like(t) for t in ts]
+        P_ = H.ctypes.c_void_p
+        arr = lambda ts_: (P_ * n)(*[t.data_ptr() for t in ts_])
+        pix = (H.ctypes.c_int64 * n)(*[t.shape[0] * t.shape[2] * t.shape[3] for t in ts])
+        with H.guard(dev):
+            rc = H.lib().cpm_rpn_pred_backward_data(arr(dcs), arr(dbs), arr(ts), arr(dts), pix, n, H.ptr(wcm),
+                                                    H.ptr(wbm), int(a), int(c), 1, H.stream())
+        H.check(rc, "rpn_pred_backward_data")
+        for i, (x, dt) in enumerate(zip(xs, dts)):
+            if x.numel() == 0:
+                continue
+            if bufs[0] is not None:
+                conv2d_backward_weight(x, dt, wm, 1, 1, 1, 1, out=bufs[0], dbias=bufs[1])
+            elif bufs[1] is not None:
+                bufs[1] += dt.sum(dim=(0, 2, 3))
+            if dfe[i] is None:
+                continue
+            if dfe[i] is False:
+                t = conv2d_backward_data(dt, wm, tuple(x.shape), 1, 1, 1, 1)
+                h = ctx.holders[i]
+                if h is not None:
+                    h["acc"] = t
+                dfe[i], dret[i] = t, t
+            else:
+                conv2d_backward_data(dt, wm, tuple(x.shape), 1, 1, 1, 1, accumulate_into=dfe[i])
+
+
+def rpn_head(feats, w, b, wc, bc, wb, bb):
+    """([objectness(f) for f in feats], [deltas(f) for f in feats]) of the RPN head as one autograd node (_RPNHeadFn) whose
+    backward pass is sparse under the RPN loss; None when the shapes are outside its kernels (the caller then goes conv
+    by conv)."""
+    c = wc.shape[1]
+    if (not _RPN_SPARSE or len(feats) < 1 or len(feats) > 8 or c % 4 or 256 % (c // 4) or 5 * wc.shape[0] * c * 4 > 65536
+            or wb.shape[0] != 4 * wc.shape[0] or tuple(wc.shape[2:]) != (1, 1) or tuple(wb.shape[2:]) != (1, 1)
+            or tuple(w.shape) != (c, c, 3, 3) or b is None or bc is None or bb is None
+            or any(t.dim() != 4 or t.shape[1] != c for t in feats) or not torch.is_grad_enabled()):
+        return None
+    outs = _RPNHeadFn.apply(w, b, wc, bc, wb, bb, *feats)
+    n = len(feats)
+    lo, br = list(outs[:n]), list(outs[n:])
+    for o in lo:
+        o._cpm_rpn_sparse = True        # the loss that sums over a sample of these anchors may say so (set_rpn_sample)
+    return lo, br
 
 
 _RPN_PRED_FUSED = os.environ.get("CPM_RPN_PRED_FUSED", "1") != "0"

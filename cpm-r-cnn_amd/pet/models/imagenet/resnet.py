@@ -44,6 +44,8 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         ops.mark_shared_grad(x)       # consumers: conv1, the downsample conv or conv3's residual -- all in-package
+        # the downsample conv reads x only: its kernel runs on the second stream beside conv1 -> conv2 (ops.fwd_fork)
+        forked = self.downsample is not None and ops.fwd_fork(x)
         s, b = _affine(self.bn1)
         out = self.conv1(x, scale=s, shift=b, relu=True, sole_consumer=True)       # consumed by conv2 only
         s, b = _affine(self.bn2)
@@ -51,7 +53,12 @@ class Bottleneck(nn.Module):
         residual = x
         if self.downsample is not None:
             s, b = _affine(self.downsample[1])
-            residual = self.downsample[0](x, scale=s, shift=b)
+            if forked:
+                with ops.fwd_side(x):
+                    residual = self.downsample[0](x, scale=s, shift=b)
+                ops.fwd_join(x)
+            else:
+                residual = self.downsample[0](x, scale=s, shift=b)
         s, b = _affine(self.bn3)
         return self.conv3(out, scale=s, shift=b, residual=residual, relu=True, gate_by_consumers=self.gate_out)
 

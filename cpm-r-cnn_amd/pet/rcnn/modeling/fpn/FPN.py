@@ -49,7 +49,19 @@ class fpn(nn.Module):
 
     def forward(self, x):
         px = ops.mark_shared_grad(self.p5_in(x[-1]))
-        outs = [self.p5_out(px)]
+        # a level's 3x3 output conv reads its own px only: it runs on the second stream beside the lateral chain of the
+        # finer levels (ops.fwd_fork); the finest level's -- the largest, and the last -- stays on the compute stream
+        n_lat = self.num_backbone_stages - 1
+        sided = False
+
+        def out_conv(conv, t, last):
+            nonlocal sided
+            if not last and ops.fwd_fork(t):
+                sided = True
+                with ops.fwd_side(t):
+                    return conv(t)
+            return conv(t)
+        outs = [out_conv(self.p5_out, px, n_lat == 0)]
         for i in range(self.num_backbone_stages - 1):
             c = x[-i - 2]
             if tuple(c.shape[2:]) != tuple(px.shape[2:]):
@@ -59,7 +71,9 @@ class fpn(nn.Module):
             else:
                 px = self.fpn_in[i](c, residual=px, res_mode=0)
             ops.mark_shared_grad(px)   # consumers: this level's output conv and the next lateral's top-down residual
-            outs.insert(0, self.fpn_out[i](px))
+            outs.insert(0, out_conv(self.fpn_out[i], px, i == n_lat - 1))
+        if sided:
+            ops.fwd_join(px)
         for o in outs:                 # consumers: RPN head conv, the RoIAlign calls (and P6's subsample, created first)
             ops.mark_shared_grad(o)
         if self.has_p6:

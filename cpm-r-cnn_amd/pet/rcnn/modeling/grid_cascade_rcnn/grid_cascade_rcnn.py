@@ -228,8 +228,17 @@ class GridCascadeRCNN(nn.Module):
                                                     M.FG_IOU_THRESHOLD[0])
             self._count_reads[0].start(counts_all)
         # ---- cls head on the sample's capacity, queued before the host waits for the counts -----------------
-        ev.set_packed_sample(None, sample.labels)
-        loss = dict(loss_classifier=ev([_head_logits(self.Head_cls, self.Output_cls, features, _capacity_rows(sample))]))
+        # Its kernels (RoIAlign: HBM-bound; fc6 / fc7: 128-tile GEMMs) go to the second stream, beside the first grid
+        # stage's convolutions on ~100 RoIs (ops.fwd_fork); the loss -- framework ops, which follow torch's current
+        # stream -- is formed behind the join at the end.  The RSM head does the same beside the last grid stage.
+        loss = {}
+        cls_forked = ops.fwd_fork(features[0])
+        if cls_forked:
+            with ops.fwd_side(features[0]):
+                cls_logits = _head_logits(self.Head_cls, self.Output_cls, features, _capacity_rows(sample))
+        else:
+            ev.set_packed_sample(None, sample.labels)
+            loss["loss_classifier"] = ev([_head_logits(self.Head_cls, self.Output_cls, features, _capacity_rows(sample))])
         c = self._count_reads[0].wait()                               # host round trip 1 of 3
         if c[-1]:
             raise RuntimeError("an image holds more than %d proposals; set CPM_DEVICE_LISTS=0" % RL.roi_sample_max_rows())
@@ -240,9 +249,13 @@ class GridCascadeRCNN(nn.Module):
         # ---- CMM cascade ---------------------------------------------------------------------------------
         cur, R0 = pos, pos.total
         x = None
+        rsm = None
         for s in range(self.stage_num):
             gev = self.grid_loss_evaluators[s]
             last = s == self.stage_num - 1
+            if last and G.RESCORE_ON:
+                # the RSM sample needs the boxes this last stage STARTS from: its head runs beside the stage
+                rsm = self._rsm_head(features, sample, pos, cur, R0, S, gt_all, gt_labels, gt_off, seeds[2], sizes)
             R = cur.total
             self._last_counts["grid_%d" % s] = R
             rois = cur.boxes[:R]
@@ -268,9 +281,24 @@ class GridCascadeRCNN(nn.Module):
                 self._count_reads[1 + s].start(nxt.counts)
                 nxt.host_counts = self._count_reads[1 + s].wait()     # the stage's one host round trip
                 cur = nxt
+        if cls_forked or (rsm is not None and rsm[3]):
+            ops.fwd_join(features[0])                                 # the compute stream has the heads' logits now
+        if cls_forked:
+            ev.set_packed_sample(None, sample.labels)
+            loss["loss_classifier"] = ev([cls_logits])
+            ev.set_packed_sample(_RowsNow(sample, sizes, (("objectness", "obj"), ("labels", "labels"))), sample.labels)
         if not G.RESCORE_ON:
             return x, _views(cur, sizes), loss
-        # ---- RSM, again on the sample's capacity: its count is read back lazily -----------------------------
+        result, rs, logits, _ = rsm
+        rev = self.rescore_loss_evaluator
+        rev.set_packed_sample(result, rs.labels)
+        loss["loss_rescore"] = rev([logits]) * G.RESCORE_LOSS_WEIGHT
+        return x, result, loss
+
+    def _rsm_head(self, features, sample, pos, cur, R0, S, gt_all, gt_labels, gt_off, seed, sizes):
+        """RSM on the sample's capacity (its count is read back lazily): candidates = the cls sample's negatives + the
+        boxes the last stage starts from, one sampling launch, then the head -- on the second stream when there is one.
+        Returns (lazy views, the sampled list, logits, forked)."""
         rev = self.rescore_loss_evaluator
         m, sp = rev.proposal_matcher, rev.fg_bg_sampler
         with torch.no_grad():
@@ -278,14 +306,17 @@ class GridCascadeRCNN(nn.Module):
                 cur.src = torch.arange(R0, device=cur.boxes.device)
             cand = RL.rescore_gather(sample, cur, pos.src, R0, S + cur.total)
             rs, _, counts_all = RL.roi_sample(cand, gt_all, gt_labels, gt_off, m.high_threshold, m.low_threshold,
-                                              sp.batch_size_per_image, sp.positive_fraction, seeds[2])
+                                              sp.batch_size_per_image, sp.positive_fraction, seed)
             self._count_reads[-1].start(counts_all)
         result = _LazyViews(self, rs, sizes)
         self._pending = result
-        rev.set_packed_sample(result, rs.labels)
-        logits = _head_logits(self.Head_rescore, self.Output_rescore, features, _capacity_rows(rs))
-        loss["loss_rescore"] = rev([logits]) * G.RESCORE_LOSS_WEIGHT
-        return x, result, loss
+        forked = ops.fwd_fork(features[0])
+        if forked:
+            with ops.fwd_side(features[0]):
+                logits = _head_logits(self.Head_rescore, self.Output_rescore, features, _capacity_rows(rs))
+        else:
+            logits = _head_logits(self.Head_rescore, self.Output_rescore, features, _capacity_rows(rs))
+        return result, rs, logits, forked
 
     def _resolve_pending(self):
         """read the RSM sample's counts of the previous step (and its status) if nobody asked for them yet"""

@@ -22,10 +22,27 @@ class RPNHead(nn.Module):
             nn.init.normal_(l.weight, std=0.01)
             nn.init.constant_(l.bias, 0)
 
-    def forward(self, x):
+    def forward(self, x, sparse_backward=False):
+        # sparse_backward: the caller's loss is a sum over a SAMPLE of the anchors and announces it (RPNLossComputation
+        # -> ops.set_rpn_sample): the whole head is one node whose backward pass touches those anchors only
+        if sparse_backward:
+            out = ops.rpn_head(list(x), self.conv.weight, self.conv.bias, self.cls_logits.weight, self.cls_logits.bias,
+                               self.bbox_pred.weight, self.bbox_pred.bias)
+            if out is not None:
+                return out
         # both predictors on every level as one autograd node: their data gradients (reductions of 3 and 12, two passes
         # over each level's map) become one launch that also applies this conv's ReLU gate (ops.conv._RPNPredFn)
-        ts = [self.conv(feature, relu=True, gate_by_consumers=True) for feature in x]
+        # the shared conv on the coarser levels runs on the second stream beside the finest level's (ops.fwd_fork)
+        ts = []
+        forked = len(x) > 1 and ops.fwd_fork(x[0])
+        for li, feature in enumerate(x):
+            if forked and li > 0:
+                with ops.fwd_side(feature):
+                    ts.append(self.conv(feature, relu=True, gate_by_consumers=True))
+            else:
+                ts.append(self.conv(feature, relu=True, gate_by_consumers=True))
+        if forked:
+            ops.fwd_join(x[0])
         fused = ops.rpn_predictors(ts, self.cls_logits.weight, self.cls_logits.bias, self.bbox_pred.weight,
                                    self.bbox_pred.bias) if ts else None
         if fused is not None:
@@ -51,7 +68,10 @@ class RPNModule(nn.Module):
     def forward(self, images, features, targets=None, head_out=None):
         """head_out: (objectness, box deltas) already computed by the caller -- the statically captured part of the step
         (Generalized_RCNN.capture_static_part) ends behind the head's convolutions."""
-        objectness, rpn_box_regression = self.head(features) if head_out is None else head_out
+        # (training under the fused loss: that loss registers its anchor sample, see RPNHead.forward)
+        sparse = (self.training and head_out is None and not cfg.MODEL.RPN_ONLY
+                  and getattr(self.loss_evaluator, "fused_glue", False))
+        objectness, rpn_box_regression = self.head(features, sparse_backward=sparse) if head_out is None else head_out
         anchors = self.anchor_generator(images, features)
         if self.training:
             return self._forward_train(anchors, objectness, rpn_box_regression, targets)

@@ -248,6 +248,27 @@ int cpm_im2col(const float* x, int layout, int N, int C, int H, int W, int R, in
 int cpm_rpn_pred_backward_data(const float* const* dy_cls, const float* const* dy_box, const float* const* t,
                                float* const* dx, const int64_t* pixels, int n_levels, const float* w_cls,
                                const float* w_box, int A, int C, int gate, void* stream);
+/* Sparse backward of the RPN head (rpn/rpn.py:34-41) under its loss (rpn/loss.py:88-126): that loss sums over the
+ * SAMPLED anchors only (balanced_positive_negative_sampler.py:27-67: 256 per image), so the gradient entering the head
+ * is zero at every other anchor and the head's backward pass reduces to <= images x 256 rows of small dense matrices
+ * (csrc/rpn_sparse.hip has the algebra).  Three pieces; the matrix products in between are cpm_conv2d_backward_weight*
+ * / cpm_conv2d_backward_data on [1, C, rows, 1] "images":
+ *   cpm_mask_compact: pos | neg (bool [total]) -> ascending positions, idx int32 [cap] (-1 behind the last), count [1];
+ *   cpm_rpn_sparse_rows: per listed anchor (flat index n * per_image + level offset + (h * W + w) * A + a, the order of
+ *     concat_box_prediction_layers, rcnn/utils/misc.py:17-26): DT [cap][C] (gradient at the 3x3 conv's output, ReLU
+ *     gate applied), Gc [cap][A] / Gb [cap][4A] (the predictors' output gradients), T [cap][C] (their input), X
+ *     [cap][9C] (the 3x3 conv's input patch, tap-major = the KRSC weight's column order), pix4 int32 [cap][4] = (level,
+ *     image, h, w) or level -1; dlog / dbox / t / feat: per-level NHWC maps [N][H_l][W_l][A | 4A | C | C];
+ *   cpm_rpn_sparse_scatter: dfeat_l[n][h + dr][w + ds][:] += dX[row][(tap, :)] (float atomics; a NULL level is skipped).
+ * Replaces, for those layers, the dense autograd path the reference takes through nn.Conv2d. */
+int cpm_mask_compact(const uint8_t* pos, const uint8_t* neg, int64_t total, int cap, int32_t* idx, int32_t* count,
+                     void* stream);
+int cpm_rpn_sparse_rows(const int32_t* idx, int cap, int n_img, int n_levels, const int* hs, const int* ws, int A, int C,
+                        const float* const* dlog, const float* const* dbox, const float* const* t,
+                        const float* const* feat, const float* w_cls, const float* w_box, float* DT, float* Gc, float* Gb,
+                        float* T, float* X, int32_t* pix4, void* stream);
+int cpm_rpn_sparse_scatter(const int32_t* pix4, int cap, int n_levels, const int* hs, const int* ws, int C,
+                           const float* dX, float* const* dfeat, void* stream);
 /* The ResNet / ResNeXt stem as one kernel (bf16x3 arithmetic only): y = relu?(conv7x7 / stride 2 / pad 3 (x) * scale +
  * shift), x NHWC [N][H][W][3], w KRSC [64][7][7][3], y NHWC [N][P][Q][64] -- no column image (pet/models/imagenet/
  * resnet.py:175-181: conv1 + frozen bn1 + relu; the max-pool follows as cpm_maxpool3x3s2_forward). */

@@ -534,3 +534,66 @@ def test_dgrad_weight_images_follow_the_optimizer():
         assert torch.isfinite(loss) and _prepared_wt(p0, *p0._cpm_wt_desc[:4], sc0) is p0._cpm_wt
     finally:
         config.reset_cfg()
+
+
+@pytest.fixture()
+def fresh_model():
+    """a model of its own (the module-scoped one may carry a flat optimizer's gradient sinks from an earlier test)"""
+    from detfill import det_fill_
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.model_builder import Generalized_RCNN
+    from pet.utils.net import convert_bn2affine_model
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS)
+    m = convert_bn2affine_model(Generalized_RCNN(is_train=True))
+    det_fill_(m)
+    yield m.cuda().to(memory_format=CL)
+    config.reset_cfg()
+
+
+def test_second_forward_stream_changes_nothing_but_the_schedule(fresh_model, golden_model, deterministic_reductions):
+    """independent forward branches (a stage's downsample conv, the FPN's output convs above the
+    finest level, the RPN's shared conv on P3..P6) are queued on the second stream (ops.fwd_fork / fwd_side / fwd_join).
+    Only the schedule may change: features, RPN outputs, and -- in deterministic mode -- every gradient are BIT-identical
+    with the switch on and off."""
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as C
+    model = fresh_model
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    model.train()
+    x = torch.from_numpy(golden_model["m_img"]).cuda()
+    x = torch.cat([x, x.flip(3)], 0)
+    go = None
+
+    def run(on):
+        nonlocal go
+        C._FWD_SIDE = on
+        model.zero_grad(set_to_none=True)
+        p = model.Conv_Body_FPN(model.Conv_Body(x))
+        lo, br = model.RPN.head(p)
+        outs = list(p) + list(lo) + list(br)
+        if go is None:
+            g = torch.Generator(device="cpu").manual_seed(3)
+            go = [torch.randn(o.shape, generator=g).cuda().contiguous(memory_format=CL) if o.dim() == 4
+                  else torch.randn(o.shape, generator=g).cuda() for o in outs]
+        torch.autograd.backward(outs, go)
+        torch.cuda.synchronize()
+        grads = {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.grad is not None}
+        return [o.detach().clone() for o in outs], grads
+    try:
+        o0, g0 = run(False)
+        o1, g1 = run(True)
+        o2, g2 = run(True)
+    finally:
+        C._FWD_SIDE = True
+        _hip.set_conv_math(prev)
+    assert len(g0) > 50 and set(g0) == set(g1)
+    for a, b, c in zip(o0, o1, o2):
+        assert torch.equal(a, b) and torch.equal(b, c)
+    for k in g0:
+        if g0[k].dim() >= 2:
+            assert torch.equal(g0[k], g1[k]), k
+            assert torch.equal(g1[k], g2[k]), k
+        else:       # bias sums end in one float atomic per (workgroup, channel) also in deterministic mode: order noise
+            torch.testing.assert_close(g0[k], g1[k], rtol=1e-5, atol=1e-5 * float(g0[k].abs().max()))
