@@ -65,6 +65,8 @@ def main():
                     "+ ReLU (bottleneck conv3), data gradient accumulating into an existing tensor")
     ap.add_argument("--math", default="f32", choices=["f32", "bf16x3", "w4"],
                     help="w4 = bf16x3 with the forward weight given as its pre-split image (cpm_split_w4)")
+    ap.add_argument("--only", default="", choices=["", "fwd", "dgrad", "wgrad"], help="run one direction only (per-"
+                    "direction counter passes: tools/pmc_traffic.sh)")
     a = ap.parse_args()
     from pet.lib.ops import _hip
     use_w4 = a.math == "w4"
@@ -95,7 +97,7 @@ def main():
         if use_w4:
             w4 = ops.split_w4(w)
             fwd = lambda: ops.conv2d_forward(x, w, None, None, None, 0, False, st, pad, 1, g, w4=w4)
-        if a.math != "f32" and a.epi == "plain":
+        if a.math != "f32" and a.epi == "plain" and not a.only:
             y1 = fwd()
             d1 = dgr()
             _hip.set_conv_math("f32")
@@ -104,9 +106,9 @@ def main():
             _hip.set_conv_math(a.math)
             err = "  err fwd %.1e dgrad %.1e" % (float((y1 - y0).abs().max() / y0.abs().max()),
                                                float((d1 - d0).abs().max() / d0.abs().max()))
-        t_f = timeit(fwd, a.iters)
-        t_d = timeit(dgr, a.iters)
-        t_w = timeit(lambda: ops.conv2d_backward_weight(x, dy, w, st, pad, 1, g, out=dw), a.iters)
+        t_f = timeit(fwd, a.iters) if a.only in ("", "fwd") else 1e9
+        t_d = timeit(dgr, a.iters) if a.only in ("", "dgrad") else 1e9
+        t_w = timeit(lambda: ops.conv2d_backward_weight(x, dy, w, st, pad, 1, g, out=dw), a.iters) if a.only in ("", "wgrad") else 1e9
         print("%-20s %9.1f | %8.1f %7.1f | %8.1f %7.1f | %8.1f %7.1f" % (
             name, gf, t_f * 1e3, gf / t_f, t_d * 1e3, gf / t_d, t_w * 1e3, gf / t_w) + err)
         for k, t in (("fwd", t_f), ("dgrad", t_d), ("wgrad", t_w)):
