@@ -526,6 +526,32 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el_other = float(t.item())
         _hip.set_conv_math(a.conv_math)
+    # the same step with the RPN head differentiated densely (every pixel of P2..P6, the autograd default) instead of
+    # over the sampled anchors only: same gradients (tests/test_gpu_rpn_sparse.py), reported beside for transparency
+    dense_rpn = None
+    if not a.no_other_math:
+        from pet.lib.ops import conv as conv_ops
+        keep = conv_ops._RPN_SPARSE
+        conv_ops._RPN_SPARSE = 0
+        k_d = max(1, min(a.steps, 8))
+        for _ in range(2):
+            trainer.step(images, targets)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(k_d):
+            trainer.step(images, targets)
+        sync()
+        el_d = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([el_d], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el_d = float(t.item())
+        conv_ops._RPN_SPARSE = keep
+        dense_rpn = {"img_per_s": round(a.batch * world * k_d / el_d, 3), "ms_per_step": round(1000.0 * el_d / k_d, 2),
+                     "steps": k_d}
+        for _ in range(2):
+            trainer.step(images, targets)
+        sync()
     chunk_sweep = None
     if world > 1 and len(chunk_list) > 1:
         # the same step with the flat gradient cut into other numbers of all-reduce pieces (all ranks: collective)
@@ -659,6 +685,11 @@ def main():
                        "other_conv_math": None if not k_other else {
                            "mode": other, "img_per_s": round(a.batch * world * k_other / el_other, 3),
                            "ms_per_step": round(1000.0 * el_other / k_other, 2), "steps": k_other},
+                       "rpn_head_backward": "over the anchors the RPN loss sampled (256 per image): its gradient is exactly "
+                                            "zero at every other anchor, so the head's dense data / weight gradients "
+                                            "over P2..P6 multiply zeros (csrc/rpn_sparse.hip; same gradients: "
+                                            "tests/test_gpu_rpn_sparse.py; CPM_RPN_SPARSE=0 = dense)",
+                       **({"dense_rpn_head_backward": dense_rpn} if dense_rpn else {}),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        **({"host_input": host_input} if host_input else {}),
                        **({"full_rois": full_rois} if full_rois else {}),
