@@ -729,9 +729,10 @@ def mask_compact(pos, neg, cap):
     device (cpm_mask_compact)"""
     idx = torch.empty((cap,), dtype=torch.int32, device=pos.device)
     cnt = torch.empty((1,), dtype=torch.int32, device=pos.device)
+    ws = torch.empty((pos.numel() // 4096 + 1,), dtype=torch.int32, device=pos.device)
     with H.guard(pos.device):
         rc = H.lib().cpm_mask_compact(H.ptr(pos), H.ptr(neg), H.c_int64(pos.numel()), int(cap), H.ptr(idx), H.ptr(cnt),
-                                      H.stream())
+                                      H.ptr(ws), H.stream())
     H.check(rc, "mask_compact")
     return idx, cnt
 

@@ -265,9 +265,11 @@ class GridCascadeRCNN(nn.Module):
             ratio = M.STAGE_MAPPING_RATIO[s]
             loss_grid = ops.grid_bce_loss(logits, rois, cur.gt[:R], gev.whole_map_size, gev.sub_regions, ratio,
                                           gev.pos_radius, gev.loss_weight)
-            loss["loss_grid_%d" % (s + 1)] = loss_grid * self.stage_loss_weight[s]
+            # (a weight of exactly 1 is not multiplied: one elementwise kernel forward, one backward and an autograd node
+            # each, queued where the device waits for the host -- the start of the backward pass)
+            loss["loss_grid_%d" % (s + 1)] = _scaled(loss_grid, self.stage_loss_weight[s])
             if G.IOU_HELPER and last:
-                loss["loss_iou_%d" % (s + 1)] = ops.l2_loss_fused(iou_logits, iou=cur.iou[:R]) * G.IOU_LOSS_WEIGHT
+                loss["loss_iou_%d" % (s + 1)] = _scaled(ops.l2_loss_fused(iou_logits, iou=cur.iou[:R]), G.IOU_LOSS_WEIGHT)
             if last:
                 break
             with torch.no_grad():
@@ -292,7 +294,7 @@ class GridCascadeRCNN(nn.Module):
         result, rs, logits, _ = rsm
         rev = self.rescore_loss_evaluator
         rev.set_packed_sample(result, rs.labels)
-        loss["loss_rescore"] = rev([logits]) * G.RESCORE_LOSS_WEIGHT
+        loss["loss_rescore"] = _scaled(rev([logits]), G.RESCORE_LOSS_WEIGHT)
         return x, result, loss
 
     def _rsm_head(self, features, sample, pos, cur, R0, S, gt_all, gt_labels, gt_off, seed, sizes):
@@ -356,6 +358,10 @@ class GridCascadeRCNN(nn.Module):
     def _forward_test_rescore(self, features, proposals):
         logits = self.Output_rescore(self.Head_rescore(features, proposals))
         return self.cls_post_processor(logits, proposals, rescore=True)
+
+
+def _scaled(loss, weight):
+    return loss if float(weight) == 1.0 else loss * weight
 
 
 def _head_logits(head, output, features, rows):

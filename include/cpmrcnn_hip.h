@@ -254,6 +254,7 @@ int cpm_rpn_pred_backward_data(const float* const* dy_cls, const float* const* d
  * (csrc/rpn_sparse.hip has the algebra).  Three pieces; the matrix products in between are cpm_conv2d_backward_weight*
  * / cpm_conv2d_backward_data on [1, C, rows, 1] "images":
  *   cpm_mask_compact: pos | neg (bool [total]) -> ascending positions, idx int32 [cap] (-1 behind the last), count [1];
+ *     workspace: ceil(total / 4096) int32 of device scratch (per-block counts);
  *   cpm_rpn_sparse_rows: per listed anchor (flat index n * per_image + level offset + (h * W + w) * A + a, the order of
  *     concat_box_prediction_layers, rcnn/utils/misc.py:17-26): DT [cap][C] (gradient at the 3x3 conv's output, ReLU
  *     gate applied), Gc [cap][A] / Gb [cap][4A] (the predictors' output gradients), T [cap][C] (their input), X
@@ -262,7 +263,7 @@ int cpm_rpn_pred_backward_data(const float* const* dy_cls, const float* const* d
  *   cpm_rpn_sparse_scatter: dfeat_l[n][h + dr][w + ds][:] += dX[row][(tap, :)] (float atomics; a NULL level is skipped).
  * Replaces, for those layers, the dense autograd path the reference takes through nn.Conv2d. */
 int cpm_mask_compact(const uint8_t* pos, const uint8_t* neg, int64_t total, int cap, int32_t* idx, int32_t* count,
-                     void* stream);
+                     int32_t* workspace, void* stream);
 int cpm_rpn_sparse_rows(const int32_t* idx, int cap, int n_img, int n_levels, const int* hs, const int* ws, int A, int C,
                         const float* const* dlog, const float* const* dbox, const float* const* t,
                         const float* const* feat, const float* w_cls, const float* w_box, float* DT, float* Gc, float* Gb,
