@@ -11,6 +11,11 @@ from pet.rcnn.modeling.rpn.loss import make_rpn_loss_evaluator
 from pet.rcnn.utils.box_coder import BoxCoder
 
 
+import os
+
+_LOSS_ON_SIDE = os.environ.get("CPM_RPN_LOSS_SIDE", "1") != "0"
+
+
 class RPNHead(nn.Module):
     def __init__(self, dim_in, num_anchors):
         super().__init__()
@@ -85,11 +90,28 @@ class RPNModule(nn.Module):
             # proposals up to the NMS, then the (host-sync-free) loss kernels, then the rest of the selection: the
             # loss runs on the device while the host waits for the NMS counts and builds the proposal lists
             on_device = sel.can_keep_on_device(objectness, targets) and getattr(self, "roi_heads_take_lists", False)
+            # The proposal chain (sigmoid, top-k, decode, NMS, finalize: ~0.5 ms of one-to-ten-workgroup kernels) and the
+            # loss chain (anchor matching over 2 x 268 569 anchors, labels, sampler, loss + gradients, sample list:
+            # ~0.2 ms) both start from the head's outputs and meet nowhere in the forward pass: with the proposals kept
+            # on the device the loss chain runs on the second stream beside them.  A real torch stream here (the chain
+            # mixes package and framework ops): its autograd nodes belong to that stream, the engine orders their
+            # backward against the compute stream by itself.
+            side = ops.conv.wgrad_stream(objectness[0].device) if (on_device and _LOSS_ON_SIDE
+                                                                    and ops.conv._FWD_SIDE) else None
+            if side is not None:
+                main = torch.cuda.current_stream(objectness[0].device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression,
+                                                                            targets)
             with torch.no_grad():
                 pending = sel.start_fused(anchors, objectness, rpn_box_regression, read_counts=not on_device)
                 if on_device:
                     boxes = sel.finish_device(pending, targets)         # a packed RoIList; nothing is read back
-            loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+            if side is None:
+                loss_objectness, loss_rpn_box_reg = self.loss_evaluator(anchors, objectness, rpn_box_regression, targets)
+            else:
+                main.wait_stream(side)        # (cheap: the chain is long finished; keeps every later consumer simple)
             if not on_device:
                 with torch.no_grad():
                     boxes = sel.finish_fused(pending, targets)
