@@ -379,7 +379,16 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__
                                                        const bool* __restrict__ pos, const bool* __restrict__ neg,
                                                        int64_t total, int per_image, float wx, float wy, float ww,
                                                        float wh, float beta, float* __restrict__ sums,
-                                                       float* __restrict__ dlogits, float4* __restrict__ dreg) {
+                                                       float* __restrict__ dlogits, float4* __restrict__ dreg,
+                                                       const int* __restrict__ quota, int n_quota) {
+  // quota (or null): the sampler's per-image (positives, negatives) counts -- both sums and both gradients leave the
+  // kernel divided by their total, the loss's normalisation (rpn/loss.py:121-126), instead of by framework ops
+  float inv = 1.f;
+  if (quota) {
+    int n = 0;
+    for (int i = 0; i < n_quota; ++i) n += quota[i];
+    inv = 1.f / (float)n;
+  }
   float obj = 0.f, box = 0.f;
   for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const bool p = pos[t], n = neg[t];
@@ -411,8 +420,8 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__
       }
       dr = make_float4(d[0], d[1], d[2], d[3]);
     }
-    dlogits[t] = dl;
-    dreg[t] = dr;
+    dlogits[t] = dl * inv;
+    dreg[t] = make_float4(dr.x * inv, dr.y * inv, dr.z * inv, dr.w * inv);
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { obj += __shfl_xor(obj, d, 64); box += __shfl_xor(box, d, 64); }
@@ -421,8 +430,8 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) { s_o[wave] = obj; s_b[wave] = box; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], s_o[0] + s_o[1] + s_o[2] + s_o[3]);
-    atomicAdd(&sums[1], s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+    atomicAdd(&sums[0], (s_o[0] + s_o[1] + s_o[2] + s_o[3]) * inv);
+    atomicAdd(&sums[1], (s_b[0] + s_b[1] + s_b[2] + s_b[3]) * inv);
   }
 }
 
@@ -485,7 +494,7 @@ CPM_EXPORT int cpm_grid_decode(const float* logits, const int64_t* strides, cons
 CPM_EXPORT int cpm_rpn_loss(const float* logits, const float* reg, const float* anchors, const int64_t* matched,
                             const float* gts, const int* gt_off, const uint8_t* pos, const uint8_t* neg, int64_t total,
                             int per_image, const float* weights4, float beta, float* sums2, float* dlogits, float* dreg,
-                            void* stream) {
+                            const int32_t* quota, int n_quota, void* stream) {
   CPM_REQUIRE(total >= 0 && per_image > 0 && total % per_image == 0, "bad sizes");
   CPM_REQUIRE(sums2 && weights4, "null pointer");
   hipStream_t s = (hipStream_t)stream;
@@ -499,7 +508,7 @@ CPM_EXPORT int cpm_rpn_loss(const float* logits, const float* reg, const float* 
   hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)b), dim3(256), 0, s, logits, (const float4*)reg,
                      (const float4*)anchors, matched, (const float4*)gts, gt_off, (const bool*)pos, (const bool*)neg,
                      total, per_image, weights4[0], weights4[1], weights4[2], weights4[3], beta, sums2, dlogits,
-                     (float4*)dreg);
+                     (float4*)dreg, quota, quota ? n_quota : 0);
   return cpm::check_launch("rpn_loss");
 }
 

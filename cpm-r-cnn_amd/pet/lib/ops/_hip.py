@@ -103,6 +103,27 @@ def deterministic():
     return _deterministic
 
 
+_UNIT_SEEDS = {}
+
+
+def unit_seed(device):
+    """THE scalar 1 of this device: pet.utils.parallel.backward_losses seeds every loss term with it (no ones_like per
+    term), and a loss node that receives it as its upstream gradient returns its stored gradient as is (scaled_by)."""
+    one = _UNIT_SEEDS.get(device)
+    if one is None:
+        one = _UNIT_SEEDS[device] = torch.ones((), dtype=torch.float32, device=device)
+    return one
+
+
+def scaled_by(grad, g):
+    """grad * g -- without the elementwise kernel when g IS the unit seed (a sum of several upstream gradients, or a
+    weighted one, is a different tensor and is multiplied)."""
+    one = _UNIT_SEEDS.get(g.device)
+    if one is not None and g.dim() == 0 and g.data_ptr() == one.data_ptr():
+        return grad
+    return grad * g
+
+
 def check(rc, what):
     if rc != 0:
         raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().cpm_last_error().decode()))

@@ -79,7 +79,7 @@ class _GridBCEFn(Function):
     @once_differentiable
     def backward(ctx, g):
         grad, = ctx.saved_tensors
-        return grad * g, None, None, None, None, None, None, None
+        return H.scaled_by(grad, g), None, None, None, None, None, None, None
 
 
 def grid_bce_loss(logits, rois, gt_boxes, map_size, sub_regions, mapping_ratio, radius, weight=1.0):
@@ -245,7 +245,7 @@ class _RPNLossFn(torch.autograd.Function):
     """(sum of BCE terms, sum of smooth-L1 terms) over the sampled anchors, gradients produced by the same launch."""
 
     @staticmethod
-    def forward(ctx, logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta):
+    def forward(ctx, logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta, quota):
         H.require_gpu(logits, reg, anchors, gts)
         total = logits.numel()
         logits_c = logits.contiguous()
@@ -258,7 +258,9 @@ class _RPNLossFn(torch.autograd.Function):
             rc = H.lib().cpm_rpn_loss(H.ptr(logits_c), H.ptr(reg_c), H.ptr(_boxes(anchors)), H.ptr(matched.contiguous()),
                                       H.ptr(_boxes(gts)), H.ptr(gt_off.contiguous()), H.ptr(pos.contiguous()),
                                       H.ptr(neg.contiguous()), H.c_int64(total), int(per_image), w4, H.f(beta),
-                                      H.ptr(sums), H.ptr(dlog), H.ptr(dreg), H.stream())
+                                      H.ptr(sums), H.ptr(dlog), H.ptr(dreg),
+                                      H.ptr(quota) if quota is not None else None,
+                                      quota.numel() if quota is not None else 0, H.stream())
         H.check(rc, "rpn_loss")
         ctx.save_for_backward(dlog, dreg)
         ctx.shapes = (logits.shape, reg.shape)
@@ -268,15 +270,21 @@ class _RPNLossFn(torch.autograd.Function):
     def backward(ctx, g_obj, g_box):
         dlog, dreg = ctx.saved_tensors
         ls, rs = ctx.shapes
-        return ((dlog * g_obj).view(ls), (dreg * g_box).view(rs), None, None, None, None, None, None, None, None, None)
+        return (H.scaled_by(dlog, g_obj).view(ls), H.scaled_by(dreg, g_box).view(rs), None, None, None, None, None, None,
+                None, None, None, None)
 
 
-def rpn_loss(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta):
+def rpn_loss(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta, quota=None):
     """logits [T], reg [T,4], anchors [T,4], matched int64 [T], gts [G,4], gt_off int32 [images+1], pos / neg bool [T].
-    Returns the two UNDIVIDED sums (BCE over pos|neg, smooth-L1 over pos), differentiable w.r.t. logits and reg."""
+    Returns the two sums (BCE over pos|neg, smooth-L1 over pos), differentiable w.r.t. logits and reg: UNDIVIDED without
+    `quota`; with the sampler's quota ([images, 2] int32, device) divided by its total inside the kernel -- the two losses
+    of loss.py:121-126 as they are."""
     if matched.dtype != torch.int64 or pos.dtype != torch.bool or neg.dtype != torch.bool or gt_off.dtype != torch.int32:
         raise RuntimeError("rpn_loss: matched int64, gt_off int32, pos / neg bool")
-    return _RPNLossFn.apply(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta)
+    if quota is not None:
+        if quota.dtype != torch.int32 or not quota.is_contiguous() or quota.device != logits.device:
+            raise RuntimeError("rpn_loss: quota int32, contiguous, on the logits' device")
+    return _RPNLossFn.apply(logits, reg, anchors, matched, gts, gt_off, pos, neg, per_image, weights, beta, quota)
 
 
 _SAMPLE_WS = {}

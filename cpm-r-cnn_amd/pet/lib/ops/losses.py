@@ -56,7 +56,8 @@ class _L2PairsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         grad, = ctx.saved_tensors
-        return grad * g, None, None
+        from . import _hip as H
+        return H.scaled_by(grad, g), None, None
 
 
 def l2_loss_fused(x, target=None, iou=None):

@@ -263,11 +263,12 @@ class GridCascadeRCNN(nn.Module):
             grid_logits, iou_logits = getattr(self, "Output_grid_%d" % s)(x, None)
             logits = grid_logits["unfused"]
             ratio = M.STAGE_MAPPING_RATIO[s]
-            loss_grid = ops.grid_bce_loss(logits, rois, cur.gt[:R], gev.whole_map_size, gev.sub_regions, ratio,
-                                          gev.pos_radius, gev.loss_weight)
-            # (a weight of exactly 1 is not multiplied: one elementwise kernel forward, one backward and an autograd node
-            # each, queued where the device waits for the host -- the start of the backward pass)
-            loss["loss_grid_%d" % (s + 1)] = _scaled(loss_grid, self.stage_loss_weight[s])
+            # the stage's weight rides on the loss kernel's own weight (value and gradient leave it scaled): no
+            # elementwise kernel forward, none backward, no autograd node -- all of them queued where the device waits
+            # for the host, the start of the backward pass.  (A weight of exactly 1 elsewhere is not multiplied either.)
+            loss["loss_grid_%d" % (s + 1)] = ops.grid_bce_loss(logits, rois, cur.gt[:R], gev.whole_map_size,
+                                                              gev.sub_regions, ratio, gev.pos_radius,
+                                                              gev.loss_weight * float(self.stage_loss_weight[s]))
             if G.IOU_HELPER and last:
                 loss["loss_iou_%d" % (s + 1)] = _scaled(ops.l2_loss_fused(iou_logits, iou=cur.iou[:R]), G.IOU_LOSS_WEIGHT)
             if last:

@@ -71,7 +71,6 @@ class RPNLossComputation(object):
                 lab = torch.where(vis, lab, -1.0)
         pos, neg, quota = batch_pos_neg_sample(lab, [per] * n_img, self.fg_bg_sampler.batch_size_per_image,
                                                self.fg_bg_sampler.positive_fraction)
-        n_sampled = quota.sum()
         if getattr(objectness[0], "_cpm_rpn_sparse", False):
             # the head is one autograd node (ops.rpn_head): tell it which anchors this loss sums over -- everywhere else
             # the gradient it receives is exactly zero -- as an index list built on the device
@@ -81,10 +80,10 @@ class RPNLossComputation(object):
         objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
         # targets (BoxCoder.encode of the matched gt), smooth-L1 over the positives, BCE over the sample, and the
         # gradients of both: ONE launch (cpm_rpn_loss) instead of ~100 elementwise / reduction kernels
-        s_obj, s_box = ops.rpn_loss(objectness.squeeze(1), box_regression, abox, matched, gt_all, gt_off, pos, neg, per,
-                                    self.box_coder.weights, cfg.RPN.SMOOTH_L1_BETA)
-        objectness_loss, box_loss = s_obj / n_sampled, s_box / n_sampled
-        return objectness_loss, box_loss
+        # (the division by the number of sampled anchors, loss.py:121-126, happens inside the launch too: it reads the
+        # sampler's quota on the device -- no sum, no two divisions, no two backward multiplications)
+        return ops.rpn_loss(objectness.squeeze(1), box_regression, abox, matched, gt_all, gt_off, pos, neg, per,
+                            self.box_coder.weights, cfg.RPN.SMOOTH_L1_BETA, quota=quota.contiguous())
 
     def __call__(self, anchors, objectness, box_regression, targets):
         if self.fused_glue:

@@ -13,7 +13,7 @@ from pet.rcnn.utils.box_coder import BoxCoder
 
 import os
 
-_LOSS_ON_SIDE = os.environ.get("CPM_RPN_LOSS_SIDE", "1") != "0"
+_LOSS_ON_SIDE = os.environ.get("CPM_RPN_LOSS_SIDE", "0") != "0"
 
 
 class RPNHead(nn.Module):

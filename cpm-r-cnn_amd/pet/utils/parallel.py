@@ -174,7 +174,12 @@ def backward_losses(losses):
     1, which is the same gradient, minus the 7 add kernels, their autograd nodes and ~0.1 ms of host time that sat
     between the last forward and the first backward kernel, where the device has nothing else queued."""
     terms = [v for v in losses.values() if v.requires_grad]
-    torch.autograd.backward(terms)
+    # the seeds: ONE cached scalar 1 per device instead of a fresh ones_like per term (eight fill kernels and
+    # allocations queued exactly where the device waits for the host: the start of the backward pass)
+    from pet.lib.ops import _hip as H
+    seeds = [H.unit_seed(v.device) if v.dim() == 0 and v.dtype == torch.float32 and v.is_cuda else torch.ones_like(v)
+             for v in terms]
+    torch.autograd.backward(terms, seeds)
 
 
 def reduce_losses(losses):

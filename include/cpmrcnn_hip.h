@@ -371,11 +371,14 @@ int cpm_box_voting(const float* boxes, const float* scores, const int64_t* label
  * anchor, smooth-L1 (beta) over the sampled positives, BCE-with-logits over the sampled anchors -- values AND gradients
  * in one pass over all `total` = images x per_image anchors.  logits [total], reg / anchors [total,4], matched [total]
  * (gt index inside the image, < 0: none), gts [G,4] with gt_off [images+1] (device), pos / neg [total] bool masks.
- * sums2[0] = sum of the BCE terms, sums2[1] = sum of the smooth-L1 terms (NOT divided by the sample count);
- * dlogits [total], dreg [total,4] = derivatives of those sums (zero outside the sample). */
+ * sums2[0] = sum of the BCE terms, sums2[1] = sum of the smooth-L1 terms;
+ * dlogits [total], dreg [total,4] = derivatives of those sums (zero outside the sample).
+ * quota (device, n_quota int32; NULL: sums and derivatives stay undivided): the sampler's per-image (positive, negative)
+ * counts -- sums and derivatives leave divided by their total, the normalisation of loss.py:121-126. */
 int cpm_rpn_loss(const float* logits, const float* reg, const float* anchors, const int64_t* matched, const float* gts,
                  const int* gt_off, const uint8_t* pos, const uint8_t* neg, int64_t total, int per_image,
-                 const float* weights4, float beta, float* sums2, float* dlogits, float* dreg, void* stream);
+                 const float* weights4, float beta, float* sums2, float* dlogits, float* dreg, const int32_t* quota,
+                 int n_quota, void* stream);
 
 /* ---- row-wise top-k for the RPN proposal selection --------------------------------------
  * Replaces `objectness.topk(pre_nms_top_n, dim=1, sorted=True)` of pet/rcnn/modeling/rpn/inference.py:79-84 (torch's
