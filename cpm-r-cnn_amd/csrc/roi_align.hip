@@ -324,20 +324,37 @@ __device__ void axis_row(float start, float bin, int grid, int P, int size, int 
   const int s_lo = (int)flo, s_hi = (int)fhi;
   if (s_hi < s_lo) { *first = 0; *cnt = 0; return; }
   const int p_lo = s_lo / grid, p_hi = s_hi / grid;
-  for (int p = p_lo; p <= p_hi; ++p) row[p] = 0.f;
+  // the samples arrive in bin order: a bin's sum is formed in a register (0 + the terms in sample order, as a
+  // read-modify-write of row[p] per term would) and stored once
+  int p = p_lo, i = s_lo - p_lo * grid;
+  int nz_lo = 1 << 20, nz_hi = -1;                           // the bins whose sum is not zero (a contiguous run)
+  float sum = 0.f;
   for (int sidx = s_lo; sidx <= s_hi; ++sidx) {
-    const int p = sidx / grid, i = sidx - p * grid;
     float y = start + (float)p * bin + ((float)i + .5f) * bin / (float)grid;       // the forward's expression
-    if (y < -1.0f || y > (float)size) continue;
-    if (y <= 0.f) y = 0.f;
-    int lo = (int)y, hi;
-    if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else { hi = lo + 1; }
-    const float l = y - (float)lo, h = 1.f - l;
-    if (lo == pix) row[p] += h;
-    if (hi == pix) row[p] += l;
+    if (!(y < -1.0f || y > (float)size)) {
+      if (y <= 0.f) y = 0.f;
+      int lo = (int)y, hi;
+      if (lo >= size - 1) { hi = lo = size - 1; y = (float)lo; } else { hi = lo + 1; }
+      const float l = y - (float)lo, h = 1.f - l;
+      if (lo == pix) sum += h;
+      if (hi == pix) sum += l;
+    }
+    if (++i == grid) {
+      row[p] = sum;
+      if (sum != 0.f) { nz_lo = min(nz_lo, p); nz_hi = p; }
+      sum = 0.f;
+      i = 0;
+      ++p;
+    }
   }
-  *first = p_lo;
-  *cnt = p_hi - p_lo + 1;
+  if (i != 0) {
+    row[p] = sum;
+    if (sum != 0.f) { nz_lo = min(nz_lo, p); nz_hi = p; }
+  }
+  // (the index range above carries a margin of a sample on either side: the bins it adds weigh exactly zero and
+  // contribute nothing; reporting the non-zero run keeps them out of the consumers' loops and staging)
+  *first = nz_hi >= nz_lo ? nz_lo : 0;
+  *cnt = nz_hi >= nz_lo ? nz_hi - nz_lo + 1 : 0;
 }
 
 __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __restrict__ grad, Levels L, GatherLevels G,
