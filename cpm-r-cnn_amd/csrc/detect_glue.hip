@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void match_rowmax_kernel(const float4* __restr
       for (int k = 0; k < RM_ITEMS; ++k)
         if (img[k] >= 0) v = fmaxf(v, iou_plus1(gt, p[k]));
       for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-      if (lane == 0 && v > 0.f) atomicMax(row_max + g, __float_as_int(v));
+      // (atomics on one address are served one at a time, ~4 ns each: a wave whose maximum does not beat the value
+      // already there -- a stale read can only be LOWER than the truth, the maximum never falls -- issues none)
+      if (lane == 0 && v > 0.f && __float_as_int(v) > __atomic_load_n(row_max + g, __ATOMIC_RELAXED))
+        atomicMax(row_max + g, __float_as_int(v));
     }
     return;
   }
@@ -390,14 +393,14 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__
     inv = 1.f / (float)n;
   }
   float obj = 0.f, box = 0.f;
-  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const bool p = pos[t], n = neg[t];
-    float dl = 0.f;
-    float4 dr = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one anchor: its two loss terms into obj / box, its two derivatives out
+  auto anchor = [&](int64_t t, bool p, bool n, float& dl, float4& dr) {
+    dl = 0.f;
+    dr = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p || n) {
       const float x = logits[t], z = p ? 1.f : 0.f;
       obj += fmaxf(x, 0.f) - x * z + log1pf(expf(-fabsf(x)));                   // binary_cross_entropy_with_logits
-      dl = 1.f / (1.f + expf(-x)) - z;
+      dl = (1.f / (1.f + expf(-x)) - z) * inv;
     }
     if (p) {
       const float4 a = anchors[t];
@@ -418,10 +421,32 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__
         else if (ae < beta) { box += 0.5f * ae * ae / beta; d[k] = e / beta; }
         else { box += ae - 0.5f * beta; d[k] = e > 0.f ? 1.f : -1.f; }
       }
-      dr = make_float4(d[0], d[1], d[2], d[3]);
+      dr = make_float4(d[0] * inv, d[1] * inv, d[2] * inv, d[3] * inv);
     }
-    dlogits[t] = dl * inv;
-    dreg[t] = make_float4(dr.x * inv, dr.y * inv, dr.z * inv, dr.w * inv);
+  };
+  // Nearly every anchor is outside the sample (256 per image of 268 569): the kernel is a 1-byte-per-anchor read of the
+  // two masks and a zero fill of the gradients.  Four anchors per thread: one 4-byte load per mask, a 16-byte store of
+  // the logit gradients (the masks are torch.bool: one byte each; total's remainder is handled one by one below).
+  const int64_t gtid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x, gstride = (int64_t)gridDim.x * blockDim.x;
+  const bool vec = ((((uintptr_t)pos | (uintptr_t)neg) & 3) == 0) && (((uintptr_t)dlogits & 15) == 0);
+  const int64_t n4 = vec ? total >> 2 : 0;
+  for (int64_t q = gtid; q < n4; q += gstride) {
+    const uchar4 pp = ((const uchar4*)pos)[q], nn = ((const uchar4*)neg)[q];
+    const bool p4[4] = {pp.x != 0, pp.y != 0, pp.z != 0, pp.w != 0}, m4[4] = {nn.x != 0, nn.y != 0, nn.z != 0, nn.w != 0};
+    float dl[4];
+    float4 dr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) anchor(4 * q + k, p4[k], m4[k], dl[k], dr[k]);
+    ((float4*)dlogits)[q] = make_float4(dl[0], dl[1], dl[2], dl[3]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) dreg[4 * q + k] = dr[k];
+  }
+  for (int64_t t = 4 * n4 + gtid; t < total; t += gstride) {
+    float dl;
+    float4 dr;
+    anchor(t, pos[t], neg[t], dl, dr);
+    dlogits[t] = dl;
+    dreg[t] = dr;
   }
 #pragma unroll
   for (int d = 32; d > 0; d >>= 1) { obj += __shfl_xor(obj, d, 64); box += __shfl_xor(box, d, 64); }
@@ -430,8 +455,11 @@ __global__ void __launch_bounds__(256) rpn_loss_kernel(const float* __restrict__
   if ((threadIdx.x & 63) == 0) { s_o[wave] = obj; s_b[wave] = box; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(&sums[0], (s_o[0] + s_o[1] + s_o[2] + s_o[3]) * inv);
-    atomicAdd(&sums[1], (s_b[0] + s_b[1] + s_b[2] + s_b[3]) * inv);
+    // (most workgroups hold no sampled anchor: they add nothing, and an atomic on these two words costs every other one
+    // its turn)
+    const float so = s_o[0] + s_o[1] + s_o[2] + s_o[3], sb = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    if (so != 0.f) atomicAdd(&sums[0], so * inv);
+    if (sb != 0.f) atomicAdd(&sums[1], sb * inv);
   }
 }
 
@@ -503,7 +531,8 @@ CPM_EXPORT int cpm_rpn_loss(const float* logits, const float* reg, const float* 
   CPM_REQUIRE(logits && reg && anchors && matched && gts && gt_off && pos && neg && dlogits && dreg, "null pointer");
   CPM_REQUIRE((((uintptr_t)reg | (uintptr_t)anchors | (uintptr_t)gts | (uintptr_t)dreg) & 15) == 0,
               "box tensors must be 16-byte aligned");
-  int64_t b = (total + 255) / 256;
+  int64_t b = (total / 4 + 255) / 256;                     // four anchors per thread
+  if (b < 1) b = 1;
   if (b > 2048) b = 2048;
   hipLaunchKernelGGL(rpn_loss_kernel, dim3((unsigned)b), dim3(256), 0, s, logits, (const float4*)reg,
                      (const float4*)anchors, matched, (const float4*)gts, gt_off, (const bool*)pos, (const bool*)neg,

@@ -234,6 +234,49 @@ struct SampleArgs {
   int32_t* status;                // != 0: an image held more than MAX_ROWS rows (nothing was sampled)
 };
 
+// The `want`-th smallest (1-based) of the keys s_key[r], r < cnt, whose class byte s_cls[r] equals c: radix select,
+// eight 8-bit digits from the top, a 256-bin LDS histogram per digit (the lists hold a few thousand rows: two or four
+// per thread).  The keys are distinct (the row index is their low word), so `key <= result` marks exactly `want` members.
+// Every thread of the workgroup calls; s_hist (256 ints) and s_sel (2 ints) are scratch.  Replaces a rank-by-counting
+// loop over all rows per row (4 M LDS reads per image at 2 000 proposals: most of the kernel's time).
+__device__ unsigned long long kth_smallest_key(const unsigned long long* s_key, const uint8_t* s_cls, int c, int cnt,
+                                               int want, int* s_hist, int* s_sel) {
+  unsigned long long prefix = 0;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    if (threadIdx.x < 256) s_hist[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long himask = shift == 56 ? 0ull : ~0ull << (shift + 8);
+    for (int r = threadIdx.x; r < cnt; r += THREADS) {
+      const unsigned long long k = s_key[r];
+      if (s_cls[r] == c && (k & himask) == prefix) atomicAdd(&s_hist[(int)((k >> shift) & 255)], 1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 64) {                          // wave 0: four bins per lane, prefix over the lanes
+      const int l = threadIdx.x;
+      const int h0 = s_hist[4 * l], h1 = s_hist[4 * l + 1], h2 = s_hist[4 * l + 2], h3 = s_hist[4 * l + 3];
+      const int mine = h0 + h1 + h2 + h3;
+      int incl = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d, 64);
+        if (l >= d) incl += t;
+      }
+      const int below = incl - mine;                 // members in lower bins
+      if (below < want && want <= incl) {            // the crossing lies in this lane's bins
+        int b = 4 * l, acc = below;
+        if (acc + h0 < want) { acc += h0; ++b; if (acc + h1 < want) { acc += h1; ++b; if (acc + h2 < want) { acc += h2; ++b; } } }
+        s_sel[0] = b;
+        s_sel[1] = want - acc;                       // rank inside the bin
+      }
+    }
+    __syncthreads();
+    prefix |= (unsigned long long)s_sel[0] << shift;
+    want = s_sel[1];
+    __syncthreads();                                 // s_sel is rewritten by the next digit
+  }
+  return prefix;
+}
+
 __global__ void __launch_bounds__(THREADS) roi_sample_kernel(SampleArgs a) {
   __shared__ unsigned long long s_key[MAX_ROWS];   // (key << 32 | row) of the row's sampling draw
   __shared__ uint8_t s_cls[MAX_ROWS];              // 0 positive, 1 negative, 2 ignored
@@ -241,6 +284,8 @@ __global__ void __launch_bounds__(THREADS) roi_sample_kernel(SampleArgs a) {
   __shared__ uint8_t s_take[MAX_ROWS];
   __shared__ int s_wave[WAVES];
   __shared__ int s_n[2];
+  __shared__ int s_hist[256];
+  __shared__ int s_sel[2];
   int in_off = 0, out_s = 0, out_p = 0;
   for (int img = 0; img < a.n_img; ++img)
     if (a.counts[img] > MAX_ROWS) {                 // uniform: every thread reads the same counts
@@ -281,18 +326,16 @@ __global__ void __launch_bounds__(THREADS) roi_sample_kernel(SampleArgs a) {
     const int q_neg = n_neg < room ? n_neg : room;
     // the sample of a class = its `quota` members with the smallest (key, row): BalancedPositiveNegativeSampler's
     // uniformly random subset (balanced_positive_negative_sampler.py:27-67), drawn as cpm_sample_pos_neg draws it
+    // (a class with more members than places: the threshold key of its quota; uniform branches)
+    unsigned long long thr_pos = ~0ull, thr_neg = ~0ull;
+    if (q_pos > 0 && q_pos < n_pos) thr_pos = kth_smallest_key(s_key, s_cls, 0, cnt, q_pos, s_hist, s_sel);
+    if (q_neg > 0 && q_neg < n_neg) thr_neg = kth_smallest_key(s_key, s_cls, 1, cnt, q_neg, s_hist, s_sel);
     for (int r = threadIdx.x; r < cnt; r += THREADS) {
       const int c = s_cls[r];
       uint8_t take = 0;
       if (c < 2) {
-        const int quota = c == 0 ? q_pos : q_neg, size = c == 0 ? n_pos : n_neg;
-        if (quota >= size) take = 1;
-        else if (quota > 0) {
-          const unsigned long long mine = s_key[r];
-          int rank = 0;
-          for (int t = 0; t < cnt; ++t) rank += (s_cls[t] == c) & (s_key[t] < mine);
-          take = rank < quota;
-        }
+        const int quota = c == 0 ? q_pos : q_neg;
+        take = quota > 0 && s_key[r] <= (c == 0 ? thr_pos : thr_neg);
       }
       s_take[r] = take;
     }
@@ -300,22 +343,23 @@ __global__ void __launch_bounds__(THREADS) roi_sample_kernel(SampleArgs a) {
     // positives of the sample: all, or the max_grid with the smallest second draw (misc.py:54-94, a random subset)
     const uint32_t gseed = a.seed_grid + (uint32_t)img * 0x632BE5ABu;
     const bool subset = a.max_grid > 0 && q_pos > a.max_grid;
+    unsigned long long thr_grid = ~0ull;
     if (subset) {
-      for (int r = threadIdx.x; r < cnt; r += THREADS)
+      // second draw; the class byte of a sampled positive becomes 3 for the selection (nothing below reads the 0 again
+      // except through `s_cls[r] == 0 || == 3`)
+      for (int r = threadIdx.x; r < cnt; r += THREADS) {
         s_key[r] = ((unsigned long long)sample_key(gseed, (uint32_t)r) << 32) | (uint32_t)r;
+        if (s_take[r] && s_cls[r] == 0) s_cls[r] = 3;
+      }
       __syncthreads();
+      thr_grid = kth_smallest_key(s_key, s_cls, 3, cnt, a.max_grid, s_hist, s_sel);
     }
     int run_s = 0, run_p = 0;
     for (int start = 0; start < cnt; start += THREADS) {
       const int r = start + threadIdx.x;
       const bool take = r < cnt && s_take[r];
-      bool posi = a.max_grid > 0 && take && s_cls[r] == 0;
-      if (posi && subset) {
-        const unsigned long long mine = s_key[r];
-        int rank = 0;
-        for (int t = 0; t < cnt; ++t) rank += (s_take[t] != 0) & (s_cls[t] == 0) & (s_key[t] < mine);
-        posi = rank < a.max_grid;
-      }
+      bool posi = a.max_grid > 0 && take && (s_cls[r] == 0 || s_cls[r] == 3);
+      if (posi && subset) posi = s_key[r] <= thr_grid;
       int tot_s, tot_p;
       const int before_s = run_s + block_rank(take, s_wave, &tot_s);
       const int before_p = run_p + block_rank(posi, s_wave, &tot_p);

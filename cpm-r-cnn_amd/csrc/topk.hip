@@ -11,6 +11,7 @@
 // NMS stage sorts by (nms.hip make_key), so equal scores keep a defined order end to end.  Traffic: 5 reads of
 // the segment, 12 bytes written per selected element.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -97,16 +98,36 @@ struct TopkLevels {
   int n[TOPK_LEVELS], k[TOPK_LEVELS];
 };
 
-__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv) {
+// Long rows in slices.  One workgroup per row lives on its own memory-level parallelism: the RPN's finest level
+// (201 600 anchors per image) took 140 us of a 19 ms step with the rest of the chip idle.  With `cand` given, a row of
+// at least 2 x TOPK_SLICE_MIN elements is cut into up to TOPK_SLICES slices (blockIdx.z): each slice's workgroup
+// selects ITS k best the same way and leaves them unsorted in cand as (~key << 32 | index in the row); the row's
+// k best are the k smallest of those composites (topk_merge_kernel).  Shorter rows are finished here as before.
+constexpr int TOPK_SLICES = 8;
+constexpr int TOPK_SLICE_MIN = 16384;
+
+__host__ __device__ inline int topk_slices(int n) {
+  const int s = n / TOPK_SLICE_MIN;
+  return s < 2 ? 1 : (s > TOPK_SLICES ? TOPK_SLICES : s);
+}
+__host__ __device__ inline int topk_slice_len(int n, int slices) { return ((n + slices - 1) / slices + 3) & ~3; }
+
+__global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv, unsigned long long* __restrict__ cand) {
   const float* __restrict__ scores = lv.scores[blockIdx.y];
   float* __restrict__ out_scores = lv.out_scores[blockIdx.y];
   int64_t* __restrict__ out_idx = lv.out_idx[blockIdx.y];
-  const int n = lv.n[blockIdx.y], k = lv.k[blockIdx.y];
+  const int n_row = lv.n[blockIdx.y], k_row = lv.k[blockIdx.y];
+  const int slices = cand ? topk_slices(n_row) : 1;
+  if ((int)blockIdx.z >= slices) return;
+  const int slice_len = slices > 1 ? topk_slice_len(n_row, slices) : n_row;
+  const int lo = (int)blockIdx.z * slice_len;              // (a multiple of 4: the slice is aligned like the row)
+  const int n = min(n_row, lo + slice_len) - lo;
+  const int k = min(k_row, n);
   __shared__ int hist[256 * COPIES];
   __shared__ int tot[256];
   __shared__ unsigned long long sel[TOPK_MAX];
   __shared__ int s_bin, s_above, s_count, s_ties;
-  const float* row = scores + (int64_t)blockIdx.x * n;
+  const float* row = scores + (int64_t)blockIdx.x * n_row + lo;
   const int tid = threadIdx.x;
 
   uint32_t prefix = 0;           // key bits fixed so far (in place)
@@ -177,6 +198,11 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv) 
     }
   }
   __syncthreads();
+  if (slices > 1) {
+    unsigned long long* out = cand + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TOPK_SLICES + blockIdx.z) * TOPK_MAX;
+    for (int j = tid; j < k; j += TOPK_THREADS) out[j] = sel[j] + (unsigned long long)lo;     // index in the row
+    return;
+  }
   // bitonic sort of the k composite keys (ascending == score descending, index ascending)
   int np2 = 1;
   while (np2 < k) np2 <<= 1;
@@ -203,6 +229,80 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv) 
   }
 }
 
+// The k smallest of a sliced row's candidate composites (they are distinct: the index is their low word), sorted.
+// <= TOPK_SLICES x TOPK_MAX candidates, 16 per thread in registers; radix select on the complemented composite (so that
+// find_bin's "largest" is the smallest), digit by digit from the top, stopping as soon as the chosen bin holds exactly
+// what is still wanted -- without ties on the k-th score that is after the four score digits.
+__global__ void __launch_bounds__(TOPK_THREADS) topk_merge_kernel(TopkLevels lv, const unsigned long long* __restrict__ cand) {
+  const int n_row = lv.n[blockIdx.y], k = lv.k[blockIdx.y];
+  const int slices = topk_slices(n_row);
+  if (slices == 1) return;
+  __shared__ int hist[256 * COPIES];
+  __shared__ int tot[256];
+  __shared__ unsigned long long sel[TOPK_MAX];
+  __shared__ int s_bin, s_above, s_count;
+  const int tid = threadIdx.x;
+  const int slice_len = topk_slice_len(n_row, slices);
+  const unsigned long long* base = cand + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * TOPK_SLICES * TOPK_MAX;
+  constexpr int PER = TOPK_SLICES * TOPK_MAX / TOPK_THREADS;        // 16
+  unsigned long long d[PER];                                          // ~composite, 0 = no candidate
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    const int e = tid + i * TOPK_THREADS, z = e / TOPK_MAX, j = e - z * TOPK_MAX;
+    const int len = min(n_row, (z + 1) * slice_len) - z * slice_len;
+    d[i] = (z < slices && j < min(k, len)) ? ~base[(size_t)z * TOPK_MAX + j] : 0ull;
+  }
+  unsigned long long prefix = 0, mask = 0;
+  int want = k;
+  const int copy = tid & (COPIES - 1);
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    for (int i = tid; i < 256 * COPIES; i += TOPK_THREADS) hist[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < PER; ++i)
+      if (d[i] != 0ull && (d[i] & mask) == prefix) atomicAdd(&hist[(int)((d[i] >> shift) & 255ull) * COPIES + copy], 1);
+    __syncthreads();
+    find_bin(hist, tot, want, &s_bin, &s_above);
+    __syncthreads();
+    prefix |= (unsigned long long)s_bin << shift;
+    mask |= 255ull << shift;
+    want -= s_above;
+    const bool done = tot[s_bin] == want;                           // the whole bin is taken: nothing left to split
+    __syncthreads();
+    if (done) break;
+  }
+  if (tid == 0) s_count = 0;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < PER; ++i)
+    if (d[i] != 0ull && (d[i] & mask) >= prefix) sel[atomicAdd(&s_count, 1)] = ~d[i];
+  __syncthreads();
+  int np2 = 1;
+  while (np2 < k) np2 <<= 1;
+  for (int i = k + tid; i < np2; i += TOPK_THREADS) sel[i] = ~0ull;
+  __syncthreads();
+  for (int size = 2; size <= np2; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < np2 / 2; t += TOPK_THREADS) {
+        const int lo = ((t / stride) * stride * 2) + (t % stride);
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        const unsigned long long a = sel[lo], b2 = sel[hi];
+        if ((a > b2) == up) { sel[lo] = b2; sel[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  const float* row = lv.scores[blockIdx.y] + (int64_t)blockIdx.x * n_row;
+  float* os = lv.out_scores[blockIdx.y] + (int64_t)blockIdx.x * k;
+  int64_t* oi = lv.out_idx[blockIdx.y] + (int64_t)blockIdx.x * k;
+  for (int j = tid; j < k; j += TOPK_THREADS) {
+    const uint32_t idx = (uint32_t)(sel[j] & 0xffffffffull);
+    os[j] = row[idx];
+    oi[j] = (int64_t)idx;
+  }
+}
+
 }  // namespace
 
 CPM_EXPORT int cpm_topk_rows(const float* scores, int rows, int n, int k, float* out_scores, int64_t* out_idx,
@@ -214,12 +314,19 @@ CPM_EXPORT int cpm_topk_rows(const float* scores, int rows, int n, int k, float*
   CPM_REQUIRE(scores && out_scores && out_idx, "null pointer");
   TopkLevels lv = {};
   lv.scores[0] = scores; lv.out_scores[0] = out_scores; lv.out_idx[0] = out_idx; lv.n[0] = n; lv.k[0] = k;
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, 1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, 1), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv,
+                     (unsigned long long*)nullptr);
   return cpm::check_launch("topk_rows");
 }
 
+CPM_EXPORT size_t cpm_topk_rows_multi_workspace_bytes(int levels, int rows) {
+  if (levels < 1 || rows < 1) return 0;
+  return (size_t)levels * rows * TOPK_SLICES * TOPK_MAX * sizeof(unsigned long long);
+}
+
 CPM_EXPORT int cpm_topk_rows_multi(const float* const* scores, const int* n, const int* k, int levels, int rows,
-                                   float* const* out_scores, int64_t* const* out_idx, void* stream) {
+                                   float* const* out_scores, int64_t* const* out_idx, void* workspace,
+                                   size_t workspace_bytes, void* stream) {
   CPM_REQUIRE(levels >= 1 && levels <= TOPK_LEVELS && rows >= 0, "1 <= levels <= 8");
   CPM_REQUIRE(scores && n && k && out_scores && out_idx, "null pointer");
   if (rows == 0) return CPM_OK;
@@ -231,6 +338,18 @@ CPM_EXPORT int cpm_topk_rows_multi(const float* const* scores, const int* n, con
     lv.scores[l] = scores[l]; lv.out_scores[l] = out_scores[l]; lv.out_idx[l] = out_idx[l];
     lv.n[l] = n[l]; lv.k[l] = k[l];
   }
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, levels), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv);
-  return cpm::check_launch("topk_rows_multi");
+  int max_slices = 1;
+  for (int l = 0; l < levels; ++l) max_slices = std::max(max_slices, topk_slices(n[l]));
+  const bool sliced = max_slices > 1 && workspace && (((uintptr_t)workspace & 7) == 0) &&
+                      workspace_bytes >= cpm_topk_rows_multi_workspace_bytes(levels, rows);
+  if (!sliced) {
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, levels), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv,
+                       (unsigned long long*)nullptr);
+    return cpm::check_launch("topk_rows_multi");
+  }
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows, levels, max_slices), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv,
+                     (unsigned long long*)workspace);
+  hipLaunchKernelGGL(topk_merge_kernel, dim3(rows, levels), dim3(TOPK_THREADS), 0, (hipStream_t)stream, lv,
+                     (const unsigned long long*)workspace);
+  return cpm::check_launch("topk_rows_multi (sliced)");
 }

@@ -206,6 +206,12 @@ def topk_rows(scores, k):
     return vals, idx
 
 
+def _topk_ws_bytes(levels, rows):
+    f = H.lib().cpm_topk_rows_multi_workspace_bytes
+    f.restype = ctypes.c_size_t
+    return int(f(int(levels), int(rows)))
+
+
 def topk_rows_multi(score_list, ks, out=None):
     """topk_rows for several [rows, n_l] matrices (same rows) in one launch (cpm_topk_rows_multi): the RPN's FPN levels.
     Returns a list of (values, indices); `out` may supply that list ([rows, k_l] fp32 / int64, contiguous)."""
@@ -234,9 +240,13 @@ def topk_rows_multi(score_list, ks, out=None):
     vp = ctypes.c_void_p * L
     ip = ctypes.c_int * L
     with H.guard(ss[0].device):
+        # (long rows -- the finest FPN level -- are selected by several workgroups each: scratch for their candidates)
+        need = _topk_ws_bytes(L, rows) if max(s.shape[1] for s in ss) >= 32768 else 0
+        wsb = H.workspace(need, ss[0].device) if need else None
         rc = H.lib().cpm_topk_rows_multi(vp(*[s.data_ptr() for s in ss]), ip(*[s.shape[1] for s in ss]),
                                          ip(*[int(k) for k in ks]), L, rows, vp(*[o[0].data_ptr() for o in outs]),
-                                         vp(*[o[1].data_ptr() for o in outs]), H.stream())
+                                         vp(*[o[1].data_ptr() for o in outs]), H.ptr(wsb) if need else None,
+                                         H.c_size_t(wsb.numel() if need else 0), H.stream())
     H.check(rc, "topk_rows_multi")
     return outs
 

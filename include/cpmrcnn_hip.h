@@ -388,9 +388,14 @@ int cpm_rpn_loss(const float* logits, const float* reg, const float* anchors, co
 int cpm_topk_rows(const float* scores, int rows, int n, int k, float* out_scores, int64_t* out_idx, void* stream);
 /* The same for several matrices of `rows` rows each in ONE launch (the RPN's five FPN levels, inference.py:67-114 loops
  * over them): HOST arrays of `levels` <= 8 device pointers / sizes; level l: scores[l] [rows][n[l]] -> out_scores[l],
- * out_idx[l] [rows][k[l]]. */
+ * out_idx[l] [rows][k[l]].
+ * workspace (device, 8-byte aligned, cpm_topk_rows_multi_workspace_bytes; may be NULL): with it, rows of 32 768 elements
+ * and more are selected by up to 8 workgroups each (slices of the row, then a merge launch) instead of one -- the same
+ * result, the order of equal values included. */
+size_t cpm_topk_rows_multi_workspace_bytes(int levels, int rows);
 int cpm_topk_rows_multi(const float* const* scores, const int* n, const int* k, int levels, int rows,
-                        float* const* out_scores, int64_t* const* out_idx, void* stream);
+                        float* const* out_scores, int64_t* const* out_idx, void* workspace, size_t workspace_bytes,
+                        void* stream);
 
 /* ---- fixed-size positive / negative sampling for the whole batch ---------------------------
  * Replaces BalancedPositiveNegativeSampler.__call__ (pet/rcnn/utils/balanced_positive_negative_sampler.py:27-67, called

@@ -394,6 +394,12 @@ def test_topk_rows_multi_equals_per_level():
         v1, i1 = ops.topk_rows(s, k)
         assert torch.equal(v, v1) and torch.equal(i, i1)
         assert torch.equal(v, s.topk(k, dim=1, sorted=True)[0])
+    # rows cut into slices (>= 32 768 elements) with masses of equal values, at the k-th place too: the lowest indices
+    # win, in every slice and in the merge, exactly as in the one-workgroup selection
+    tied = [(torch.randint(0, m, (2, n), generator=g) / float(m)).cuda() for m, n in ((50, 201600), (3, 50400), (1, 40000))]
+    for (v, i), s in zip(ops.topk_rows_multi(tied, [2000, 2000, 100]), tied):
+        v1, i1 = ops.topk_rows(s, v.shape[1])
+        assert torch.equal(v, v1) and torch.equal(i, i1)
     (v, i), = ops.topk_rows_multi([ss[4]], [819])
     assert torch.equal(v, ss[4].sort(dim=1, descending=True)[0])
     with pytest.raises(RuntimeError):
