@@ -30,16 +30,23 @@ __device__ __forceinline__ float iou_plus1(const float4 g, const float4 p) {
 // IoU >= 0, so the int view of the float orders like the float
 constexpr int RM_ITEMS = 8;     // predictions per thread in the row-maximum pass
 
-__global__ __launch_bounds__(256) void match_rowmax_kernel(const float4* __restrict__ rois,
-                                                           const int* __restrict__ roi_img,
-                                                           const float4* __restrict__ gts,
-                                                           const int* __restrict__ gt_off, int R,
-                                                           int* __restrict__ row_max) {
-  // 268 k anchors per image against a few dozen gts whose maxima share ONE cache line: every atomic on it is
-  // serialised.  A thread therefore folds RM_ITEMS predictions per gt in registers, a wave whose predictions all
-  // belong to one image reduces across its 64 lanes, and only lane 0 issues the atomic (one per wave and gt for
-  // 512 predictions); a wave straddling an image boundary falls back to per-prediction atomics.
-  const int base = (blockIdx.x * 256 + (threadIdx.x & ~63)) * RM_ITEMS + (threadIdx.x & 63);
+constexpr int RM_THREADS = 512, RM_WAVES = RM_THREADS / 64, RM_GTS = 128;
+
+__global__ __launch_bounds__(RM_THREADS) void match_rowmax_kernel(const float4* __restrict__ rois,
+                                                                  const int* __restrict__ roi_img,
+                                                                  const float4* __restrict__ gts,
+                                                                  const int* __restrict__ gt_off, int R,
+                                                                  int* __restrict__ row_max) {
+  // 268 k anchors per image against a few dozen gts whose maxima share ONE cache line: every atomic on it is served
+  // alone (~4 ns), and a value read beforehand is no filter -- all workgroups start together, on zeros.  A thread
+  // therefore folds RM_ITEMS predictions per gt in registers, a wave whose predictions all belong to one image
+  // reduces across its 64 lanes, the workgroup's 16 waves meet in LDS, and ONE atomic per gt and workgroup (8 192
+  // predictions) goes out.  A wave straddling an image boundary (or an image with more than RM_GTS gts) issues its
+  // own atomic per gt.
+  __shared__ float s_max[RM_WAVES][RM_GTS];
+  __shared__ int s_img[RM_WAVES];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int base = (blockIdx.x * RM_THREADS + (threadIdx.x & ~63)) * RM_ITEMS + lane;
   float4 p[RM_ITEMS];
   int img[RM_ITEMS];
   bool uniform = true;
@@ -54,28 +61,58 @@ __global__ __launch_bounds__(256) void match_rowmax_kernel(const float4* __restr
     uniform = uniform && __all(img[k] == img0 || !live);
   }
   uniform = uniform && img0 >= 0;
-  if (uniform) {
-    const int lane = threadIdx.x & 63;
-    for (int g = gt_off[img0]; g < gt_off[img0 + 1]; ++g) {
-      const float4 gt = gts[g];
+  const bool pooled = uniform && gt_off[img0 + 1] - gt_off[img0] <= RM_GTS;   // this wave's maxima go through LDS
+  if (lane == 0) s_img[wave] = pooled ? img0 : -1;
+  // the images present in the wave, one after the other (one, except for the wave at an image boundary, whose
+  // per-prediction atomics -- 8 192 turns on one cache line -- were most of this kernel's time)
+  int done_img = -1;
+  for (;;) {
+    int im = 0x7fffffff;
+#pragma unroll
+    for (int k = 0; k < RM_ITEMS; ++k)
+      if (img[k] > done_img) im = min(im, img[k]);
+    for (int o = 32; o > 0; o >>= 1) im = min(im, __shfl_xor(im, o, 64));
+    if (im == 0x7fffffff) break;
+    done_img = im;
+    const int g0 = gt_off[im], ng = gt_off[im + 1] - g0;
+    float4 gt_lane = make_float4(0.f, 0.f, 0.f, 0.f);               // gt (g & ~63) + lane: one load per 64 gts, not one per gt
+    for (int g = 0; g < ng; ++g) {
+      if ((g & 63) == 0) gt_lane = (g + lane < ng) ? gts[g0 + g + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 gt = make_float4(__shfl(gt_lane.x, g & 63, 64), __shfl(gt_lane.y, g & 63, 64),
+                                    __shfl(gt_lane.z, g & 63, 64), __shfl(gt_lane.w, g & 63, 64));
+      // 64 neighbouring anchors x 8 rarely touch a given gt at all: then every IoU is 0, and the wave skips the eight
+      // divisions and the reduction (the overlap test is iou_plus1's own intersection, so "no overlap" is exactly v == 0)
+      bool touch = false;
+#pragma unroll
+      for (int k = 0; k < RM_ITEMS; ++k) {
+        const float w = fminf(gt.z, p[k].z) - fmaxf(gt.x, p[k].x) + 1.f, h = fminf(gt.w, p[k].w) - fmaxf(gt.y, p[k].y) + 1.f;
+        touch = touch || (img[k] == im && w > 0.f && h > 0.f);
+      }
+      if (!__any(touch)) {
+        if (lane == 0 && pooled) s_max[wave][g] = 0.f;
+        continue;
+      }
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < RM_ITEMS; ++k)
-        if (img[k] >= 0) v = fmaxf(v, iou_plus1(gt, p[k]));
+        if (img[k] == im) v = fmaxf(v, iou_plus1(gt, p[k]));
       for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-      // (atomics on one address are served one at a time, ~4 ns each: a wave whose maximum does not beat the value
-      // already there -- a stale read can only be LOWER than the truth, the maximum never falls -- issues none)
-      if (lane == 0 && v > 0.f && __float_as_int(v) > __atomic_load_n(row_max + g, __ATOMIC_RELAXED))
-        atomicMax(row_max + g, __float_as_int(v));
+      if (lane == 0) {
+        if (pooled) s_max[wave][g] = v;
+        else if (v > 0.f) atomicMax(row_max + g0 + g, __float_as_int(v));
+      }
     }
-    return;
   }
-#pragma unroll
-  for (int k = 0; k < RM_ITEMS; ++k) {
-    if (img[k] < 0) continue;
-    for (int g = gt_off[img[k]]; g < gt_off[img[k] + 1]; ++g) {
-      const float v = iou_plus1(gts[g], p[k]);
-      if (v > 0.f) atomicMax(row_max + g, __float_as_int(v));
+  __syncthreads();
+  // the pooled waves, image by image (a workgroup spans two images at most once per image boundary)
+  for (int w0 = 0; w0 < RM_WAVES; ++w0) {
+    const int im = s_img[w0];
+    if (im < 0 || (w0 > 0 && s_img[w0 - 1] == im)) continue;          // first wave of a run of one image
+    const int b0 = gt_off[im], n = gt_off[im + 1] - b0;
+    for (int g = threadIdx.x; g < n; g += RM_THREADS) {
+      float v = 0.f;
+      for (int w = w0; w < RM_WAVES && s_img[w] == im; ++w) v = fmaxf(v, s_max[w][g]);
+      if (v > 0.f) atomicMax(row_max + b0 + g, __float_as_int(v));
     }
   }
 }
@@ -478,8 +515,8 @@ CPM_EXPORT int cpm_match_rois(const float* rois, const int* roi_img, const float
   if (allow_low_quality) {
     if (hipMemsetAsync(row_max_ws, 0, sizeof(int) * (size_t)(num_gts > 0 ? num_gts : 1), s) != hipSuccess)
       return CPM_ELAUNCH;
-    hipLaunchKernelGGL(match_rowmax_kernel, dim3((unsigned)((R + 256 * RM_ITEMS - 1) / (256 * RM_ITEMS))), dim3(256),
-                       0, s, (const float4*)rois, roi_img,
+    hipLaunchKernelGGL(match_rowmax_kernel, dim3((unsigned)((R + RM_THREADS * RM_ITEMS - 1) / (RM_THREADS * RM_ITEMS))),
+                       dim3(RM_THREADS), 0, s, (const float4*)rois, roi_img,
                        (const float4*)gts, gt_off, R, row_max_ws);
   }
   hipLaunchKernelGGL(match_kernel, dim3(blocks), dim3(256), 0, s, (const float4*)rois, roi_img, (const float4*)gts,

@@ -232,13 +232,13 @@ __global__ __launch_bounds__(64) void mask_tiles_t(const float4* __restrict__ sb
   const int r_size = min(n - rb * 64, 64), c_size = min(n - cb * 64, 64);
   if (lane < r_size) {
     rbox[lane] = sboxes[base + rb * 64 + lane];
-    rlab[lane] = slabels[base + rb * 64 + lane];
+    rlab[lane] = slabels ? slabels[base + rb * 64 + lane] : 0;
   }
   __syncthreads();
   if (lane < c_size) {
     const int c = cb * 64 + lane;
     const float4 b = sboxes[base + c];
-    const int32_t bl = slabels[base + c];
+    const int32_t bl = slabels ? slabels[base + c] : 0;
     uint64_t t = 0;
     const int limit = (rb == cb) ? lane : r_size;              // only EARLIER boxes can suppress
     for (int i = 0; i < limit; ++i)
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(64) void sweep_segments_small(const uint64_t* __res
       if (j <= blk) v = m[(int64_t)j * (nblk * 64) + row];       // wave-uniform condition (blk < nblk)
       w[j] = (row < n && j <= blk) ? v : 0ull;
     }
-    ord = order[base + (row < n ? row : n - 1)];
+    ord = order ? order[base + (row < n ? row : n - 1)] : row;   // (no order list: the segment came sorted)
   };
   uint64_t wa[SMALL_NB], wb[SMALL_NB];
   int32_t oa = 0, ob = 0;
@@ -373,9 +373,9 @@ CPM_EXPORT size_t cpm_nms_workspace_bytes(const int32_t* h_offsets, int P) {
   return ws_layout(h_offsets, P).total;
 }
 
-CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const int64_t* labels,
-                               const int32_t* h_offsets, int P, float iou_threshold, int topk, int64_t* keep,
-                               int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream) {
+static int nms_batched_impl(const float* boxes, const float* scores, const int64_t* labels,
+                            const int32_t* h_offsets, int P, float iou_threshold, int topk, int64_t* keep,
+                            int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream, bool presorted) {
   CPM_REQUIRE(h_offsets && P > 0, "segment table");
   CPM_REQUIRE(keep_count, "null keep_count");
   hipStream_t s = (hipStream_t)stream;
@@ -421,6 +421,17 @@ CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const in
       (void)hipMemsetAsync(keep_count + p0, 0, sizeof(int32_t) * np, s);
       continue;
     }
+    // segments that arrive in descending score order (the RPN's: the pre-NMS top-k leaves them sorted), unlabelled and
+    // small enough for the transposed tiles: the stable sort is the identity -- no sort, no gather, the tiles read the
+    // caller's boxes
+    if (presorted && !labels && maxn <= SMALL_NB * 64 && (((uintptr_t)boxes) & 15) == 0) {
+      const int nblk = (maxn + 63) / 64;
+      hipLaunchKernelGGL(mask_tiles_t, dim3(nblk, nblk, np), dim3(64), 0, s, (const float4*)boxes,
+                         (const int32_t*)nullptr, T, iou_threshold, mask);
+      hipLaunchKernelGGL(sweep_segments_small, dim3(np), dim3(64), 0, s, mask, (const int32_t*)nullptr, T, topk, keep,
+                         keep_count + p0);
+      continue;
+    }
     // 1. sort
     {
       int lds_n = maxn < LDS_SORT_MAX ? maxn : LDS_SORT_MAX;
@@ -457,6 +468,20 @@ CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const in
     }
   }
   return cpm::check_launch("nms_batched");
+}
+
+CPM_EXPORT int cpm_nms_batched(const float* boxes, const float* scores, const int64_t* labels,
+                               const int32_t* h_offsets, int P, float iou_threshold, int topk, int64_t* keep,
+                               int32_t* keep_count, void* workspace, size_t workspace_bytes, void* stream) {
+  return nms_batched_impl(boxes, scores, labels, h_offsets, P, iou_threshold, topk, keep, keep_count, workspace,
+                          workspace_bytes, stream, false);
+}
+
+CPM_EXPORT int cpm_nms_batched_presorted(const float* boxes, const float* scores, const int32_t* h_offsets, int P,
+                                         float iou_threshold, int topk, int64_t* keep, int32_t* keep_count,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  return nms_batched_impl(boxes, scores, nullptr, h_offsets, P, iou_threshold, topk, keep, keep_count, workspace,
+                          workspace_bytes, stream, true);
 }
 
 CPM_EXPORT int cpm_box_iou(const float* boxes, int N, const float* query, int K, float* out, void* stream) {

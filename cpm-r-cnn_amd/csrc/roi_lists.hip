@@ -65,6 +65,37 @@ __device__ __forceinline__ uint32_t ordered_bits(float v) {
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);          // ascending unsigned order == ascending float order
 }
 
+// From a 256-bin histogram: the highest digit d with  count(bins > d) < want <= count(bins >= d), and count(bins > d).
+// Wave 0 of the workgroup: four bins per lane, suffix sums over the lanes (a walk down the bins by one thread read 256
+// LDS words one after the other, four times per selection).  Results in out[0] (digit), out[1] (above); the caller
+// puts barriers around the call.
+__device__ __forceinline__ void find_digit_desc(const int* hist, int want, int* out) {
+  if (threadIdx.x >= 64) return;
+  const int l = threadIdx.x;
+  const int h0 = hist[4 * l], h1 = hist[4 * l + 1], h2 = hist[4 * l + 2], h3 = hist[4 * l + 3];
+  const int mine = h0 + h1 + h2 + h3;
+  int incl = mine;                                     // this lane's bins and every higher lane's
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_down(incl, d, 64);
+    if (l + d < 64) incl += t;
+  }
+  const int above_lane = incl - mine;
+  // exactly one lane holds the crossing when 1 <= want <= total; with want beyond the total the walk ended at digit 0
+  if (above_lane < want && (want <= incl || l == 0)) {
+    int d = 4 * l + 3, above = above_lane;             // down the lane's bins to the first with above + count >= want
+    if (above + h3 < want) {
+      above += h3; --d;
+      if (above + h2 < want) {
+        above += h2; --d;
+        if (above + h1 < want) { above += h1; --d; }     // (bin 4 l is the crossing, or digit 0 at the end of the walk)
+      }
+    }
+    out[0] = d;
+    out[1] = above;
+  }
+}
+
 struct SegOff { int32_t off[MAX_SEGS + 1]; };
 
 // ---- proposals: post-NMS top-n per (image, level), top-k over the whole batch, gts appended --------------------
@@ -83,6 +114,9 @@ __global__ void __launch_bounds__(THREADS) proposals_finalize_kernel(
   __shared__ int s_selpre[MAX_IMAGES + 1];
   __shared__ uint32_t s_prefix;
   __shared__ int s_remaining;
+  __shared__ int s_digit[2];
+  constexpr int KEYCAP = 12288;              // candidate keys kept in LDS after the first pass (48 KB)
+  __shared__ uint32_t s_keys[KEYCAP];
   const int n_seg = n_img * n_lvl;
   if (threadIdx.x == 0) {
     int run = 0;
@@ -122,19 +156,26 @@ __global__ void __launch_bounds__(THREADS) proposals_finalize_kernel(
       __syncthreads();
       const uint32_t himask = shift == 24 ? 0u : (0xFFFFFFFFu << (shift + 8));
       const uint32_t prefix = s_prefix;
+      // (a candidate's key costs a binary search and two dependent global loads: the first digit's pass keeps it in LDS)
       for (int t = threadIdx.x; t < T; t += THREADS) {
-        int q, row;
-        locate(t, q, row);
-        const uint32_t key = ordered_bits(seg_scores[row]);
+        uint32_t key;
+        if (shift != 24 && t < KEYCAP) {
+          key = s_keys[t];
+        } else {
+          int q, row;
+          locate(t, q, row);
+          key = ordered_bits(seg_scores[row]);
+          if (t < KEYCAP) s_keys[t] = key;
+        }
         if (((key ^ prefix) & himask) == 0u) atomicAdd(&s_hist[(key >> shift) & 255u], 1);
       }
       __syncthreads();
+      const int remaining = s_remaining;
+      find_digit_desc(s_hist, remaining, s_digit);
+      __syncthreads();
       if (threadIdx.x == 0) {
-        int cum = 0, d = 255;
-        const int remaining = s_remaining;
-        while (d > 0 && cum + s_hist[d] < remaining) cum += s_hist[d--];
-        s_prefix = prefix | ((uint32_t)d << shift);
-        s_remaining = remaining - cum;                           // still to take among keys == prefix (so far)
+        s_prefix = prefix | ((uint32_t)s_digit[0] << shift);
+        s_remaining = remaining - s_digit[1];                    // still to take among keys == prefix (so far)
       }
       __syncthreads();
     }

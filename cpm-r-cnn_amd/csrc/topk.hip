@@ -26,6 +26,19 @@ __device__ __forceinline__ uint32_t order_key(float v) {
 
 constexpr int COPIES = 32;
 
+// A place in an LDS list for every lane that raises `flag`: one atomic per wavefront (the lanes of a wavefront that
+// reach this call together), not one per lane -- 2 000 selected elements took 2 000 turns on one LDS word.
+__device__ __forceinline__ int wave_slot(bool flag, int* counter) {
+  const unsigned long long m = __ballot(flag);
+  if (m == 0ull) return -1;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader, 64);
+  return flag ? base + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+}
+
 // f(value, index) over one row, every element once.  16-byte loads, two in flight per lane, when the row is aligned:
 // a single workgroup per row lives on memory-level parallelism.
 template <class F>
@@ -53,6 +66,49 @@ __device__ __forceinline__ void scan_row(const float* __restrict__ row, int n, F
   } else {
     for (int i = tid; i < n; i += TOPK_THREADS) f(row[i], i);
   }
+}
+
+// Ascending bitonic sort of the first k (<= 2048) entries of an LDS list by a workgroup of 1024 threads.  Thread t holds
+// elements t and t + 1024 in registers (places >= k count as the largest key): a compare-exchange whose partner is
+// t ^ stride is a register pair (stride 1024), a wavefront shuffle (stride < 64: 51 of the 66 steps) or an exchange
+// through the list with a barrier (strides 64 .. 512: 14 steps).  The plain network -- every step through LDS behind a
+// barrier -- took ~20 us of a one-workgroup kernel for 2 000 keys.
+__device__ __forceinline__ void bitonic_sort_2048(unsigned long long* list, int k) {
+  const int tid = threadIdx.x;
+  unsigned long long e[2] = {tid < k ? list[tid] : ~0ull, tid + 1024 < k ? list[tid + 1024] : ~0ull};
+  __syncthreads();
+  for (int size = 2; size <= 2048; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (stride == 1024) {                                       // (size 2048: one ascending run)
+        const unsigned long long a = e[0], b = e[1];
+        e[0] = a < b ? a : b;
+        e[1] = a < b ? b : a;
+        continue;
+      }
+      unsigned long long p[2];
+      if (stride < 64) {
+        p[0] = __shfl_xor(e[0], stride, 64);
+        p[1] = __shfl_xor(e[1], stride, 64);
+      } else {
+        list[tid] = e[0];
+        list[tid + 1024] = e[1];
+        __syncthreads();
+        p[0] = list[tid ^ stride];
+        p[1] = list[(tid ^ stride) + 1024];
+        __syncthreads();
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = tid + h * 1024;
+        const bool up = (i & size) == 0, low = (i & stride) == 0;   // ascending run; the pair's lower place
+        const unsigned long long mn = e[h] < p[h] ? e[h] : p[h], mx = e[h] < p[h] ? p[h] : e[h];
+        e[h] = (low == up) ? mn : mx;
+      }
+    }
+  }
+  list[tid] = e[0];
+  list[tid + 1024] = e[1];
+  __syncthreads();
 }
 
 // From the 256 x COPIES lane-private counters: the bin b with  count(bins > b) < want <= count(bins >= b), and
@@ -155,10 +211,8 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv, 
   __syncthreads();
   scan_row(row, n, [&](float v, int i) {
     const uint32_t key = order_key(v);
-    if (key > kth) {
-      const int p = atomicAdd(&s_count, 1);
-      sel[p] = ((unsigned long long)(~key) << 32) | (uint32_t)i;
-    }
+    const int p = wave_slot(key > kth, &s_count);
+    if (p >= 0) sel[p] = ((unsigned long long)(~key) << 32) | (uint32_t)i;
     // ties can be most of the row (saturated scores): one LDS atomic per wavefront, not per lane
     const unsigned long long m = __ballot(key == kth);
     if (key == kth && (m & ((1ull << (tid & 63)) - 1ull)) == 0) atomicAdd(&s_ties, __popcll(m));
@@ -168,10 +222,8 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv, 
   if (s_ties == want) {                         // every tie has a place: order does not matter here, the sort fixes it
     scan_row(row, n, [&](float v, int i) {
       const uint32_t key = order_key(v);
-      if (key == kth) {
-        const int p = atomicAdd(&s_count, 1);
-        sel[p] = ((unsigned long long)(~key) << 32) | (uint32_t)i;
-      }
+      const int p = wave_slot(key == kth, &s_count);
+      if (p >= 0) sel[p] = ((unsigned long long)(~key) << 32) | (uint32_t)i;
     });
   } else {
     // more ties than places: the lowest indices win.  Walk the row in index order, 1024 elements at a time, with a
@@ -203,23 +255,8 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_rows_kernel(TopkLevels lv, 
     for (int j = tid; j < k; j += TOPK_THREADS) out[j] = sel[j] + (unsigned long long)lo;     // index in the row
     return;
   }
-  // bitonic sort of the k composite keys (ascending == score descending, index ascending)
-  int np2 = 1;
-  while (np2 < k) np2 <<= 1;
-  for (int i = k + tid; i < np2; i += TOPK_THREADS) sel[i] = ~0ull;
-  __syncthreads();
-  for (int size = 2; size <= np2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < np2 / 2; t += TOPK_THREADS) {
-        const int lo = ((t / stride) * stride * 2) + (t % stride);
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const unsigned long long a = sel[lo], b2 = sel[hi];
-        if ((a > b2) == up) { sel[lo] = b2; sel[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
+  // the k composite keys in order (ascending == score descending, index ascending)
+  bitonic_sort_2048(sel, k);
   float* os = out_scores + (int64_t)blockIdx.x * k;
   int64_t* oi = out_idx + (int64_t)blockIdx.x * k;
   for (int j = tid; j < k; j += TOPK_THREADS) {
@@ -275,24 +312,12 @@ __global__ void __launch_bounds__(TOPK_THREADS) topk_merge_kernel(TopkLevels lv,
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < PER; ++i)
-    if (d[i] != 0ull && (d[i] & mask) >= prefix) sel[atomicAdd(&s_count, 1)] = ~d[i];
-  __syncthreads();
-  int np2 = 1;
-  while (np2 < k) np2 <<= 1;
-  for (int i = k + tid; i < np2; i += TOPK_THREADS) sel[i] = ~0ull;
-  __syncthreads();
-  for (int size = 2; size <= np2; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < np2 / 2; t += TOPK_THREADS) {
-        const int lo = ((t / stride) * stride * 2) + (t % stride);
-        const int hi = lo + stride;
-        const bool up = ((lo & size) == 0);
-        const unsigned long long a = sel[lo], b2 = sel[hi];
-        if ((a > b2) == up) { sel[lo] = b2; sel[hi] = a; }
-      }
-      __syncthreads();
-    }
+  {
+    const int p = wave_slot(d[i] != 0ull && (d[i] & mask) >= prefix, &s_count);
+    if (p >= 0) sel[p] = ~d[i];
   }
+  __syncthreads();
+  bitonic_sort_2048(sel, k);
   const float* row = lv.scores[blockIdx.y] + (int64_t)blockIdx.x * n_row;
   float* os = lv.out_scores[blockIdx.y] + (int64_t)blockIdx.x * k;
   int64_t* oi = lv.out_idx[blockIdx.y] + (int64_t)blockIdx.x * k;

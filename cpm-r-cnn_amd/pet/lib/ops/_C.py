@@ -75,9 +75,11 @@ def roi_align_backward(grad, rois, spatial_scale, pooled_height, pooled_width, b
     return gin
 
 
-def nms_segments(boxes, scores, labels, offsets, iou_threshold, topk=0):
+def nms_segments(boxes, scores, labels, offsets, iou_threshold, topk=0, presorted=False):
     """Batched device NMS over segments (host list `offsets`, len P+1).  Returns (keep, counts):
-    keep int64 [N] (segment-relative indices, valid in [off[p], off[p]+counts[p])), counts int32 [P] on device."""
+    keep int64 [N] (segment-relative indices, valid in [off[p], off[p]+counts[p])), counts int32 [P] on device.
+    presorted (unlabelled segments only): the caller vouches that the scores descend along every segment -- the stable
+    sort would be the identity and is skipped."""
     H.require_gpu(boxes, scores, labels)
     P = len(offsets) - 1
     N = int(offsets[-1])
@@ -92,8 +94,13 @@ def nms_segments(boxes, scores, labels, offsets, iou_threshold, topk=0):
     with H.guard(boxes.device):
         nbytes = H.lib().cpm_nms_workspace_bytes(off, P)
         ws = H.workspace(nbytes, boxes.device)
-        rc = H.lib().cpm_nms_batched(H.ptr(b), H.ptr(s), H.ptr(lab), off, P, H.f(iou_threshold), int(topk),
-                                     H.ptr(keep), H.ptr(counts), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
+        if presorted and lab is None:
+            rc = H.lib().cpm_nms_batched_presorted(H.ptr(b), H.ptr(s), off, P, H.f(iou_threshold), int(topk),
+                                                   H.ptr(keep), H.ptr(counts), H.ptr(ws), H.c_size_t(ws.numel()),
+                                                   H.stream())
+        else:
+            rc = H.lib().cpm_nms_batched(H.ptr(b), H.ptr(s), H.ptr(lab), off, P, H.f(iou_threshold), int(topk),
+                                         H.ptr(keep), H.ptr(counts), H.ptr(ws), H.c_size_t(ws.numel()), H.stream())
     H.check(rc, "nms_batched")
     return keep, counts
 

@@ -101,7 +101,8 @@ class RPNPostProcessor(torch.nn.Module):
                 seg_boxes.append(boxes.view(N * lvl_k[lvl], 4))
                 seg_scores.append(scores.reshape(N * lvl_k[lvl]))
             all_boxes, all_scores = torch.cat(seg_boxes, 0), torch.cat(seg_scores, 0)
-        keep, counts = nms_segments(all_boxes, all_scores, None, offsets, self.nms_thresh, 0)
+        # (every segment is a row of a sorted top-k: its scores descend, the NMS's stable sort would change nothing)
+        keep, counts = nms_segments(all_boxes, all_scores, None, offsets, self.nms_thresh, 0, presorted=True)
         # host round trip 1, split in two: the kept counts travel to pinned memory behind the NMS kernels and an
         # event marks the copy; the caller may queue unrelated device work (the RPN loss) before finish() waits for
         # that event only -- the device then stays busy while the host builds the index lists below

@@ -87,6 +87,12 @@ size_t cpm_nms_workspace_bytes(const int32_t* h_offsets, int P);
 int cpm_nms_batched(const float* boxes, const float* scores, const int64_t* labels, const int32_t* h_offsets,
                     int P, float iou_threshold, int topk, int64_t* keep, int32_t* keep_count, void* workspace,
                     size_t workspace_bytes, void* stream);
+/* The same for unlabelled segments whose scores ALREADY descend along each segment (the RPN's: its pre-NMS top-k,
+ * inference.py:79-84, leaves them sorted): the stable sort is the identity, so sort and gather are skipped.  Same keep
+ * lists as cpm_nms_batched on such input; the caller vouches for the order. */
+int cpm_nms_batched_presorted(const float* boxes, const float* scores, const int32_t* h_offsets, int P,
+                              float iou_threshold, int topk, int64_t* keep, int32_t* keep_count, void* workspace,
+                              size_t workspace_bytes, void* stream);
 
 /* box_iou: replaces _C.box_iou (pet/lib/ops/csrc/Box_ops/box_iou.h:13-30). out [N,K], no +1 */
 int cpm_box_iou(const float* boxes, int N, const float* query, int K, float* out, void* stream);

@@ -172,6 +172,29 @@ def test_nms_segments_rpn_shape(oracle, C):
         assert np.array_equal(keep[off[p]: off[p] + counts[p]], want)
 
 
+def test_nms_segments_presorted_equals_sorting_path(oracle, C):
+    """Segments whose scores already descend (rows of a sorted top-k, ties included): the entry that skips sort and
+    gather keeps the same boxes in the same order as the sorting one, and as the oracle."""
+    rng = np.random.default_rng(6)
+    sizes = [2000, 2048, 1, 65, 0, 1575, 273]
+    off = np.concatenate([[0], np.cumsum(sizes)])
+    boxes = _rand_boxes(rng, off[-1], span=900)
+    scores = np.concatenate([-np.sort(-np.round(rng.uniform(0, 1, n), 2)) for n in sizes]).astype(np.float32)   # ties
+    a, ca = C.nms_segments(dev(boxes), dev(scores), None, off.tolist(), 0.7, 0)
+    b, cb = C.nms_segments(dev(boxes), dev(scores), None, off.tolist(), 0.7, 0, presorted=True)
+    assert torch.equal(ca, cb)
+    ca = ca.cpu().numpy()
+    for p, n in enumerate(sizes):
+        assert torch.equal(a[off[p]: off[p] + ca[p]], b[off[p]: off[p] + ca[p]])
+        want = oracle.nms(boxes[off[p]:off[p + 1]], scores[off[p]:off[p + 1]], 0.7)
+        assert np.array_equal(b[off[p]: off[p] + ca[p]].cpu().numpy(), want)
+    c, cc = C.nms_segments(dev(boxes), dev(scores), None, off.tolist(), 0.7, 100, presorted=True)        # topk early-out
+    d, cd = C.nms_segments(dev(boxes), dev(scores), None, off.tolist(), 0.7, 100)
+    assert torch.equal(cc, cd)
+    for p in range(len(sizes)):
+        assert torch.equal(c[off[p]: off[p] + int(cc[p])], d[off[p]: off[p] + int(cc[p])])
+
+
 def test_nms_big_segment_global_sort(oracle, C):
     rng = np.random.default_rng(9)
     n = 20000                                   # > 16384: global bitonic path
