@@ -331,10 +331,22 @@ def hbm_kernel_rooflines(device, batch, h, w, rois_per_head):
     scores = torch.rand(n_seg * per, generator=gen).to(device)
     offs = [i * per for i in range(n_seg + 1)]
     t = timed(lambda: ops.nms_segments(boxes, scores, None, offs, 0.7, 0))
-    out["nms_batched (10 segments x 2000 boxes, thr 0.7)"] = (28 * n_seg * per, t)
-    return [{"kernel": k, "bound": "hbm", "algorithmic_bytes": int(b), "us": round(t * 1e6, 1),
+    out["nms_batched (10 segments x 2000 boxes, thr 0.7): sort + gather + tiles + sweep"] = (28 * n_seg * per, t)
+    # the call the training step makes: every segment is a row of the sorted pre-NMS top-k, so the sort is skipped
+    s_sorted = scores.view(n_seg, per).sort(dim=1, descending=True)[0].reshape(-1).contiguous()
+    t = timed(lambda: ops.nms_segments(boxes, s_sorted, None, offs, 0.7, 0, presorted=True))
+    out["nms_batched_presorted (the RPN's call: tiles + sweep)"] = (28 * n_seg * per, t)
+    res = []
+    for k, (b, t) in out.items():
+        e = {"kernel": k, "bound": "hbm", "algorithmic_bytes": int(b), "us": round(t * 1e6, 1),
              "achieved": round(b / t / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(b / t / 8e12, 4)}
-            for k, (b, t) in out.items()]
+        if k.startswith("nms"):
+            # 560 KB of boxes: a latency chain (64-box blocks resolved one after the other per segment), not a stream --
+            # the time is the figure, the GB/s are kept for the record's uniform shape only
+            e["bound"] = "latency"
+            e["note"] = "dependent chain of 32 block resolutions per segment; judge by us"
+        res.append(e)
+    return res
 
 
 def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3), batch=2):
