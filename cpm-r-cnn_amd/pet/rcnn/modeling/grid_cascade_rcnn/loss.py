@@ -15,7 +15,6 @@ from pet.lib.ops import l2_loss
 from pet.rcnn.core.config import cfg
 from pet.rcnn.modeling.grid_rcnn.loss import calc_sub_regions
 from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
-from pet.rcnn.utils.fused_sampling import batch_pos_neg_sample
 from pet.rcnn.utils.matcher import Matcher
 from pet.rcnn.utils.misc import cat
 from pet.utils.data.structures.boxlist_ops import boxlist_iou
@@ -65,7 +64,7 @@ class CLSLossComputation(object):
         lab = gt_labels[matched.clamp(min=0) + base]
         lab = torch.where(matched == Matcher.BELOW_LOW_THRESHOLD, 0, lab)
         lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1, lab)
-        pos, neg, _ = batch_pos_neg_sample(lab, counts, self.fg_bg_sampler.batch_size_per_image,
+        pos, neg, _ = ops.sample_pos_neg(lab, counts, self.fg_bg_sampler.batch_size_per_image,
                                            self.fg_bg_sampler.positive_fraction)
         # the one host round trip: the selection mask, carrying the labels of the selected rows along (-2 = not
         # selected) so that later label-driven selections (positives for the grid branch, negatives for the RSM

@@ -13,7 +13,6 @@ from pet.rcnn.core.config import cfg
 from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from pet.rcnn.utils.matcher import Matcher
 from pet.rcnn.utils.misc import concat_box_prediction_layers
-from pet.rcnn.utils.fused_sampling import batch_pos_neg_sample
 from pet.utils.data.structures.boxlist_ops import box_iou_plus1
 
 
@@ -69,7 +68,7 @@ class RPNLossComputation(object):
                 lab = torch.where(matched == Matcher.BETWEEN_THRESHOLDS, -1.0, lab)
             if "not_visibility" in self.discard_cases:
                 lab = torch.where(vis, lab, -1.0)
-        pos, neg, quota = batch_pos_neg_sample(lab, [per] * n_img, self.fg_bg_sampler.batch_size_per_image,
+        pos, neg, quota = ops.sample_pos_neg(lab, [per] * n_img, self.fg_bg_sampler.batch_size_per_image,
                                                self.fg_bg_sampler.positive_fraction)
         if getattr(objectness[0], "_cpm_rpn_sparse", False):
             # the head is one autograd node (ops.rpn_head): tell it which anchors this loss sums over -- everywhere else

@@ -118,32 +118,41 @@ def _bcast_worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _run_world2(worker):
+    """two spawned ranks over gloo on 127.0.0.1; a rendezvous that fails (the probed port was taken in between, a
+    slow spawn) is tried once more on another port -- an assertion inside a worker is not retried"""
+    import queue
+    for attempt in range(2):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=worker, args=(r, 2, port, q)) for r in range(2)]
+        for p in procs:
+            p.start()
+        try:
+            results = [q.get(timeout=180) for _ in procs]
+        except queue.Empty:
+            results = []
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.kill()
+        if sorted(results) == [(0, "ok"), (1, "ok")]:
+            return
+        rendezvous = not results or any("AssertionError" not in r[1] and r[1] != "ok" for r in results)
+        if attempt == 0 and rendezvous and not any("AssertionError" in r[1] for r in results):
+            continue
+        assert sorted(results) == [(0, "ok"), (1, "ok")], results
+
+
 def test_broadcast_initial_state_world2():
     """ranks that initialise their heads unseeded must hold rank 0's weights before the first step
     (the reference gets this from DistributedDataParallel's constructor, tools/rcnn/train_net.py:134-136)."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bcast_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+    _run_world2(_bcast_worker)
 
 
 def test_flat_reducer_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(results) == [(0, "ok"), (1, "ok")], results
+    _run_world2(_worker)
 
 
 def test_lr_schedule_matches_reference_formula():
