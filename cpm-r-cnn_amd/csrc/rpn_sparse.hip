@@ -31,6 +31,7 @@ struct RpnLevels {
   int off[MAXL + 1];            // first anchor of the level inside an image's run (per_image = off[n_levels])
   const float* dlog[MAXL];      // [N][H][W][A]
   const float* dbox[MAXL];      // [N][H][W][4A]
+  long long dlog_ns[MAXL], dbox_ns[MAXL];   // floats between two images of dlog / dbox (H * W * A | 4A when dense)
   const float* t[MAXL];         // [N][H][W][C]   relu(conv(feature))
   const float* feat[MAXL];      // [N][H][W][C]
   float* dfeat[MAXL];           // [N][H][W][C]   (scatter kernel)
@@ -147,10 +148,11 @@ __global__ __launch_bounds__(256) void rpn_rows_kernel(RpnLevels L, const int* _
   const int Wl = L.W[l], Hl = L.H[l];
   const int w = p % Wl, h = p / Wl;
   const size_t pb = ((size_t)n * Hl + h) * Wl + w;
-  const float dl = L.dlog[l][pb * A + a];
+  const size_t pin = (size_t)h * Wl + w;                // pixel inside its image
+  const float dl = L.dlog[l][(size_t)n * L.dlog_ns[l] + pin * A + a];
   float db[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) db[j] = L.dbox[l][pb * 4 * A + 4 * a + j];
+  for (int j = 0; j < 4; ++j) db[j] = L.dbox[l][(size_t)n * L.dbox_ns[l] + pin * 4 * A + 4 * a + j];
   const float* tp = L.t[l] + pb * C;
   for (int c = tid; c < C; c += 256) {
     const float tv = tp[c];
@@ -224,7 +226,8 @@ static int fill_levels(RpnLevels& L, int n_levels, const int* hs, const int* ws,
 CPM_EXPORT int cpm_rpn_sparse_rows(const int32_t* idx, int cap, int n_img, int n_levels, const int* hs, const int* ws, int A,
                                    int C, const float* const* dlog, const float* const* dbox, const float* const* t,
                                    const float* const* feat, const float* w_cls, const float* w_box, float* DT, float* Gc,
-                                   float* Gb, float* T, float* X, int32_t* pix4, void* stream) {
+                                   float* Gb, float* T, float* X, int32_t* pix4, const int64_t* dlog_image_stride,
+                                   const int64_t* dbox_image_stride, void* stream) {
   CPM_REQUIRE(idx && dlog && dbox && t && feat && w_cls && w_box && DT && Gc && Gb && T && X && pix4, "null pointer");
   CPM_REQUIRE(cap >= 1 && n_img >= 1, "bad sizes");
   RpnLevels L = {};
@@ -233,6 +236,10 @@ CPM_EXPORT int cpm_rpn_sparse_rows(const int32_t* idx, int cap, int n_img, int n
   for (int l = 0; l < n_levels; ++l) {
     CPM_REQUIRE(dlog[l] && dbox[l] && t[l] && feat[l], "null level pointer");
     L.dlog[l] = dlog[l]; L.dbox[l] = dbox[l]; L.t[l] = t[l]; L.feat[l] = feat[l];
+    L.dlog_ns[l] = dlog_image_stride ? dlog_image_stride[l] : (long long)hs[l] * ws[l] * A;
+    L.dbox_ns[l] = dbox_image_stride ? dbox_image_stride[l] : (long long)hs[l] * ws[l] * 4 * A;
+    CPM_REQUIRE(L.dlog_ns[l] >= (long long)hs[l] * ws[l] * A && L.dbox_ns[l] >= (long long)hs[l] * ws[l] * 4 * A,
+                "image stride below the image's size");
   }
   hipLaunchKernelGGL(rpn_rows_kernel, dim3((unsigned)cap), dim3(256), 0, (hipStream_t)stream, L, idx, n_img, w_cls, w_box,
                      DT, Gc, Gb, T, X, (int4*)pix4);

@@ -745,6 +745,13 @@ def _krsc_matrix(t):
     return v.reshape(k, r * s * c, 1, 1)
 
 
+def _image_dense(g):
+    """a [N, ch, H, W] gradient whose every image is a dense NHWC block (the images may lie further apart)"""
+    n, ch, h, w = g.shape
+    return (g.dtype == torch.float32 and g.stride(1) == 1 and g.stride(3) == ch and g.stride(2) == w * ch
+            and g.stride(0) >= h * w * ch)
+
+
 class _RPNHeadFn(Function):
     """(objectness_l, deltas_l for every level l) = RPNHead(features): shared 3x3 conv + ReLU, the two 1x1 predictors."""
 
@@ -790,8 +797,13 @@ class _RPNHeadFn(Function):
 
         def zmap(x, ch):
             return torch.zeros((x.shape[0], ch, x.shape[2], x.shape[3]), device=dev).contiguous(memory_format=CL)
-        dcs = [nhwc(g) if g is not None else zmap(x, a) for g, x in zip(grads[:n], xs)]
-        dbs = [nhwc(g) if g is not None else zmap(x, 4 * a) for g, x in zip(grads[n:], xs)]
+        # (the sparse path reads <= cap elements of these maps: it takes them as they come -- slices of the loss's one
+        # gradient tensor, dense inside an image -- instead of paying ten transposing copies; see _image_dense)
+        sample = _take_rpn_sample(ctx.out_ptrs)
+        sparse = sample is not None and _RPN_SPARSE and (_RPN_SPARSE == 2 or not H.deterministic())
+        raw = sparse and all(g is not None and _image_dense(g) for g in grads[:2 * n])
+        dcs = [g if raw else (nhwc(g) if g is not None else zmap(x, a)) for g, x in zip(grads[:n], xs)]
+        dbs = [g if raw else (nhwc(g) if g is not None else zmap(x, 4 * a)) for g, x in zip(grads[n:], xs)]
         # gradient buffers of the six parameters: the flat optimizer's slice (accumulated in place) or a fresh one
         bufs, rets = [], []
         for i, like in enumerate((wm, None, wcm, None, wbm, None)):
@@ -813,10 +825,9 @@ class _RPNHeadFn(Function):
                 dfe.append(h["acc"]); dret.append(None)
             else:
                 dfe.append(False); dret.append(None)        # made below (zero-filled / fresh), the two paths differ
-        sample = _take_rpn_sample(ctx.out_ptrs)
         # (_RPN_SPARSE == 2: also under deterministic mode -- the tests compare the two formulations there, where
         # everything else of a step is reproducible)
-        if sample is not None and _RPN_SPARSE and (_RPN_SPARSE == 2 or not H.deterministic()):
+        if sparse:
             _RPNHeadFn._backward_sparse(ctx, sample, dcs, dbs, xs, ts, wm, wcm, wbm, bufs, dfe, dret)
         else:
             _RPNHeadFn._backward_dense(ctx, dcs, dbs, xs, ts, wm, wcm, wbm, bufs, dfe, dret)
@@ -850,10 +861,12 @@ class _RPNHeadFn(Function):
         arr = lambda ts_: (P_ * n)(*[t.data_ptr() if t is not None else None for t in ts_])
         hs = (H.ctypes.c_int * n)(*[int(x.shape[2]) for x in xs])
         ws = (H.ctypes.c_int * n)(*[int(x.shape[3]) for x in xs])
+        i64 = H.ctypes.c_int64 * n
         with H.guard(dev):
             rc = H.lib().cpm_rpn_sparse_rows(H.ptr(idx), cap, n_img, n, hs, ws, int(a), int(c), arr(dcs), arr(dbs),
                                              arr(ts), arr(xs), H.ptr(wcm), H.ptr(wbm), H.ptr(DT), H.ptr(Gc), H.ptr(Gb),
-                                             H.ptr(T), H.ptr(X), H.ptr(pix), H.stream())
+                                             H.ptr(T), H.ptr(X), H.ptr(pix), i64(*[int(g.stride(0)) for g in dcs]),
+                                             i64(*[int(g.stride(0)) for g in dbs]), H.stream())
         H.check(rc, "rpn_sparse_rows")
         img = lambda m: m.view(1, cap, 1, m.shape[1]).permute(0, 3, 1, 2)       # [1, channels, rows, 1], NHWC memory
         # the 3x3 conv: dW = DT^T X (+ the bias sum), the predictors: dWcls = Gc^T T, dWbox = Gb^T T

@@ -50,14 +50,18 @@ class _RoIAlignFPN(Function):
         ctx.save_for_backward(r)
         ctx.meta = (output_size, tuple(float(s) for s in scales), int(sampling_ratio), lvl_min, lvl_max, canonical,
                     [tuple(f.shape) for f in feats])
-        ctx.mark_non_differentiable(levels)
-        return out, levels[:K]
+        lv = levels[:K]
+        ctx.mark_non_differentiable(lv)
+        ctx.set_materialize_grads(False)       # (no zero-filled "gradient" of the level indices per backward call)
+        return out, lv
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_out, _):
         r, = ctx.saved_tensors
         (ph, pw), scales, ratio, lvl_min, lvl_max, (s0, l0, eps), shapes = ctx.meta
+        if grad_out is None:                   # nobody differentiated the pooled features
+            return (None,) * (7 + len(shapes))
         g = _nhwc(grad_out)
         K = r.shape[0]
         C = int(shapes[0][1])

@@ -266,6 +266,9 @@ int cpm_rpn_pred_backward_data(const float* const* dy_cls, const float* const* d
  *     gate applied), Gc [cap][A] / Gb [cap][4A] (the predictors' output gradients), T [cap][C] (their input), X
  *     [cap][9C] (the 3x3 conv's input patch, tap-major = the KRSC weight's column order), pix4 int32 [cap][4] = (level,
  *     image, h, w) or level -1; dlog / dbox / t / feat: per-level NHWC maps [N][H_l][W_l][A | 4A | C | C];
+ *     dlog_image_stride / dbox_image_stride (HOST, per level, in floats; NULL = dense): the distance between two images
+ *     of dlog_l / dbox_l -- the loss hands back slices of ONE [N][all anchors][1 | 4] tensor, whose images lie a whole
+ *     anchor row apart, and only <= cap elements of them are read;
  *   cpm_rpn_sparse_scatter: dfeat_l[n][h + dr][w + ds][:] += dX[row][(tap, :)] (float atomics; a NULL level is skipped).
  * Replaces, for those layers, the dense autograd path the reference takes through nn.Conv2d. */
 int cpm_mask_compact(const uint8_t* pos, const uint8_t* neg, int64_t total, int cap, int32_t* idx, int32_t* count,
@@ -273,7 +276,8 @@ int cpm_mask_compact(const uint8_t* pos, const uint8_t* neg, int64_t total, int 
 int cpm_rpn_sparse_rows(const int32_t* idx, int cap, int n_img, int n_levels, const int* hs, const int* ws, int A, int C,
                         const float* const* dlog, const float* const* dbox, const float* const* t,
                         const float* const* feat, const float* w_cls, const float* w_box, float* DT, float* Gc, float* Gb,
-                        float* T, float* X, int32_t* pix4, void* stream);
+                        float* T, float* X, int32_t* pix4, const int64_t* dlog_image_stride,
+                        const int64_t* dbox_image_stride, void* stream);
 int cpm_rpn_sparse_scatter(const int32_t* pix4, int cap, int n_levels, const int* hs, const int* ws, int C,
                            const float* dX, float* const* dfeat, void* stream);
 /* The ResNet / ResNeXt stem as one kernel (bf16x3 arithmetic only): y = relu?(conv7x7 / stride 2 / pad 3 (x) * scale +
