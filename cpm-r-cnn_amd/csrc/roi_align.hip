@@ -277,11 +277,31 @@ struct GatherLevels {
   int tiles_y[5], tiles_x[5];
 };
 
-__global__ void __launch_bounds__(64) roi_bin_tiles(Levels L, GatherLevels G, const float* __restrict__ rois, int K,
-                                                    int B, int PH, int PW, int cap, int* __restrict__ tile_count,
+// Several RoI sets differentiated by ONE pass over the tiles: the heads of a training step pool the same pyramid with
+// their own RoIs, pooled sizes and gradient tensors (cls 7x7, three grid stages 14x14, RSM 7x7).  RoI n of the launch
+// belongs to set s with first[s] <= n < first[s + 1]; its gradient rows are grad[s] + ((n - first[s]) * ph * pw + bin) * C.
+constexpr int GSETS = 8;
+struct RoiSets {
+  const float* rois[GSETS];
+  const float* grad[GSETS];
+  int first[GSETS + 1];
+  int ph[GSETS], pw[GSETS], ratio[GSETS];
+  int n;
+};
+
+__device__ __forceinline__ int set_of(const RoiSets& S, int n) {
+  int s = 0;
+  while (s + 1 < S.n && n >= S.first[s + 1]) ++s;
+  return s;
+}
+
+__global__ void __launch_bounds__(64) roi_bin_tiles(Levels L, GatherLevels G, RoiSets S, int K,
+                                                    int B, int cap, int* __restrict__ tile_count,
                                                     int* __restrict__ tile_list) {
   const int n = blockIdx.x;                                  // one wavefront per RoI, lanes sweep its tiles
-  const float* roi = rois + 5 * (size_t)n;
+  const int set = set_of(S, n);
+  const int PH = S.ph[set], PW = S.pw[set];
+  const float* roi = S.rois[set] + 5 * (size_t)(n - S.first[set]);
   const int lv = map_level(roi, L);
   const int H = L.l[lv].H, W = L.l[lv].W;
   const Geom g = roi_geometry(roi, L.l[lv].scale, PH, PW, 1, false);
@@ -357,13 +377,14 @@ __device__ void axis_row(float start, float bin, int grid, int P, int size, int 
   *cnt = nz_hi >= nz_lo ? nz_hi - nz_lo + 1 : 0;
 }
 
-__global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __restrict__ grad, Levels L, GatherLevels G,
-                                                            const float* __restrict__ rois, int C, int PH, int PW,
-                                                            int sampling_ratio, int cap,
+__global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(Levels L, GatherLevels G, RoiSets S, int C, int cap,
                                                             const int* __restrict__ tile_count,
                                                             const int* __restrict__ tile_list,
                                                             const int* __restrict__ active_count,
                                                             const int* __restrict__ active, int accumulate_mask) {
+  __shared__ const float* s_grad[GSETS];                    // the sets' gradient tensors, indexed per list entry
+  __shared__ int s_pw[GCHUNK];                              // pooled width of the chunk's RoIs (bin index = row * pw + col)
+  if (threadIdx.x < GSETS) s_grad[threadIdx.x] = threadIdx.x < S.n ? S.grad[threadIdx.x] : nullptr;
   __shared__ float s_wy[GCHUNK][GT * GBINS + 1];            // +1: lane-per-RoI reads hit distinct banks
   __shared__ float s_wx[GCHUNK][GT * GBINS + 1];
   __shared__ int s_fy[GCHUNK][GT + 1], s_ny[GCHUNK][GT + 1], s_fx[GCHUNK][GT + 1], s_nx[GCHUNK][GT + 1];
@@ -407,7 +428,6 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
         __syncthreads();
       }
   }
-  const int nbins = PH * PW;
   for (int c0 = 0; c0 < C; c0 += 256) {                     // 64 lanes x float4 per pass over the channels
     const int c = c0 + lane * 4;
     const bool c_ok = c < C;
@@ -420,11 +440,15 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
       for (int wi = tid; wi < nch * 2 * GT; wi += GTHREADS) { // one work item per (RoI, axis, tile row / column)
         const int j = wi / (2 * GT), rem = wi - j * (2 * GT), axis = rem / GT, r = rem - axis * GT;
         const int n = sorted ? s_sorted[chunk + j] : list[chunk + j];
-        const Geom g = roi_geometry(rois + 5 * (size_t)n, L.l[lv].scale, PH, PW, sampling_ratio, false);
+        const int set = set_of(S, n), PH = S.ph[set], PW = S.pw[set];
+        const Geom g = roi_geometry(S.rois[set] + 5 * (size_t)(n - S.first[set]), L.l[lv].scale, PH, PW, S.ratio[set],
+                                    false);
         if (axis == 0) {
           axis_row(g.start_h, g.bin_h, g.grid_h, PH, H, ty0 + r, &s_wy[j][r * GBINS], &s_fy[j][r], &s_ny[j][r]);
           if (r == 0) {
-            s_roi[j] = n;
+            // the RoI's first gradient row, tagged with its set (rows of one set stay below 2^24: K <= 8192, 256 bins)
+            s_roi[j] = (set << 24) | ((n - S.first[set]) * PH * PW);
+            s_pw[j] = PW;
             s_inv[j] = 1.f / (float)(g.grid_h * g.grid_w);
           }
         } else {
@@ -448,7 +472,8 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
                 w8[u] = s_ew[wave][e + u];
-                v[u] = *(const float4*)(grad + (size_t)s_eo[wave][e + u] * C + c);
+                const int eo = s_eo[wave][e + u];
+                v[u] = *(const float4*)(s_grad[eo >> 24] + (size_t)(eo & 0xFFFFFF) * C + c);
               }
 #pragma unroll
               for (int u = 0; u < 8; ++u) {
@@ -458,7 +483,8 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
             }
             for (; e < ne; ++e) {
               const float w = s_ew[wave][e];
-              const float4 v = *(const float4*)(grad + (size_t)s_eo[wave][e] * C + c);
+              const int eo = s_eo[wave][e];
+              const float4 v = *(const float4*)(s_grad[eo >> 24] + (size_t)(eo & 0xFFFFFF) * C + c);
               acc[pi].x += w * v.x; acc[pi].y += w * v.y; acc[pi].z += w * v.z; acc[pi].w += w * v.w;
             }
           }
@@ -466,13 +492,14 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
         };
         // collection, one lane per RoI of the chunk: count this pixel's non-zero bins, exclusive prefix over the
         // lanes (RoI order = list order, so the summation order stays fixed), then each lane writes its entries
-        int ny = 0, nx = 0, fy = 0, fx = 0, base = 0, cnt = 0;
+        int ny = 0, nx = 0, fy = 0, fx = 0, base = 0, cnt = 0, PW = 0;
         float inv = 0.f;
         if (lane < nch) {
           ny = s_ny[lane][r]; nx = s_nx[lane][cc];
           if (ny != 0 && nx != 0) {
             fy = s_fy[lane][r]; fx = s_fx[lane][cc];
-            base = s_roi[lane] * nbins;
+            base = s_roi[lane];
+            PW = s_pw[lane];
             inv = s_inv[lane];
             for (int a = 0; a < ny; ++a) {
               const float wy = s_wy[lane][r * GBINS + fy + a] * inv;
@@ -510,7 +537,7 @@ __global__ void __launch_bounds__(GTHREADS) roi_align_bwd_gather(const float* __
             const int jy = s_ny[j][r], jx = s_nx[j][cc];
             if (jy == 0 || jx == 0) continue;
             const int gy = s_fy[j][r], gx = s_fx[j][cc];
-            const int jbase = s_roi[j] * nbins;
+            const int jbase = s_roi[j], PW = s_pw[j];
             const float jinv = s_inv[j];
             for (int a = 0; a < jy; ++a) {
               const float wy = s_wy[j][r * GBINS + gy + a] * jinv;
@@ -787,18 +814,14 @@ CPM_EXPORT size_t cpm_roi_align_fpn_gather_workspace_bytes(const int* hs, const 
   return tiles * sizeof(int) * (2 + (size_t)(K > 0 ? K : 1)) + 64;
 }
 
-CPM_EXPORT int cpm_roi_align_fpn_backward_gather(const float* grad_output, float* const* grad_feats, const int* hs,
-                                                 const int* ws, const float* scales, int num_levels,
-                                                 const float* rois, int K, int B, int C, int pooled_h, int pooled_w,
-                                                 int sampling_ratio, float k_min, float k_max, float canonical_scale,
-                                                 float canonical_level, float eps, int accumulate_mask,
-                                                 void* workspace, size_t workspace_bytes, void* stream) {
-  CPM_REQUIRE(K >= 0 && B > 0 && C > 0 && pooled_h > 0 && pooled_w > 0, "bad shape");
-  CPM_REQUIRE(pooled_h <= GBINS && pooled_w <= GBINS, "pooled size above 16: use cpm_roi_align_fpn_backward");
+static int backward_gather_sets(const RoiSets& S, int K, float* const* grad_feats, const int* hs, const int* ws,
+                                const float* scales, int num_levels, int B, int C, float k_min, float k_max,
+                                float canonical_scale, float canonical_level, float eps, int accumulate_mask,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(K >= 0 && B > 0 && C > 0, "bad shape");
   CPM_REQUIRE(C % 4 == 0, "C must be a multiple of 4");
   CPM_REQUIRE(K <= 8192, "more than 8192 RoIs: use cpm_roi_align_fpn_backward");
   CPM_REQUIRE(grad_feats && hs && ws && scales, "null pointer");
-  CPM_REQUIRE(K == 0 || (grad_output && rois), "null pointer");
   Levels L = {};
   CPM_REQUIRE(fill_levels(L, nullptr, grad_feats, hs, ws, scales, num_levels, k_min, k_max, canonical_scale,
                           canonical_level, eps) == CPM_OK, "bad level table");
@@ -821,18 +844,63 @@ CPM_EXPORT int cpm_roi_align_fpn_backward_gather(const float* grad_output, float
         hipMemsetAsync(grad_feats[i], 0, (size_t)B * hs[i] * ws[i] * C * sizeof(float), s) != hipSuccess)
       return CPM_ELAUNCH;
   if (K == 0) return CPM_OK;
-  hipLaunchKernelGGL(roi_bin_tiles, dim3(K), dim3(64), 0, s, L, G, rois, K, B, pooled_h, pooled_w, cap, tile_count,
-                     tile_list);
+  hipLaunchKernelGGL(roi_bin_tiles, dim3(K), dim3(64), 0, s, L, G, S, K, B, cap, tile_count, tile_list);
   {
     int rc = cpm::check_launch("roi_align gather: binning");
     if (rc != CPM_OK) return rc;
   }
   hipLaunchKernelGGL(roi_active_tiles, dim3(cpm::cdiv(tiles, 256)), dim3(256), 0, s, tile_count, tiles, active_count,
                      active);
-  hipLaunchKernelGGL(roi_align_bwd_gather, dim3(tiles < 2048 ? tiles : 2048), dim3(GTHREADS), 0, s, grad_output, L, G,
-                     rois, C, pooled_h, pooled_w, sampling_ratio, cap, tile_count, tile_list, active_count, active,
-                     accumulate_mask);
+  hipLaunchKernelGGL(roi_align_bwd_gather, dim3(tiles < 2048 ? tiles : 2048), dim3(GTHREADS), 0, s, L, G, S, C, cap,
+                     tile_count, tile_list, active_count, active, accumulate_mask);
   return cpm::check_launch("roi_align gather: tiles");
+}
+
+CPM_EXPORT int cpm_roi_align_fpn_backward_gather(const float* grad_output, float* const* grad_feats, const int* hs,
+                                                 const int* ws, const float* scales, int num_levels,
+                                                 const float* rois, int K, int B, int C, int pooled_h, int pooled_w,
+                                                 int sampling_ratio, float k_min, float k_max, float canonical_scale,
+                                                 float canonical_level, float eps, int accumulate_mask,
+                                                 void* workspace, size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(pooled_h > 0 && pooled_w > 0, "bad shape");
+  CPM_REQUIRE(pooled_h <= GBINS && pooled_w <= GBINS, "pooled size above 16: use cpm_roi_align_fpn_backward");
+  CPM_REQUIRE(K == 0 || (grad_output && rois), "null pointer");
+  RoiSets S = {};
+  S.n = 1;
+  S.rois[0] = rois; S.grad[0] = grad_output; S.first[0] = 0; S.first[1] = K;
+  S.ph[0] = pooled_h; S.pw[0] = pooled_w; S.ratio[0] = sampling_ratio;
+  return backward_gather_sets(S, K, grad_feats, hs, ws, scales, num_levels, B, C, k_min, k_max, canonical_scale,
+                              canonical_level, eps, accumulate_mask, workspace, workspace_bytes, stream);
+}
+
+CPM_EXPORT int cpm_roi_align_fpn_backward_gather_sets(int n_sets, const float* const* grad_outputs,
+                                                      const float* const* rois, const int* Ks, const int* pooled_hs,
+                                                      const int* pooled_ws, const int* sampling_ratios,
+                                                      float* const* grad_feats, const int* hs, const int* ws,
+                                                      const float* scales, int num_levels, int B, int C, float k_min,
+                                                      float k_max, float canonical_scale, float canonical_level,
+                                                      float eps, int accumulate_mask, void* workspace,
+                                                      size_t workspace_bytes, void* stream) {
+  CPM_REQUIRE(n_sets >= 1 && n_sets <= GSETS, "1 .. 8 RoI sets");
+  CPM_REQUIRE(grad_outputs && rois && Ks && pooled_hs && pooled_ws && sampling_ratios, "null pointer");
+  RoiSets S = {};
+  int total = 0;
+  for (int i = 0; i < n_sets; ++i) {
+    CPM_REQUIRE(Ks[i] >= 0 && pooled_hs[i] > 0 && pooled_ws[i] > 0 && pooled_hs[i] <= GBINS && pooled_ws[i] <= GBINS,
+                "bad set (pooled size 1 .. 16)");
+    if (Ks[i] == 0) continue;                                 // an empty set takes no slot
+    CPM_REQUIRE(grad_outputs[i] && rois[i], "null set pointer");
+    CPM_REQUIRE((((uintptr_t)grad_outputs[i]) & 15) == 0, "gradients must be 16-byte aligned");
+    const int k = S.n++;
+    S.rois[k] = rois[i]; S.grad[k] = grad_outputs[i];
+    S.first[k] = total;
+    S.ph[k] = pooled_hs[i]; S.pw[k] = pooled_ws[i]; S.ratio[k] = sampling_ratios[i];
+    total += Ks[i];
+  }
+  S.first[S.n] = total;
+  if (S.n == 0) S.n = 1;                                      // all empty: K == 0 below clears the fresh maps only
+  return backward_gather_sets(S, total, grad_feats, hs, ws, scales, num_levels, B, C, k_min, k_max, canonical_scale,
+                              canonical_level, eps, accumulate_mask, workspace, workspace_bytes, stream);
 }
 
 CPM_EXPORT int cpm_pool_points_interp_forward(const float* input, const float* pts, int K, int B, int C, int H,

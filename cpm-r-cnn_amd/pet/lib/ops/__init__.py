@@ -2,7 +2,7 @@
 every other name of the reference package as an importable off-path placeholder (offpath.py)."""
 from .nms import nms, ml_nms, nms_segments, soft_nms, ml_soft_nms, soft_nms_segments
 from .roi_align import roi_align, ROIAlign
-from .pooler_fpn import roi_align_fpn
+from .pooler_fpn import roi_align_fpn, roi_backward_group
 from .affine import AffineChannel2d
 from .losses import smooth_l1_loss, l2_loss, l2_loss_nosync, l2_loss_fused
 from .modules import Conv2d, Linear, ConvTranspose2d, GroupNorm, ReLU

@@ -103,6 +103,16 @@ def deterministic():
     return _deterministic
 
 
+# Work a backward node has put off until a later point of the same backward pass (pooler_fpn: the heads' RoIAlign
+# gradients, differentiated together).  Whoever is about to read what such work produces runs it first.
+deferred = []
+
+
+def run_deferred():
+    while deferred:
+        deferred.pop(0)()
+
+
 _UNIT_SEEDS = {}
 
 

@@ -500,6 +500,8 @@ class _ConvFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
+        if H.deferred:                      # gradient work parked by earlier nodes (pooler_fpn) may be part of dy
+            H.run_deferred()
         x, w, scale, y = ctx.saved_tensors
         stride, pad, dil, groups, relu, res_mode, x_shape, res_shape = ctx.cfg
         has_scale, has_shift, has_res = ctx.has
@@ -788,6 +790,8 @@ class _RPNHeadFn(Function):
     @staticmethod
     @once_differentiable
     def backward(ctx, *grads):
+        if H.deferred:
+            H.run_deferred()
         n = ctx.n
         wm, wcm, wbm = ctx.saved_tensors[:3]
         xs, ts = ctx.saved_tensors[3:3 + n], ctx.saved_tensors[3 + n:3 + 2 * n]

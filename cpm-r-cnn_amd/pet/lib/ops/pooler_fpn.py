@@ -4,6 +4,7 @@ Replaces the loop in Pooler.forward (pet/rcnn/utils/poolers.py:113-132: 4 `nonze
 4 RoIAlign launches, 4 scatters) with cpm_roi_align_fpn_{forward,backward}.  Feature maps are NHWC.
 """
 import ctypes
+import os
 
 import torch
 from torch.autograd import Function
@@ -25,10 +26,71 @@ def _nhwc(t):
         memory_format=torch.channels_last)
 
 
+_GROUPED = os.environ.get("CPM_ROI_BWD_GROUP", "1") != "0"
+
+
+class _RoiBackwardGroup(object):
+    """The RoIAlign calls of one forward pass on one pyramid whose gradients are formed by ONE pass over the pyramid's
+    tiles (cpm_roi_align_fpn_backward_gather_sets): each call's backward node parks its pooled gradient here, the last
+    one -- or whoever needs the maps first (H.run_deferred) -- launches.  The gather kernel's time is per tile, not per
+    RoI (a workgroup per 8x8 tile walks dependent phases whatever the list length): five calls of a step visit the
+    tiles five times, 0.74 ms; together once."""
+
+    def __init__(self):
+        self.registered = 0
+        self.pending = []
+        self.meta = None
+        self.holders = None
+
+    def flush(self):
+        if not self.pending:
+            return
+        from . import conv as C
+        pend, self.pending = self.pending, []
+        scales, lvl_min, lvl_max, (s0, l0, eps), shapes = self.meta
+        accs = []
+        for h in self.holders:
+            C._wait_readers(h)
+            accs.append(h["acc"])
+        n = len(accs)
+        hs, ws, sc = _tables(accs, scales)
+        m = len(pend)
+        vp, ip = ctypes.c_void_p * m, ctypes.c_int * m
+        dev = accs[0].device
+        ktot = sum(int(r.shape[0]) for _, r, _, _, _ in pend)
+        with H.guard(dev):
+            need = H.lib().cpm_roi_align_fpn_gather_workspace_bytes(hs, ws, n, int(shapes[0][0]), ktot)
+            wsb = H.workspace(need, dev)
+            rc = H.lib().cpm_roi_align_fpn_backward_gather_sets(
+                m, vp(*[g.data_ptr() for g, _, _, _, _ in pend]), vp(*[r.data_ptr() for _, r, _, _, _ in pend]),
+                ip(*[int(r.shape[0]) for _, r, _, _, _ in pend]), ip(*[p[2] for p in pend]), ip(*[p[3] for p in pend]),
+                ip(*[p[4] for p in pend]), (ctypes.c_void_p * n)(*[t.data_ptr() for t in accs]), hs, ws, sc, n,
+                int(shapes[0][0]), int(shapes[0][1]), H.f(lvl_min), H.f(lvl_max), H.f(s0), H.f(l0), H.f(eps),
+                (1 << n) - 1, H.ptr(wsb), H.c_size_t(wsb.numel()), H.stream())
+        H.check(rc, "roi_align_fpn_backward_gather_sets")
+
+
+def roi_backward_group(feats):
+    """Called by the model once per training forward, before its heads pool `feats`: the RoIAlign calls on these maps
+    are then differentiated together (see _RoiBackwardGroup).  Only for maps opted into shared gradient accumulation
+    (conv.mark_shared_grad): their gradient tensors are written in place, which is what lets a node answer autograd
+    before its contribution has been added."""
+    if not (_GROUPED and torch.is_grad_enabled() and feats and feats[0].is_cuda):
+        return None
+    if getattr(feats[0], "_cpm_gacc", None) is None:      # (a call whose maps lack an accumulator goes alone: backward)
+        return None
+    grp = _RoiBackwardGroup()
+    feats[0]._cpm_roi_group = grp
+    return grp
+
+
 class _RoIAlignFPN(Function):
     @staticmethod
     def forward(ctx, rois, output_size, scales, sampling_ratio, lvl_min, lvl_max, canonical, *feats):
         H.require_gpu(rois, *feats)
+        ctx.group = getattr(feats[0], "_cpm_roi_group", None) if any(ctx.needs_input_grad[7:]) else None
+        if ctx.group is not None:
+            ctx.group.registered += 1
         feats = [_nhwc(f) for f in feats]
         B, C = feats[0].shape[:2]
         K = rois.shape[0]
@@ -69,6 +131,31 @@ class _RoIAlignFPN(Function):
         # scatter kernel otherwise.  A level whose feature map is opted into shared gradient accumulation and already
         # has an accumulator gets this call's contribution added there (and reports None to autograd).
         gather = ph <= 16 and pw <= 16 and C % 4 == 0 and K <= 8192
+        grp = ctx.group
+        meta = (scales, lvl_min, lvl_max, (s0, l0, eps), shapes)
+        if (grp is not None and gather and all(h is not None for h in ctx.holders)
+                and (grp.meta is None or grp.meta == meta)):
+            # differentiated together with the group's other calls: make sure every map has its accumulator (the first
+            # consumer hands it to autograd, cleared), park the pooled gradient, launch when the group is complete
+            rets = []
+            for s_, h in zip(shapes, ctx.holders):
+                if "acc" in h and tuple(h["acc"].shape) == tuple(s_):
+                    rets.append(None)
+                else:
+                    t = torch.empty(s_, dtype=torch.float32, device=g.device, memory_format=torch.channels_last).zero_()
+                    h["acc"] = t
+                    rets.append(t)
+            if grp.meta is None:
+                grp.meta, grp.holders = meta, ctx.holders
+            first = not grp.pending
+            grp.pending.append((g, r, int(ph), int(pw), int(ratio)))
+            grp.registered -= 1
+            if grp.registered <= 0:
+                grp.flush()
+            elif first:
+                H.deferred.append(grp.flush)
+                torch.autograd.Variable._execution_engine.queue_callback(H.run_deferred)
+            return (None, None, None, None, None, None, None) + tuple(rets)
         grads, fresh = [], []
         for s, h in zip(shapes, ctx.holders):
             if h is not None and "acc" in h and tuple(h["acc"].shape) == tuple(s):

@@ -215,6 +215,8 @@ class GridCascadeRCNN(nn.Module):
         copies per step, the first hidden behind the cls head.  No index list is built on the host."""
         G, M = cfg.GRID_RCNN, cfg.GRID_RCNN.CASCADE_MAPPING_OPTION
         self._resolve_pending()
+        # the five heads pool the same pyramid: their RoIAlign gradients are formed by one pass over it (pooler_fpn)
+        ops.roi_backward_group(features)
         n_img, sizes = props.n_img, props.sizes
         gt_all, gt_labels, gt_off, off_h = RL.gt_pack(targets)
         n_gt = off_h[-1]

@@ -71,6 +71,16 @@ int cpm_roi_align_fpn_backward_gather(const float* grad_output, float* const* gr
                                       int B, int C, int pooled_h, int pooled_w, int sampling_ratio, float k_min,
                                       float k_max, float canonical_scale, float canonical_level, float eps,
                                       int accumulate_mask, void* workspace, size_t workspace_bytes, void* stream);
+/* Several RoI sets -- the pooled gradients of several heads on the same pyramid, each with its own RoIs [K_s,5], pooled
+ * size and sampling ratio (HOST arrays of n_sets <= 8 entries; grad_outputs[s] NHWC [K_s][ph_s][pw_s][C]) -- in ONE
+ * pass over the tiles: grad_feats receive the sum of what n_sets calls of the function above would add.  A pixel's
+ * contributions are added in (set, RoI, bin) order: bit-reproducible.  workspace sized for K = sum K_s. */
+int cpm_roi_align_fpn_backward_gather_sets(int n_sets, const float* const* grad_outputs, const float* const* rois,
+                                           const int* Ks, const int* pooled_hs, const int* pooled_ws,
+                                           const int* sampling_ratios, float* const* grad_feats, const int* hs,
+                                           const int* ws, const float* scales, int num_levels, int B, int C, float k_min,
+                                           float k_max, float canonical_scale, float canonical_level, float eps,
+                                           int accumulate_mask, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- NMS -------------------------------------------------------------------
  * Replaces torchvision.ops.nms as bound at pet/lib/ops/nms.py:2,10 (labels ==

@@ -597,3 +597,58 @@ def test_second_forward_stream_changes_nothing_but_the_schedule(fresh_model, gol
             assert torch.equal(g1[k], g2[k]), k
         else:       # bias sums end in one float atomic per (workgroup, channel) also in deterministic mode: order noise
             torch.testing.assert_close(g0[k], g1[k], rtol=1e-5, atol=1e-5 * float(g0[k].abs().max()))
+
+
+def test_grouped_roi_align_backward_equals_call_by_call(fresh_model, golden_model, deterministic_reductions):
+    """Three heads pool the same pyramid (7x7, 14x14, 7x7 with RoI sets of their own): with ops.roi_backward_group their
+    RoIAlign gradients are formed by one pass over the pyramid's tiles when the last of them is differentiated
+    (pooler_fpn._RoiBackwardGroup) -- the backbone / FPN gradients equal those of the call-by-call formulation (sums in
+    another order: 1e-5 of the tensor's scale), a repeated run gives the same bits, and a head that is never
+    differentiated does not leave the others' gradients behind."""
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip
+    from pet.lib.ops import pooler_fpn as PF
+    model = fresh_model
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    model.train()
+    x = torch.from_numpy(golden_model["m_img"]).cuda()
+    x = torch.cat([x, x.flip(3)], 0)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    H_, W_ = x.shape[2], x.shape[3]
+
+    def rois(k):
+        xy = torch.rand(k, 2, generator=g) * torch.tensor([W_ - 40., H_ - 40.])
+        wh = torch.rand(k, 2, generator=g) * 120 + 8
+        return torch.cat([torch.randint(0, 2, (k, 1), generator=g).float(), xy, xy + wh], 1).cuda()
+    sets = [(rois(200), 7), (rois(30), 14), (rois(150), 7)]
+    scales = (1 / 4., 1 / 8., 1 / 16., 1 / 32.)
+    gos = None
+
+    def run(grouped, use=(0, 1, 2)):
+        nonlocal gos
+        PF._GROUPED = grouped
+        model.zero_grad(set_to_none=True)
+        feats = list(model.Conv_Body_FPN(model.Conv_Body(x)))[:4]
+        grp = ops.roi_backward_group(feats)
+        assert (grp is not None) == grouped
+        ys = [ops.roi_align_fpn(feats, r, (p, p), scales, 2) for r, p in sets]
+        if gos is None:
+            gos = [torch.randn(y.shape, generator=g).cuda().contiguous(memory_format=CL) for y in ys]
+        torch.autograd.backward([ys[i] for i in use], [gos[i] for i in use])
+        torch.cuda.synchronize()
+        assert not _hip.deferred and (grp is None or not grp.pending)
+        return {k: q.grad.detach().clone() for k, q in model.named_parameters() if q.grad is not None}
+    try:
+        g0, g1, g2 = run(False), run(True), run(True)
+        h0, h1 = run(False, use=(0, 2)), run(True, use=(0, 2))       # one registered call is never differentiated
+    finally:
+        PF._GROUPED = True
+        _hip.set_conv_math(prev)
+    assert len(g0) > 50 and set(g0) == set(g1) == set(h1)
+    for a, b in ((g0, g1), (h0, h1)):
+        for k in a:
+            torch.testing.assert_close(a[k], b[k], rtol=1e-4, atol=1e-5 * float(a[k].abs().max()) + 1e-12, msg=k)
+    for k in g1:
+        if g1[k].dim() >= 2:
+            assert torch.equal(g1[k], g2[k]), k

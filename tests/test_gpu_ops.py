@@ -298,6 +298,51 @@ def test_roi_align_fpn_gather_backward(oracle, ph, ratio):
     assert all(bool((t == 0).all()) for t in empty)
 
 
+def test_roi_align_fpn_gather_backward_several_sets():
+    """cpm_roi_align_fpn_backward_gather_sets: the pooled gradients of several heads (own RoIs, 7x7 / 14x14 / 3x3 bins,
+    own sampling ratios, an empty set among them) in one pass == the sum of one call per set, into maps that already
+    hold something; bit-reproducible."""
+    import ctypes
+    from pet.lib.ops import _hip as H
+    rng = np.random.default_rng(77)
+    B, Cc = 2, 64
+    sizes = [(48, 80), (24, 40), (12, 20), (6, 10)]
+    shapes = [(B, Cc, h, w) for h, w in sizes]
+    scales = [1 / 4., 1 / 8., 1 / 16., 1 / 32.]
+    sets = [(300, 7, 2), (40, 14, 2), (0, 7, 2), (25, 14, 2), (200, 3, 0)]          # (K, pooled size, sampling ratio)
+    rois = [dev(_random_rois(rng, max(k, 1), B, 320, 192)[:k]) for k, _, _ in sets]
+    gos = [torch.randn(k, Cc, ph, ph, device="cuda").contiguous(memory_format=torch.channels_last) for k, ph, _ in sets]
+    base = [torch.randn(s, device="cuda").contiguous(memory_format=torch.channels_last) for s in shapes]
+    want = [t.clone() for t in base]
+    for (k, ph, ratio), r, go in zip(sets, rois, gos):
+        if k:
+            want = _fpn_backward("gather", go, r, shapes, scales, ph, ratio, init=want)
+
+    def together():
+        acc = [t.clone() for t in base]
+        n, m = len(shapes), len(sets)
+        hs = (ctypes.c_int * n)(*[s_[2] for s_ in shapes])
+        ws = (ctypes.c_int * n)(*[s_[3] for s_ in shapes])
+        sc = (ctypes.c_float * n)(*scales)
+        vp, ip = ctypes.c_void_p * m, ctypes.c_int * m
+        ktot = sum(k for k, _, _ in sets)
+        need = H.lib().cpm_roi_align_fpn_gather_workspace_bytes(hs, ws, n, B, ktot)
+        wsb = torch.empty(int(need), dtype=torch.uint8, device="cuda")
+        rc = H.lib().cpm_roi_align_fpn_backward_gather_sets(
+            m, vp(*[g.data_ptr() if g.numel() else None for g in gos]),
+            vp(*[r.data_ptr() if r.numel() else None for r in rois]), ip(*[k for k, _, _ in sets]),
+            ip(*[p for _, p, _ in sets]), ip(*[p for _, p, _ in sets]), ip(*[q for _, _, q in sets]),
+            (ctypes.c_void_p * n)(*[t.data_ptr() for t in acc]), hs, ws, sc, n, B, Cc, H.f(2.0), H.f(5.0), H.f(224.0),
+            H.f(4.0), H.f(1e-6), (1 << n) - 1, H.ptr(wsb), H.c_size_t(wsb.numel()), H.stream())
+        H.check(rc, "gather_sets")
+        torch.cuda.synchronize()
+        return acc
+    got, again = together(), together()
+    for a, b, c in zip(got, want, again):
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5)
+        assert torch.equal(a, c)
+
+
 def test_roi_align_fpn_gather_backward_full_size():
     """BASELINE shapes (K=1024 cls RoIs 7x7 and 192 grid RoIs 14x14 on the 2 x 256-channel pyramid): gather == scatter,
     and the gradient mass is conserved for in-bounds RoIs."""
