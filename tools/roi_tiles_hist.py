@@ -6,6 +6,8 @@ Reads the binning pass's counters out of the call's workspace after each backwar
 import os
 import sys
 
+os.environ["CPM_ROI_BWD_GROUP"] = "0"      # call by call: the counters of one call at a time
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "cpm-r-cnn_amd"))
