@@ -751,7 +751,12 @@ def _image_dense(g):
     """a [N, ch, H, W] gradient whose every image is a dense NHWC block (the images may lie further apart)"""
     n, ch, h, w = g.shape
     return (g.dtype == torch.float32 and g.stride(1) == 1 and g.stride(3) == ch and g.stride(2) == w * ch
-            and g.stride(0) >= h * w * ch)
+            and (n == 1 or g.stride(0) >= h * w * ch))           # (one image: its stride says nothing)
+
+
+def _image_stride(g):
+    """floats between two images of an _image_dense tensor (a single image: the dense distance)"""
+    return int(g.stride(0)) if g.shape[0] > 1 else int(g.shape[1] * g.shape[2] * g.shape[3])
 
 
 class _RPNHeadFn(Function):
@@ -869,8 +874,8 @@ class _RPNHeadFn(Function):
         with H.guard(dev):
             rc = H.lib().cpm_rpn_sparse_rows(H.ptr(idx), cap, n_img, n, hs, ws, int(a), int(c), arr(dcs), arr(dbs),
                                              arr(ts), arr(xs), H.ptr(wcm), H.ptr(wbm), H.ptr(DT), H.ptr(Gc), H.ptr(Gb),
-                                             H.ptr(T), H.ptr(X), H.ptr(pix), i64(*[int(g.stride(0)) for g in dcs]),
-                                             i64(*[int(g.stride(0)) for g in dbs]), H.stream())
+                                             H.ptr(T), H.ptr(X), H.ptr(pix), i64(*[_image_stride(g) for g in dcs]),
+                                             i64(*[_image_stride(g) for g in dbs]), H.stream())
         H.check(rc, "rpn_sparse_rows")
         img = lambda m: m.view(1, cap, 1, m.shape[1]).permute(0, 3, 1, 2)       # [1, channels, rows, 1], NHWC memory
         # the 3x3 conv: dW = DT^T X (+ the bias sum), the predictors: dWcls = Gc^T T, dWbox = Gb^T T
