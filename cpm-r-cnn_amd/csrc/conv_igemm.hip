@@ -2672,6 +2672,16 @@ Plan plan_igemm(const IgemmArgs& a) {
     p.bm = 64; p.bn = 64; p.split = 1;
     return p;
   }
+  // 24-40 k-steps on between one and two residency rounds of 128x128 tiles (fc6's data gradient: 1024 RoIs x 12 544
+  // columns over 1 024 channels = 784 tiles): the round model below prefers 3 136 64x64 tiles (204 us); as persistent
+  // runs of two 128x128 tiles on 392 workgroups the launch takes 143 us (launch_one: igemm_pt_kernel)
+  if (g_conv_split && a.ksteps >= 24 && a.ksteps <= 40 && a.OCg >= 128 && a.groups == 1) {
+    const int64_t t = tiles(128, 128);
+    if (t > 2ll * num_cus() && t <= 4ll * num_cus()) {
+      p.bm = 128; p.bn = 128; p.split = 1;
+      return p;
+    }
+  }
   const Cand* cands = (g_conv_split && a.ksteps <= 40) ? cands_split_short : cands_f32;   // short reductions (1x1)
   const double fixed = (g_conv_split && a.ksteps <= 40) ? 10.0 : 5.0;
   double best = 1e300;
