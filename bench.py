@@ -77,7 +77,12 @@ def synthetic_batch(n, h, w, gts, seed, device):
         t.add_field("labels", torch.randint(1, 81, (gts,), generator=gen))
         targets.append(t.to(device))
     il = to_image_list(images, 32)
+    # the layout the input pipeline hands over (pet/utils/data/collate_batch.py: ImageList.to -> channels_last, written
+    # directly by the device resize, csrc/image_prep.hip); CPM_BENCH_NCHW=1: the reference's NCHW batch (the stem then
+    # goes through im2col + GEMM instead of the one-kernel stem)
     il.tensors = il.tensors.to(device)
+    if os.environ.get("CPM_BENCH_NCHW", "0") == "0":
+        il.tensors = il.tensors.contiguous(memory_format=torch.channels_last)
     return il, targets
 
 
@@ -702,6 +707,10 @@ def main():
                                             "over P2..P6 multiply zeros (csrc/rpn_sparse.hip; same gradients: "
                                             "tests/test_gpu_rpn_sparse.py; CPM_RPN_SPARSE=0 = dense)",
                        **({"dense_rpn_head_backward": dense_rpn} if dense_rpn else {}),
+                       "input_layout": "NCHW batch (CPM_BENCH_NCHW=1: stem = im2col + GEMM)"
+                                       if os.environ.get("CPM_BENCH_NCHW", "0") != "0" else
+                                       "channels-last batch, as the input pipeline writes it (collate_batch.py, "
+                                       "csrc/image_prep.hip): the stem is one kernel reading the image",
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        **({"host_input": host_input} if host_input else {}),
                        **({"full_rois": full_rois} if full_rois else {}),
