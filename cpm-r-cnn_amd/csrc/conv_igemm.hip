@@ -2912,10 +2912,16 @@ static float* slab_in(void* workspace, size_t bytes, size_t off, int split, size
   return (float*)((char*)workspace + off);
 }
 
+// cpm_conv_next_output_prepared: the caller (a layer chain) has had the previous kernel fill this call's output
+static thread_local int g_out_prepared = 0;
+CPM_EXPORT void cpm_conv_next_output_prepared(int on) { g_out_prepared = on ? 1 : 0; }
+
 static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const float* w,
                              const float* scale, const float* shift, const float* residual, int res_mode, int relu,
                              float* y, hipStream_t s, void* workspace = nullptr, size_t workspace_bytes = 0,
                              int w_presplit = 0) {
+  const bool prepared = g_out_prepared != 0;
+  g_out_prepared = 0;
   IgemmArgs a = {};
   a.b_presplit = w_presplit;
   a.in = x; a.wm = w; a.out = y; a.scale = scale; a.shift = shift; a.res = residual;
@@ -2946,11 +2952,15 @@ static int conv_forward_impl(const cpm_conv_desc* d, const float* x, const float
     // partial sums in slab planes: no zero fill, no atomics; the reduce pass below also runs the epilogue
   } else if (a.atomic_out) {
     if (shift && !scale && !residual && !relu && (a.OCtot & 3) == 0 && (((uintptr_t)shift | (uintptr_t)y) & 15) == 0) {
-      const int64_t total4 = (int64_t)a.M * a.OCtot / 4;
-      const int64_t b = (total4 + 255) / 256;
-      hipLaunchKernelGGL(seed_rows_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, y, shift, total4,
-                         a.OCtot / 4);
+      if (!prepared) {                      // (prepared: the previous kernel of the chain left the bias in every pixel)
+        const int64_t total4 = (int64_t)a.M * a.OCtot / 4;
+        const int64_t b = (total4 + 255) / 256;
+        hipLaunchKernelGGL(seed_rows_kernel, dim3((unsigned)(b > 4096 ? 4096 : b)), dim3(256), 0, s, y, shift, total4,
+                           a.OCtot / 4);
+      }
       seeded = true;
+    } else if (prepared && !shift && !scale && !residual && !relu) {
+      // cleared by the previous kernel of the chain
     } else if (hipMemsetAsync(y, 0, (size_t)a.M * a.OCtot * sizeof(float), s) != hipSuccess) {
       return CPM_ELAUNCH;
     }
@@ -3032,6 +3042,8 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
                      const float* shift, int relu, void* workspace, size_t workspace_bytes, hipStream_t s,
                      const char* who, const float* out_scale = nullptr, const float* out_mask = nullptr,
                      bool prepared = false, const float* k_scale = nullptr, int prepared_w4 = 0) {
+  const bool out_ready = g_out_prepared != 0;       // cpm_conv_next_output_prepared: consumed by this call
+  g_out_prepared = 0;
   const size_t need = dgrad_weight_bytes(d);
   if (!prepared && (!workspace || workspace_bytes < need)) {
     cpm::set_error("%s: workspace %zu < %zu", who, workspace_bytes, need);
@@ -3102,7 +3114,7 @@ static int run_dgrad(const cpm_conv_desc* d, const float* dy, const float* w, fl
     // a stride phase without taps (or one that runs unsplit) leaves plane rows unwritten: they must read as zero
     if (!all_phases && hipMemsetAsync(a.slab, 0, (size_t)a.split_k * plane * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
-  if (a.atomic_out && !accumulate && !a.slab) {
+  if (a.atomic_out && !accumulate && !a.slab && !out_ready) {     // (out_ready: cleared by the chain's previous kernel)
     if (hipMemsetAsync(dx, 0, (size_t)whole.M * a.OCtot * sizeof(float), s) != hipSuccess) return CPM_ELAUNCH;
   }
   g_flops_next = 2.0 * d->N * d->P * d->Q * (double)d->K * d->R * d->S * (d->C / d->groups);

@@ -10,8 +10,15 @@
 // ONE call per direction: the same C-ABI kernels in the same order with the same arguments as the per-op path (so the
 // results are the same), the host cost of up to 16 ops replaced by a loop in C.  Host code only: no kernels of its own.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
+
+// CPM_CHAIN_FILL=0: every split launch seeds / clears its own output (the A/B of the GroupNorm side jobs); read per call
+inline bool chain_fill() {
+  const char* v = getenv("CPM_CHAIN_FILL");
+  return !(v && v[0] == '0');
+}
 
 inline int n_pix(const cpm_conv_desc& d) { return d.P * d.Q; }
 // a full-window conv (an FC over a flattened NHWC map) seen as the 1x1 problem over R*S*C "channels" it is: every
@@ -110,22 +117,40 @@ CPM_EXPORT int cpm_layer_chain_forward(const cpm_chain_layer* layers, int n_laye
   Off off[MAX_LAYERS];
   layout(layers, n_layers, N, off, nullptr, nullptr, nullptr);
   const float* in = x;
+  bool out_filled = false;                                 // the previous layer's GroupNorm left this conv's bias in conv_out
   for (int i = 0; i < n_layers; ++i) {
     const cpm_chain_layer& L = layers[i];
     cpm_conv_desc d = L.conv;
     d.N = N;
     float* conv_out = at(fwd_base, off[i].conv_out, y);
+    if (out_filled) cpm_conv_next_output_prepared(1);
+    out_filled = false;
     // (a pre-split image serves the bf16x3 arithmetic only: under the other one the float weights are read)
     int rc = (L.w4 && cpm_get_conv_math() == CPM_MATH_BF16X3)
                  ? cpm_conv2d_forward_w4(&d, in, L.w4, nullptr, L.bias, nullptr, 0, L.has_gn ? 0 : L.relu, conv_out, workspace,
                                          workspace_bytes, stream)
                  : cpm_conv2d_forward(&d, in, L.w, nullptr, L.bias, nullptr, 0, L.has_gn ? 0 : L.relu, conv_out, workspace,
                                       workspace_bytes, stream);
+    cpm_conv_next_output_prepared(0);
     if (rc != CPM_OK) return rc;
     if (L.has_gn) {
       float* gn_out = at(fwd_base, off[i].gn_out, y);
-      rc = cpm_groupnorm_forward(conv_out, L.gamma, L.beta, N, n_pix(d), d.K, L.gn_groups, L.eps, L.relu, gn_out,
-                                 fwd_base + off[i].mean, fwd_base + off[i].rstd, stream);
+      // The next conv's output has this GroupNorm's shape and starts from its bias (a bias-only epilogue: a GroupNorm
+      // of its own follows, or no ReLU): this kernel writes it on the side -- a reduction-split launch (every grid-head
+      // conv on ~100 RoIs) then needs no seed launch (21 per step, 5 us each, between kernels of 50-110 us).
+      float* fill = nullptr;
+      if (i + 1 < n_layers) {
+        const cpm_chain_layer& Nx = layers[i + 1];
+        const cpm_conv_desc& e = Nx.conv;
+        if (chain_fill() && (Nx.has_gn || !Nx.relu) && e.K == d.K && e.P == d.P && e.Q == d.Q && off[i + 1].conv_out >= 0)
+          fill = fwd_base + off[i + 1].conv_out;
+      }
+      rc = fill ? cpm_groupnorm_forward_fill(conv_out, L.gamma, L.beta, N, n_pix(d), d.K, L.gn_groups, L.eps, L.relu,
+                                             gn_out, fwd_base + off[i].mean, fwd_base + off[i].rstd, fill,
+                                             layers[i + 1].bias, stream)
+                : cpm_groupnorm_forward(conv_out, L.gamma, L.beta, N, n_pix(d), d.K, L.gn_groups, L.eps, L.relu, gn_out,
+                                        fwd_base + off[i].mean, fwd_base + off[i].rstd, stream);
+      out_filled = fill != nullptr;
       if (rc != CPM_OK) return rc;
       in = gn_out;
     } else {
@@ -158,13 +183,21 @@ CPM_EXPORT int cpm_layer_chain_backward(const cpm_chain_layer* layers, int n_lay
     float* d_in = at(bwd_base, off[i].d_in, dx);
     const float* gc = g;                                   // gradient at the conv's own output
     int rc = CPM_OK;
+    bool din_cleared = false;
     if (L.has_gn) {
       float* d_conv = bwd_base + off[i].d_conv;
-      rc = cpm_groupnorm_backward(g, fwd_base + off[i].conv_out, at(fwd_base, off[i].gn_out, y), L.gamma,
-                                  fwd_base + off[i].mean, fwd_base + off[i].rstd, N, n_pix(d), d.K, L.gn_groups, L.relu,
-                                  d_conv, L.dgamma, L.dbeta, stream);
+      // the conv's input gradient has this GroupNorm's shape (a 3x3 / stride-1 layer of constant width): cleared on the
+      // side for the reduction-split data-gradient launch below (no clear launch of its own)
+      const bool same = chain_fill() && d_in && d_in != dx && d.C == d.K && d.H == d.P && d.W == d.Q;
+      rc = same ? cpm_groupnorm_backward_zero(g, fwd_base + off[i].conv_out, at(fwd_base, off[i].gn_out, y), L.gamma,
+                                              fwd_base + off[i].mean, fwd_base + off[i].rstd, N, n_pix(d), d.K,
+                                              L.gn_groups, L.relu, d_conv, L.dgamma, L.dbeta, d_in, stream)
+                : cpm_groupnorm_backward(g, fwd_base + off[i].conv_out, at(fwd_base, off[i].gn_out, y), L.gamma,
+                                         fwd_base + off[i].mean, fwd_base + off[i].rstd, N, n_pix(d), d.K, L.gn_groups,
+                                         L.relu, d_conv, L.dgamma, L.dbeta, stream);
       if (rc != CPM_OK) return rc;
       gc = d_conv;
+      din_cleared = same;
     }
     void* ws_w = workspace;
     size_t ws_w_bytes = workspace_bytes;
@@ -182,6 +215,7 @@ CPM_EXPORT int cpm_layer_chain_backward(const cpm_chain_layer* layers, int n_lay
     if (d_in) {
       const float* gate = (i > 0 && !layers[i - 1].has_gn && layers[i - 1].relu) ? in : nullptr;
       const cpm_conv_desc dd = L.dgrad_flat ? flat_desc(d) : d;
+      if (din_cleared) cpm_conv_next_output_prepared(1);
       if (L.wt && L.wt_w4 && cpm_get_conv_math() == CPM_MATH_BF16X3)
         rc = cpm_conv2d_backward_data_prepared_w4(&dd, gc, L.wt, d_in, 0, nullptr, gate, workspace, workspace_bytes, stream);
       else if (L.wt && !L.wt_w4)
@@ -190,6 +224,7 @@ CPM_EXPORT int cpm_layer_chain_backward(const cpm_chain_layer* layers, int n_lay
         rc = cpm_conv2d_backward_data_gated(&dd, gc, L.w, d_in, nullptr, gate, workspace, workspace_bytes, stream);
       else
         rc = cpm_conv2d_backward_data(&dd, gc, L.w, d_in, 0, workspace, workspace_bytes, stream);
+      cpm_conv_next_output_prepared(0);
       if (rc != CPM_OK) return rc;
       g = d_in;
     }

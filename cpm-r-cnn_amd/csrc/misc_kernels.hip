@@ -344,7 +344,8 @@ __global__ __launch_bounds__(256) void gn_bwd_wave_kernel(const float* __restric
                                                           const float* __restrict__ mean_in,
                                                           const float* __restrict__ rstd_in, int N, int HW, int C,
                                                           int G, int qshift, int relu, float* __restrict__ dx,
-                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                          float* __restrict__ zero_out) {
   __shared__ float part[256][9];                        // [thread][4 dgamma + 4 dbeta], padded
   __shared__ float red2[2][4];
   constexpr bool WAVE = THREADS == 64;
@@ -403,6 +404,9 @@ __global__ __launch_bounds__(256) void gn_bwd_wave_kernel(const float* __restric
       o.x = rstd * (d.x * gm.x - m1 - h.x * m2); o.y = rstd * (d.y * gm.y - m1 - h.y * m2);
       o.z = rstd * (d.z * gm.z - m1 - h.z * m2); o.w = rstd * (d.w * gm.w - m1 - h.w * m2);
       *(float4*)(dx + base + (size_t)(slot >> qshift) * C) = o;
+      // side job for a layer chain (cpm_groupnorm_backward_zero): the conv's INPUT gradient -- same shape -- cleared
+      // for the reduction-split data-gradient launch that follows
+      if (zero_out) *(float4*)(zero_out + base + (size_t)(slot >> qshift) * C) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
   if (!dgamma && !dbeta) return;
@@ -432,7 +436,9 @@ template <int THREADS, int TRIPS>
 __global__ __launch_bounds__(256) void gn_fwd_wave_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, int N, int HW, int C, int G,
                                                           int qshift, float eps, int relu, float* __restrict__ y,
-                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+                                                          float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                          float* __restrict__ fill_out,
+                                                          const float* __restrict__ fill_bias) {
   __shared__ float red2[2][4];
   constexpr bool WAVE = THREADS == 64;
   const int wave = threadIdx.x >> 6;
@@ -490,6 +496,17 @@ __global__ __launch_bounds__(256) void gn_fwd_wave_kernel(const float* __restric
       o.z = (xv[t].z - mean) * rstd * gm.z + bt.z; o.w = (xv[t].w - mean) * rstd * gm.w + bt.w;
       if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
       *(float4*)(y + base + (size_t)(slot >> qshift) * C) = o;
+    }
+  }
+  // side job for a layer chain (cpm_groupnorm_forward_fill): the NEXT convolution's output tensor -- same [N, HW, C]
+  // shape -- leaves here holding its bias (or zeros), so that a reduction-split launch adds into it without a seed /
+  // clear launch of its own
+  if (fill_out) {
+    const float4 fb = fill_bias ? *(const float4*)(fill_bias + g * Cg + 4 * quad) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int t = 0; t < TRIPS; ++t) {
+      const int slot = lane + THREADS * t;
+      if (slot < slots) *(float4*)(fill_out + base + (size_t)(slot >> qshift) * C) = fb;
     }
   }
 }
@@ -689,59 +706,106 @@ CPM_EXPORT int cpm_maxpool3x3s2_forward(const float* x, int N, int H, int W, int
   return cpm::check_launch("maxpool");
 }
 
-CPM_EXPORT int cpm_groupnorm_forward(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
-                                     int G, float eps, int relu, float* y, float* mean, float* rstd, void* stream) {
+__global__ __launch_bounds__(256) void fill_rows4_kernel(float4* __restrict__ out, const float4* __restrict__ bias4,
+                                                         int64_t total4, int c4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256)
+    out[i] = bias4 ? bias4[i % c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+static int groupnorm_forward_impl(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G,
+                                  float eps, int relu, float* y, float* mean, float* rstd, float* fill_out,
+                                  const float* fill_bias, void* stream) {
   CPM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, "bad shape");
   if (N == 0) return CPM_OK;
   CPM_REQUIRE(x && gamma && beta && y && mean && rstd, "null pointer");
   const int Cg = C / G, Q = Cg / 4;
   const bool pow2 = Q > 0 && (Q & (Q - 1)) == 0;
   const bool vec = (Cg & 3) == 0 && (C & 3) == 0 && pow2 && Q <= 64 && (int64_t)N * G < (1ll << 30) &&
-                   ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0);
+                   ((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)fill_out |
+                      (uintptr_t)fill_bias) & 15) == 0);
   int qshift = 0;
   while ((1 << qshift) < Q) ++qshift;
   if (vec && (int64_t)HW * Q <= 64 * 4) {
     hipLaunchKernelGGL((gn_fwd_wave_kernel<64, 4>), dim3((unsigned)(((int64_t)N * G + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, x, gamma, beta, N, HW, C, G, qshift, eps, relu, y, mean, rstd);
+                       (hipStream_t)stream, x, gamma, beta, N, HW, C, G, qshift, eps, relu, y, mean, rstd, fill_out,
+                       fill_bias);
     return cpm::check_launch("groupnorm_forward (wave per group)");
   }
   if (vec && (int64_t)HW * Q <= 256 * 13) {
     hipLaunchKernelGGL((gn_fwd_wave_kernel<256, 13>), dim3((unsigned)((int64_t)N * G)), dim3(256), 0,
-                       (hipStream_t)stream, x, gamma, beta, N, HW, C, G, qshift, eps, relu, y, mean, rstd);
+                       (hipStream_t)stream, x, gamma, beta, N, HW, C, G, qshift, eps, relu, y, mean, rstd, fill_out,
+                       fill_bias);
     return cpm::check_launch("groupnorm_forward (workgroup per group, single pass)");
   }
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, HW, C, G, eps, relu,
                      y, mean, rstd);
+  if (fill_out) {                                            // (the general kernel has no side job: a launch of its own)
+    CPM_REQUIRE((C & 3) == 0 && ((((uintptr_t)fill_out | (uintptr_t)fill_bias) & 15) == 0), "fill: C % 4, 16-byte aligned");
+    const int64_t total4 = (int64_t)N * HW * C / 4;
+    hipLaunchKernelGGL(fill_rows4_kernel, dim3((unsigned)(total4 / 256 + 1 > 4096 ? 4096 : total4 / 256 + 1)), dim3(256), 0,
+                       (hipStream_t)stream, (float4*)fill_out, (const float4*)fill_bias, total4, C / 4);
+  }
   return cpm::check_launch("groupnorm_forward");
 }
 
-CPM_EXPORT int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, const float* gamma,
-                                      const float* mean, const float* rstd, int N, int HW, int C, int G, int relu,
-                                      float* dx, float* dgamma, float* dbeta, void* stream) {
+CPM_EXPORT int cpm_groupnorm_forward(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
+                                     int G, float eps, int relu, float* y, float* mean, float* rstd, void* stream) {
+  return groupnorm_forward_impl(x, gamma, beta, N, HW, C, G, eps, relu, y, mean, rstd, nullptr, nullptr, stream);
+}
+
+CPM_EXPORT int cpm_groupnorm_forward_fill(const float* x, const float* gamma, const float* beta, int N, int HW, int C,
+                                          int G, float eps, int relu, float* y, float* mean, float* rstd,
+                                          float* fill_out, const float* fill_bias, void* stream) {
+  CPM_REQUIRE(fill_out, "null fill tensor");
+  return groupnorm_forward_impl(x, gamma, beta, N, HW, C, G, eps, relu, y, mean, rstd, fill_out, fill_bias, stream);
+}
+
+static int groupnorm_backward_impl(const float* dy, const float* x, const float* y, const float* gamma,
+                                   const float* mean, const float* rstd, int N, int HW, int C, int G, int relu,
+                                   float* dx, float* dgamma, float* dbeta, float* zero_out, void* stream) {
   CPM_REQUIRE(N >= 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && C / G <= 256, "bad shape");
   if (N == 0) return CPM_OK;
   CPM_REQUIRE(dy && x && gamma && mean && rstd && dx && (!relu || y), "null pointer");
   const int Cg = C / G, Q = Cg / 4;
   const bool pow2 = Q > 0 && (Q & (Q - 1)) == 0;
+  const bool al16 = ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)gamma |
+                       (uintptr_t)zero_out) & 15) == 0);
   if ((Cg & 3) == 0 && (C & 3) == 0 && pow2 && Q <= 16 && (int64_t)HW * Q <= 64 * 4 && (int64_t)N * G < (1ll << 30) &&
-      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0)) {
+      al16) {
     int qshift = 0;
     while ((1 << qshift) < Q) ++qshift;
     hipLaunchKernelGGL((gn_bwd_wave_kernel<64, 4>), dim3((unsigned)(((int64_t)N * G + 3) / 4)), dim3(256), 0,
-                       (hipStream_t)stream, dy, x, y, gamma, mean, rstd, N, HW, C, G, qshift, relu, dx, dgamma, dbeta);
+                       (hipStream_t)stream, dy, x, y, gamma, mean, rstd, N, HW, C, G, qshift, relu, dx, dgamma, dbeta,
+                       zero_out);
     return cpm::check_launch("groupnorm_backward (wave per group)");
   }
   if ((Cg & 3) == 0 && (C & 3) == 0 && pow2 && Q <= 16 && (int64_t)HW * Q <= 256 * 13 && (int64_t)N * G < (1ll << 30) &&
-      ((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)y | (uintptr_t)dx | (uintptr_t)gamma) & 15) == 0)) {
+      al16) {
     int qshift = 0;
     while ((1 << qshift) < Q) ++qshift;
     hipLaunchKernelGGL((gn_bwd_wave_kernel<256, 13>), dim3((unsigned)((int64_t)N * G)), dim3(256), 0,
-                       (hipStream_t)stream, dy, x, y, gamma, mean, rstd, N, HW, C, G, qshift, relu, dx, dgamma, dbeta);
+                       (hipStream_t)stream, dy, x, y, gamma, mean, rstd, N, HW, C, G, qshift, relu, dx, dgamma, dbeta,
+                       zero_out);
     return cpm::check_launch("groupnorm_backward (workgroup per group, single pass)");
   }
   hipLaunchKernelGGL(gn_bwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, dy, x, y, gamma, mean, rstd, HW, C,
                      G, relu, dx, dgamma, dbeta);
+  if (zero_out && hipMemsetAsync(zero_out, 0, (size_t)N * HW * C * sizeof(float), (hipStream_t)stream) != hipSuccess)
+    return CPM_ELAUNCH;
   return cpm::check_launch("groupnorm_backward");
+}
+
+CPM_EXPORT int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, const float* gamma,
+                                      const float* mean, const float* rstd, int N, int HW, int C, int G, int relu,
+                                      float* dx, float* dgamma, float* dbeta, void* stream) {
+  return groupnorm_backward_impl(dy, x, y, gamma, mean, rstd, N, HW, C, G, relu, dx, dgamma, dbeta, nullptr, stream);
+}
+
+CPM_EXPORT int cpm_groupnorm_backward_zero(const float* dy, const float* x, const float* y, const float* gamma,
+                                           const float* mean, const float* rstd, int N, int HW, int C, int G, int relu,
+                                           float* dx, float* dgamma, float* dbeta, float* zero_out, void* stream) {
+  CPM_REQUIRE(zero_out, "null tensor to clear");
+  return groupnorm_backward_impl(dy, x, y, gamma, mean, rstd, N, HW, C, G, relu, dx, dgamma, dbeta, zero_out, stream);
 }
 
 CPM_EXPORT int cpm_upsample2x_add_backward(const float* dy, int N, int P, int Q, int C, float* dtop, int accumulate,

@@ -357,6 +357,20 @@ int cpm_groupnorm_forward(const float* x, const float* gamma, const float* beta,
 int cpm_groupnorm_backward(const float* dy, const float* x, const float* y, const float* gamma, const float* mean,
                            const float* rstd, int N, int HW, int C, int G, int relu, float* dx, float* dgamma,
                            float* dbeta, void* stream);
+/* The same with a side job for the layer chains (cpm_layer_chain_*): the forward also leaves fill_out [N,HW,C] -- the
+ * NEXT convolution's output tensor -- holding fill_bias [C] in every pixel (zeros with fill_bias == NULL); the backward
+ * also clears zero_out [N,HW,C] -- the convolution's INPUT gradient.  With cpm_conv_next_output_prepared the
+ * reduction-split launch that follows adds into the tensor without a seed / clear launch of its own. */
+int cpm_groupnorm_forward_fill(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G,
+                               float eps, int relu, float* y, float* mean, float* rstd, float* fill_out,
+                               const float* fill_bias, void* stream);
+int cpm_groupnorm_backward_zero(const float* dy, const float* x, const float* y, const float* gamma, const float* mean,
+                                const float* rstd, int N, int HW, int C, int G, int relu, float* dx, float* dgamma,
+                                float* dbeta, float* zero_out, void* stream);
+/* Tells the NEXT cpm_conv2d_forward* / cpm_conv2d_backward_data* call of this thread that its output tensor already
+ * holds what a reduction-split launch starts from -- the bias in every pixel for a forward whose epilogue is a bias (or
+ * nothing: zeros), zeros for a non-accumulating data gradient.  Consumed by that call, whatever path it takes. */
+void cpm_conv_next_output_prepared(int on);
 
 /* FPN top-down backward (FPN.py:104-106): dtop[n,p,q,c] += sum of dy over the 2x2 block it was
  * upsampled to.  dy [N,P,Q,C], dtop [N,ceil(P/2),ceil(Q/2),C]. */
