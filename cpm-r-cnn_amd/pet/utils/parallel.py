@@ -173,10 +173,11 @@ def backward_losses(losses):
     (tools/rcnn/train_net.py:60-63) -- without forming the sum: every term starts its own backward pass with gradient
     1, which is the same gradient, minus the 7 add kernels, their autograd nodes and ~0.1 ms of host time that sat
     between the last forward and the first backward kernel, where the device has nothing else queued."""
+    from pet.lib.ops import _hip as H
+    H.deferred.clear()                      # (leftovers of a backward pass that raised half-way)
     terms = [v for v in losses.values() if v.requires_grad]
     # the seeds: ONE cached scalar 1 per device instead of a fresh ones_like per term (eight fill kernels and
     # allocations queued exactly where the device waits for the host: the start of the backward pass)
-    from pet.lib.ops import _hip as H
     seeds = [H.unit_seed(v.device) if v.dim() == 0 and v.dtype == torch.float32 and v.is_cuda else torch.ones_like(v)
              for v in terms]
     torch.autograd.backward(terms, seeds)

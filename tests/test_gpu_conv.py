@@ -728,6 +728,86 @@ def test_conv_gn_stack_equals_layer_by_layer():
         config.reset_cfg()
 
 
+def test_chain_side_jobs_of_groupnorm(monkeypatch):
+    """The layer chain's GroupNorm kernels also prepare the next reduction-split conv's output (forward: the next
+    layer's bias in every pixel; backward: the conv's input gradient cleared), and that conv skips its own seed / clear
+    launch (head_exec.hip, cpm_conv_next_output_prepared).  Held: the side jobs write exactly that (C ABI), and a
+    576-wide 3x3 stack on 7x7 maps at 40 RoIs -- every conv a split launch under bf16x3 -- gives the same outputs and
+    gradients with the side jobs on and off (float atomics either way: summation-order tolerance)."""
+    import ctypes
+    import torch.nn as nn
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip as H
+    from pet.lib.ops import conv as C
+    from pet.rcnn.core import config
+    from pet.utils.optimizer import Optimizer
+    N, HW, Cc, G = 5, 49, 64, 4
+    x = rnd(N, HW, Cc, seed=1).cuda()
+    gamma, beta, bias = rnd(Cc, seed=2).cuda(), rnd(Cc, seed=3).cuda(), rnd(Cc, seed=4).cuda()
+    y0, y1 = torch.empty_like(x), torch.empty_like(x)
+    mean, rstd = torch.empty(N * G, device="cuda"), torch.empty(N * G, device="cuda")
+    fill = torch.full_like(x, float("nan"))
+    H.check(H.lib().cpm_groupnorm_forward(H.ptr(x), H.ptr(gamma), H.ptr(beta), N, HW, Cc, G, H.f(1e-5), 1, H.ptr(y0),
+                                          H.ptr(mean), H.ptr(rstd), H.stream()), "gn")
+    H.check(H.lib().cpm_groupnorm_forward_fill(H.ptr(x), H.ptr(gamma), H.ptr(beta), N, HW, Cc, G, H.f(1e-5), 1,
+                                               H.ptr(y1), H.ptr(mean), H.ptr(rstd), H.ptr(fill), H.ptr(bias),
+                                               H.stream()), "gn fill")
+    assert torch.equal(y0, y1) and torch.equal(fill, bias.view(1, 1, Cc).expand(N, HW, Cc))
+    H.check(H.lib().cpm_groupnorm_forward_fill(H.ptr(x), H.ptr(gamma), H.ptr(beta), N, HW, Cc, G, H.f(1e-5), 1,
+                                               H.ptr(y1), H.ptr(mean), H.ptr(rstd), H.ptr(fill), None, H.stream()),
+            "gn fill zeros")
+    assert bool((fill == 0).all())
+    dy = rnd(N, HW, Cc, seed=5).cuda()
+    dx0, dx1 = torch.empty_like(x), torch.empty_like(x)
+    z = torch.full_like(x, float("nan"))
+    dg0, db0, dg1, db1 = (torch.zeros(Cc, device="cuda") for _ in range(4))
+    H.check(H.lib().cpm_groupnorm_backward(H.ptr(dy), H.ptr(x), H.ptr(y0), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), N, HW,
+                                           Cc, G, 1, H.ptr(dx0), H.ptr(dg0), H.ptr(db0), H.stream()), "gn bwd")
+    H.check(H.lib().cpm_groupnorm_backward_zero(H.ptr(dy), H.ptr(x), H.ptr(y0), H.ptr(gamma), H.ptr(mean), H.ptr(rstd), N,
+                                                HW, Cc, G, 1, H.ptr(dx1), H.ptr(dg1), H.ptr(db1), H.ptr(z), H.stream()),
+            "gn bwd zero")
+    torch.cuda.synchronize()
+    assert torch.equal(dx0, dx1) and bool((z == 0).all())
+    torch.testing.assert_close(dg0, dg1, rtol=1e-5, atol=1e-5)
+
+    class Stack(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.convs = nn.ModuleList([ops.Conv2d(576, 576, 3, 1, 1) for _ in range(3)])
+            self.norms = nn.ModuleList([ops.GroupNorm(36, 576) for _ in range(3)])
+
+        def forward(self, t):
+            return C.conv_gn_stack(t, list(self.convs), list(self.norms))
+
+    config.reset_cfg()
+    prev = H.get_conv_math()
+    H.set_conv_math("bf16x3")
+    try:
+        torch.manual_seed(9)
+        m = Stack().cuda().to(memory_format=CL)
+        with torch.no_grad():
+            for cv in m.convs:
+                cv.bias.uniform_(-0.5, 0.5)
+        opt = Optimizer(m, config.cfg.SOLVER).build()
+        x0 = rnd(40, 576, 7, 7, seed=31).cuda().contiguous(memory_format=CL)
+        go = rnd(40, 576, 7, 7, seed=32).cuda().contiguous(memory_format=CL)
+        res = {}
+        for on in ("1", "0"):
+            monkeypatch.setenv("CPM_CHAIN_FILL", on)
+            opt.zero_grad()
+            t = x0.clone().requires_grad_(True)
+            y = m(t)
+            assert y.grad_fn.__class__.__name__ == "_LayerChainFnBackward"
+            y.backward(go)
+            torch.cuda.synchronize()
+            res[on] = (y.detach().clone(), t.grad.clone(), opt.flat_grad.clone())
+        for a, b in zip(res["1"], res["0"]):
+            assert relerr(a, b) < 2e-5
+    finally:
+        H.set_conv_math(prev)
+        config.reset_cfg()
+
+
 def test_mlp_chain_equals_layer_by_layer():
     """cpm_layer_chain_* on a Linear chain (full-window fc6-like layer -> ReLU -> Linear -> ReLU -> Linear: the cls /
     RSM / ISM heads) against the per-module calls with their consumer-side ReLU gates: outputs and input gradient bit
