@@ -49,6 +49,30 @@ def sample_columns(x, offset, geom):
     return cols.permute(0, 3, 1, 2)
 
 
+_fused = [True]
+_capture = None          # tools/deform_capture.py: a list that receives the inputs of every fused backward
+
+
+def set_fused(on):
+    """tests / A-B runs: route every layer through the column-matrix path (False) or let the fused kernels take the
+    layers they support (True, the default; CPM_DEFORM_FUSED=0 in the environment switches them off in the library)"""
+    prev = _fused[0]
+    _fused[0] = bool(on)
+    return prev
+
+
+def fused_ok(geom, k):
+    """the sampling-inside-the-contraction kernels (csrc/deform_fused.hip) take this layer"""
+    n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
+    return _fused[0] and bool(n and p and q) and bool(H.lib().cpm_deform_conv_fused_supported(n, h, w, c, int(k), r, s, stride, pad,
+                                                                                dil, groups, dg, p, q))
+
+
+def _fused_args(geom, k):
+    n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
+    return (n, h, w, c, int(k), r, s, stride, pad, dil, groups, dg, p, q)
+
+
 def _w1x1(w):
     """[K, C/g, R, S] in KRSC memory -> the same bytes as a [K, R*S*C/g, 1, 1] weight (no copy)."""
     k, cg, r, s = w.shape
@@ -71,14 +95,25 @@ class _ColsConvFn(Function):
         ctx.wparam = w_in if (ctx.needs_input_grad[2] and getattr(w_in, "_cpm_grad_sink", None) is not None) else None
         if ctx.wparam is not None:
             F._note_use(w_in)
-        cols = sample_columns(x, offset, geom)
-        # the parameter's pre-split image (bf16x3) is the image of the [K, R*S*C/g, 1, 1] weight too: the same bytes
-        y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups,
-                             w4=F.w4_of(w_in, w, (w.shape[1] * w.shape[2] * w.shape[3])))
+        ctx.fused = fused_ok(geom, w.shape[0])
+        if ctx.fused:
+            # sampling inside the contraction, exact-f32 MFMA in either conv arithmetic: no column matrix
+            cols = None
+            y = F.empty_nhwc((geom[0], w.shape[0], geom[11], geom[12]), x)
+            with H.guard(x.device):
+                rc = H.lib().cpm_deform_conv_forward(H.ptr(x), H.ptr(offset), H.ptr(w), H.ptr(scale), H.ptr(shift),
+                                                     int(bool(relu)), *_fused_args(geom, w.shape[0]), H.ptr(y),
+                                                     H.stream())
+            H.check(rc, "deform_conv_forward")
+        else:
+            cols = sample_columns(x, offset, geom)
+            # the parameter's pre-split image (bf16x3) is the image of the [K, R*S*C/g, 1, 1] weight too: the same bytes
+            y = F.conv2d_forward(cols, _w1x1(w), scale, shift, None, 0, relu, 1, 0, 1, groups,
+                                 w4=F.w4_of(w_in, w, (w.shape[1] * w.shape[2] * w.shape[3])))
         ctx.geom, ctx.relu = geom, relu
         ctx.out_tag = out_tag                      # see conv._ConvFn: gate + scale applied by the sole consumer's dgrad
         ctx.has = (scale is not None, shift is not None)
-        need_cols = ctx.needs_input_grad[2]
+        need_cols = ctx.needs_input_grad[2] and not ctx.fused
         ctx.save_for_backward(x, offset, w, scale, y if relu else None, cols if need_cols else None)
         return y
 
@@ -99,20 +134,55 @@ class _ColsConvFn(Function):
         w1 = _w1x1(w)
         dw = None
         done_wp = None
+        fargs = _fused_args(ctx.geom, w.shape[0])
+        need_off = need_off and offset is not None
+        if _capture is not None and ctx.fused:
+            _capture.append((dpre.clone(), x, offset, w, fargs))
+
+        def params(out, doff):
+            """fused: dw (+)= and d offset in ONE kernel (both read the four corners of every sample)"""
+            if dpre.numel() == 0:
+                if doff is not None:
+                    doff.zero_()
+                return
+            with H.guard(dy.device):
+                rc = H.lib().cpm_deform_conv_backward_params(H.ptr(dpre), H.ptr(x), H.ptr(offset), H.ptr(w), *fargs,
+                                                             H.ptr(out), H.ptr(doff), H.stream())
+            H.check(rc, "deform_conv_backward_params")
+
+        dx = doff = None
+        if ctx.fused and need_off:
+            doff = torch.empty_like(offset)
         if need_w:
             wp = ctx.wparam
             if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
-                F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups, out=wp._cpm_grad_sink)
+                if ctx.fused:
+                    params(wp._cpm_grad_sink, doff)
+                else:
+                    F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups, out=wp._cpm_grad_sink)
                 done_wp = wp                            # announced at the end: the data gradient below still reads w
             else:
                 if wp is not None:                      # this use reaches the parameter through autograd's accumulation
                     wp._cpm_uses -= 1
-                dw1 = F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups)
                 k, cg = w.shape[0], w.shape[1]
+                if ctx.fused:
+                    dw1 = torch.zeros((k, r * s * cg, 1, 1), dtype=torch.float32, device=dy.device)
+                    params(dw1, doff)
+                else:
+                    dw1 = F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups)
                 dw = dw1.view(k, r, s, cg).permute(0, 3, 1, 2)
-        dx = doff = None
-        need_off = need_off and offset is not None
-        if need_x or need_off:
+        elif doff is not None:
+            params(None, doff)
+        if ctx.fused:
+            if need_x:
+                # the tap's column gradient in registers -> dx through an LDS window
+                dx = F.empty_nhwc((n, c, h, wd), dy).zero_()
+                if dpre.numel():
+                    with H.guard(dy.device):
+                        rc = H.lib().cpm_deform_conv_backward_data(H.ptr(dpre), H.ptr(offset), H.ptr(w), *fargs,
+                                                                   H.ptr(dx), H.stream())
+                    H.check(rc, "deform_conv_backward_data")
+        elif need_x or need_off:
             dcols = F.conv2d_backward_data(dpre, w1, (n, r * s * c, p, q), 1, 0, 1, groups)
             args = (n, h, wd, c, r, s, stride, pad, dil, groups, dg, p, q)
             with H.guard(dy.device):

@@ -316,6 +316,29 @@ int cpm_deform_coord_grad(const float* dcols, const float* x, const float* offse
                           int R, int S, int stride, int pad, int dilation, int groups, int deformable_groups, int P,
                           int Q, float* doffset, void* stream);
 
+/* The same three reference entries (deform_conv_cuda.cu:324-460 forward, :463-600 input + offset gradient, :603-736
+ * parameter gradient) with the sampling INSIDE the contraction -- no column matrix in memory, exact-f32 MFMA
+ * arithmetic (csrc/deform_fused.hip).  Takes 3x3 layers with as many output as input channels, 4 / 8 / 16 / 32
+ * channels per group, C a multiple of 64 and 64-channel slabs inside one deformable group
+ * (cpm_deform_conv_fused_supported = 1; CPM_DEFORM_FUSED=0 answers 0 for everything); the entries fail with
+ * CPM_EINVAL on anything else.  w [K][3][3][C/groups] (KRSC); offset NULL = plain grouped 3x3.
+ *   forward:          y = relu?( conv * scale[k] + shift[k] ) (scale / shift may be NULL)
+ *   backward_data:    dx += (caller zero-fills); dpre = gradient at the conv
+ *   backward_params:  dw += (NULL = not wanted), doffset overwritten (NULL = not wanted; needs offset and w) */
+int cpm_deform_conv_fused_supported(int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                                    int dilation, int groups, int deformable_groups, int P, int Q);
+int cpm_deform_conv_forward(const float* x, const float* offset, const float* w, const float* scale,
+                            const float* shift, int relu, int N, int H, int W, int C, int K, int R, int S, int stride,
+                            int pad, int dilation, int groups, int deformable_groups, int P, int Q, float* y,
+                            void* stream);
+int cpm_deform_conv_backward_data(const float* dpre, const float* offset, const float* w, int N, int H, int W, int C,
+                                  int K, int R, int S, int stride, int pad, int dilation, int groups,
+                                  int deformable_groups, int P, int Q, float* dx, void* stream);
+int cpm_deform_conv_backward_params(const float* dpre, const float* x, const float* offset, const float* w, int N,
+                                    int H, int W, int C, int K, int R, int S, int stride, int pad, int dilation,
+                                    int groups, int deformable_groups, int P, int Q, float* dw, float* doffset,
+                                    void* stream);
+
 /* ---- Detection glue of the training step ----------------------
  * Fused replacements for per-image chains of small tensor ops in the reference's Python; all images of the batch
  * in one launch.  Boxes are float4 (x1,y1,x2,y2), 16-byte aligned; gt_off [num_images+1] holds each image's

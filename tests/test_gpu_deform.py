@@ -17,6 +17,13 @@ CASES = [  # N, C, H, W, K, stride, pad, dil, groups, dg
     (2, 512, 25, 21, 512, 2, 1, 1, 64, 1),      # layer2 block 0: stride 2, 8 per group
     (1, 128, 13, 17, 128, 1, 1, 1, 4, 4),       # 32 per group (layer4 class), 4 deformable groups
     (1, 100, 9, 10, 50, 1, 1, 1, 5, 2),         # channel counts that are not multiples of 64
+    # shapes the fused kernels (csrc/deform_fused.hip) take, beside the two X-101 classes above
+    (1, 128, 20, 28, 128, 1, 1, 1, 8, 1),       # 16 per group (layer3 class)
+    (1, 128, 13, 17, 128, 1, 1, 1, 4, 1),       # 32 per group (layer4 class): two 16x16 blocks per tap
+    (2, 64, 11, 19, 64, 1, 1, 1, 8, 1),         # 8 per group, two images, ragged patches
+    (1, 128, 12, 10, 128, 1, 1, 1, 16, 2),      # two deformable groups of one 64-channel slab each
+    (1, 64, 17, 23, 64, 2, 1, 1, 4, 1),         # stride 2
+    (1, 64, 16, 16, 64, 1, 2, 2, 4, 1),         # dilation 2
 ]
 
 
@@ -97,6 +104,57 @@ def test_C_deform_conv_binding_as_the_reference_calls_it(oracle, case):
                                groups, dg, step)                            # CPU tensors: "Not implemented on the CPU"
     with pytest.raises(RuntimeError, match="outside the CPM R-CNN hot path"):
         _C.modulated_deform_conv_forward()
+
+
+FULL_SIZE = [  # the X-101-64x4d-FPN-DCN body's 3x3 classes at bs=1, 800x1333 (BASELINE config #5): C, H, W, groups, offsets
+    (256, 200, 336, 64, False),     # layer1: plain grouped 3x3, 4 per group
+    (512, 100, 168, 64, True),      # layer2
+    (1024, 50, 84, 64, True),       # layer3 (23 blocks)
+    (2048, 25, 42, 64, True),       # layer4
+]
+
+
+@pytest.mark.parametrize("shape", FULL_SIZE)
+def test_fused_kernels_equal_column_path_at_full_size(shape):
+    """csrc/deform_fused.hip against the column-matrix path (itself checked against the oracle above) at the sizes the
+    benchmark runs: output, input / offset / weight gradients entry by entry.  Offsets are a trained predictor's
+    (|o| < 1.5: every sample inside a patch's LDS window) with one pixel in 16 thrown far (+-6: the direct-memory
+    route), some of them off the map."""
+    import sys
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip
+    dc = sys.modules["pet.lib.ops.deform_conv"]
+    C, H, W, groups, with_offset = shape
+    g = torch.Generator().manual_seed(11)
+    x = _cl(torch.randn(1, C, H, W, generator=g))
+    w = _cl(torch.randn(C, C // groups, 3, 3, generator=g) * (2.0 / (9 * C // groups)) ** 0.5)
+    off = None
+    if with_offset:
+        off = torch.rand(1, 18, H, W, generator=g) * 3 - 1.5
+        far = (torch.rand(1, 1, H, W, generator=g) < 1 / 16).float()
+        off = _cl(off + far * (torch.rand(1, 18, H, W, generator=g) * 12 - 6))
+    scale = (torch.rand(C, generator=g) + 0.5).cuda()
+    shift = torch.randn(C, generator=g).cuda()
+    dy = _cl(torch.randn(1, C, H, W, generator=g))
+    prev_math = _hip.get_conv_math()
+    _hip.set_conv_math("f32")
+    res = []
+    try:
+        for on in (False, True):
+            was = dc.set_fused(on)
+            try:
+                xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+                oi = off.clone().requires_grad_(True) if with_offset else None
+                y = ops.cols_conv(xi, oi, wi, scale, shift, 1, 1, 1, groups, 1, relu=True)
+                y.backward(dy)
+                res.append((y.detach(), xi.grad, wi.grad, oi.grad if with_offset else None))
+            finally:
+                dc.set_fused(was)
+    finally:
+        _hip.set_conv_math(prev_math)
+    for a, b in zip(res[1], res[0]):
+        if b is not None:
+            assert float((a - b).abs().max() / b.abs().max()) < 2e-5
 
 
 def test_zero_offset_equals_grouped_conv_kernel():
@@ -219,8 +277,12 @@ def test_resnext_dcn_body_vs_cpu_oracle():
             a, b = float(p.grad.norm()), float(want.norm())
             # bilinear sampling is continuous but its derivative w.r.t. the offsets jumps where a sample crosses a
             # pixel boundary, and the random (un-normalised) weights put many samples near one: 1e-6 forward
-            # differences move a few of them across, so norms agree to ~1 %, not to the 2e-3 of the plain ResNet
-            assert abs(a - b) <= 3e-2 * b + 1e-12, (key, a, b)
+            # differences move a few of them across, so norms agree to a few %, not to the 2e-3 of the plain ResNet.
+            # The size of that effect, measured between two exact-f32 implementations of this same stack
+            # (tools/deform_fused_ab.py: the fused kernels vs the column-matrix path, which agree to 1e-7 per layer on
+            # the same inputs -- tools/deform_fused_layers.py, test_..._layer_by_layer below): features 2e-4, gradient
+            # tensors 3.9 % in L2.  The bound that says something about the KERNELS is the per-layer one.
+            assert abs(a - b) <= 8e-2 * b + 1e-12, (key, a, b)
             checked += 1
         assert checked > 60
     finally:
@@ -239,14 +301,17 @@ def test_resnext_dcn_body_layer_by_layer_in_bf16x3():
         which are counted and bounded (< 0.1 % of a tensor) as for the plain body (tests/test_gpu_model.py)."""
     from test_host_logic import CPM_OPTS
     from detfill import det_fill_
+    import sys
     from pet.lib.ops import _hip
     from pet.lib.ops.deform_conv import DeformConvPack
     from pet.rcnn.core import config
     from pet.rcnn.modeling.model_builder import Generalized_RCNN
     from pet.utils.net import convert_bn2affine_model
+    dc = sys.modules["pet.lib.ops.deform_conv"]
     config.reset_cfg()
     config.merge_cfg_from_list(CPM_OPTS + X_OPTS)
     prev = _hip.get_conv_math()
+    was_fused = dc.set_fused(False)         # the column-matrix path is the one whose arithmetic follows the conv mode
     try:
         model = convert_bn2affine_model(Generalized_RCNN(is_train=True))
         det_fill_(model)
@@ -282,6 +347,15 @@ def test_resnext_dcn_body_layer_by_layer_in_bf16x3():
                 y = m._run(xi, oi, scale, shift, relu, False)
                 y.backward(dy)
                 res[math] = (off, y.detach(), xi.grad.detach(), oi.grad.detach())
+            # the fused kernels (exact f32 in either mode) on the same inputs: the layers they take agree with the
+            # column-matrix path's f32 run to rounding (measured 1e-7 .. 8e-7), entry by entry
+            dc.set_fused(True)
+            xi, oi = x32.clone().requires_grad_(True), off32.clone().requires_grad_(True)
+            y = m._run(xi, oi, scale, shift, relu, False)
+            y.backward(dy)
+            dc.set_fused(False)
+            for got, want in zip((y.detach(), xi.grad, oi.grad), res["f32"][1:]):
+                assert _rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5, n
             r0, r1 = res["f32"], res["bf16x3"]
             assert _rel(r0[1].cpu().numpy(), out32.cpu().numpy()) < 1e-6       # the teacher-forced f32 run IS the recorded one
             e_off = _rel(r1[0].cpu().numpy(), r0[0].cpu().numpy())
@@ -297,5 +371,6 @@ def test_resnext_dcn_body_layer_by_layer_in_bf16x3():
         print("DCN layers in bf16x3 vs f32, teacher-forced: offsets %.1e, forward %.1e; gradients: %.1e of the entries "
               "beyond 2e-3 of the maximum, L2 %.1e" % (worst["offset"], worst["forward"], worst["entries"], worst["l2"]))
     finally:
+        dc.set_fused(was_fused)
         _hip.set_conv_math(prev)
         config.reset_cfg()
