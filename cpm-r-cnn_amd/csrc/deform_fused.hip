@@ -14,20 +14,28 @@
 // LDS ONCE (off-map cells are zero = the reference's "corner outside the map contributes 0"); a record per
 // (pixel, tap) holds the sample's window cell and fractions.  Samples whose offsets leave the window read / update
 // memory directly (rare: a trained offset predictor moves samples by a pixel or two).
-//   A wave owns 16 channels of the slab and two 16-pixel rows of the patch (8 waves).  The contraction runs on the f32
-// MFMA `v_mfma_f32_16x16x4_f32` (exact f32 products and sums, MI355X_MICROARCH.md: 155 TFLOP/s measured; a layer has
-// 1.24 GFLOP) with the layer's weights in REGISTERS as dense 16x16 blocks per tap -- block-diagonal for groups narrower
-// than 16 channels (zeros cost MFMA time only, and the kernel is bound by LDS reads, not by the MFMA) and two blocks per
-// tap for 32-channel groups.  A lane samples FOUR consecutive channels of ONE pixel per tap with four ds_read_b128 (the
-// corners), which is the A fragment of four MFMAs: pixel = lane & 15, channels 4*(lane >> 4) .. +3.
-//   forward:         D[px][k] += sample[px][c] * W[c][k]                   -> affine / ReLU epilogue, y
-//   data gradient:   D[c][px]  = W[c][k] * dpre[k][px] (column gradient of one tap, in registers), then
-//                    dx window in LDS += corner weight * D (ds_add_f32; flushed with one float atomic per touched
-//                    window element), d offset += D * d(bilinear)/d(h|w) from the x window (LDS sums per pixel and tap,
-//                    one float atomic per pixel, tap and slab)
-//   weight gradient: D[k][c] += dpre[k][px] * sample[px][c]: the sampled tile goes through a per-wave LDS buffer to
+//   A wave owns 16 channels of the slab.  The contraction runs on the f32 MFMA `v_mfma_f32_16x16x4_f32` (exact f32
+// products and sums, MI355X_MICROARCH.md: 155 TFLOP/s measured; a layer has 1.24 GFLOP) with the layer's weights in
+// REGISTERS as dense 16x16 blocks per tap -- block-diagonal for groups narrower than 16 channels (zeros cost MFMA time
+// only, and these kernels are bound by LDS traffic and latency, not by the MFMA) and two blocks per tap for 32-channel
+// groups.  A lane samples FOUR consecutive channels of ONE pixel per tap with four ds_read_b128 (the corners), which is
+// the A fragment of four MFMAs: pixel = lane & 15, channels 4*(lane >> 4) .. +3.
+//   forward (8 waves: slice x half of the patch):
+//                    D[px][k] += sample[px][c] * W[c][k]                   -> affine / ReLU epilogue, y
+//   data gradient (4 waves, one per slice, so that a wave OWNS its channels of the dx window):
+//                    D[c][px]  = W[c][k] * dpre[k][px] (column gradient of one tap, in registers), then
+//                    dx window in LDS += corner weight * D by plain read-add-write in collision-free rounds (see the
+//                    kernel), flushed with one float atomic per touched window element; samples outside the window
+//                    add to memory directly, re-dealt so that an atomic instruction carries 64 contiguous bytes
+//   weight + offset gradient (4 waves; both need every sample's corners from the x window):
+//                    D[k][c] += dpre[k][px] * sample[px][c]: the sampled tile goes through a per-wave LDS buffer to
 //                    change lanes from (pixel, 4 channels) to (channel, 4 pixels); workgroups walk several patches
-//                    and add their 16x16 blocks to dw once
+//                    and add their 16x16 blocks to dw once.  d offset += column gradient * d(bilinear)/d(h|w), summed
+//                    over the wave's channels by an MFMA against ones, over the slab's slices in LDS, over the slabs by
+//                    one float atomic per (pixel, tap, h|w)
+// Measured (tools/time_deform.py, layer3's 1024 x 50 x 84, offsets within +-1.5 px / +-20 px): forward 46 / 85 us
+// (columns + grouped GEMM: 113), data gradient 199 / 364 (GEMM + col2im: 291 / 444), weight + offset gradient 139 / 186
+// (coord + weight GEMM: 146; but that path also needs the 155 MB of columns kept from the forward pass).
 #include <stdlib.h>
 
 #include "common.h"
@@ -298,26 +306,46 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
   }
   __syncthreads();
   const int coff = 16 * slice + 4 * lq;                         // the D rows of this lane: channels cs0 + 4*lq .. +3
+  auto load_dpre = [&](int tile, f32x4 (&v)[NS]) {
+    const int px = tile * 16 + l15;
+    const int p = t.p0 + (px >> 3), q = t.q0 + (px & 7);
+    const bool ok = tile < 4 && p < G.P && q < G.Q;
+    const float* dp = dpre + (((int64_t)t.n * G.P + (ok ? p : 0)) * G.Q + (ok ? q : 0)) * G.C;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) v[s] = ok ? *(const f32x4*)(dp + kq[s]) : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  f32x4 bnext[NS];
+  load_dpre(0, bnext);
   for (int tile = 0; tile < 4; ++tile) {
     f32x4 breg[NS];
-    {
-      const int px = tile * 16 + l15;
-      const int p = t.p0 + (px >> 3), q = t.q0 + (px & 7);
-      const bool ok = p < G.P && q < G.Q;
-      const float* dp = dpre + (((int64_t)t.n * G.P + (ok ? p : 0)) * G.Q + (ok ? q : 0)) * G.C;
 #pragma unroll
-      for (int s = 0; s < NS; ++s) breg[s] = ok ? *(const f32x4*)(dp + kq[s]) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < NS; ++s) breg[s] = bnext[s];
+    load_dpre(tile + 1, bnext);                       // in flight while this tile is scattered
+    // the nine taps' column gradients (independent MFMA chains) and records of this tile, before the window updates
+    // (whose wave fences keep the compiler from looking ahead)
+    f32x4 gs[DF_TAPS];
+    int4 recs[DF_TAPS];
+    int ranks[DF_TAPS];
+#pragma unroll
+    for (int tap = 0; tap < DF_TAPS; ++tap) {
+      recs[tap] = srec[tap * DF_PX + tile * 16 + l15];
+      ranks[tap] = srank[tap * DF_PX + tile * 16 + l15];
+      gs[tap] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+        for (int tap = 0; tap < DF_TAPS; ++tap)
+          gs[tap] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tap][s][kb], breg[s][kb], gs[tap], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int tap = 0; tap < DF_TAPS; ++tap) {
-      f32x4 g = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int s = 0; s < NS; ++s) {
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb) g = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[tap][s][kb], breg[s][kb], g, 0, 0, 0);
-      }
-      const int4 rec = srec[tap * DF_PX + tile * 16 + l15];
-      const int rank = srank[tap * DF_PX + tile * 16 + l15];
+      const f32x4 g = gs[tap];
+      const int4 rec = recs[tap];
+      const int rank = ranks[tap];
       const bool valid = rec.x != -2, inwin = rec.x >= 0;
       const float lh = __int_as_float(rec.y), lw = __int_as_float(rec.z);
       const float hh = 1.f - lh, hw = 1.f - lw;
@@ -336,8 +364,8 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
       }
       // samples that left the window: direct float atomics.  The lanes are re-dealt through LDS from (pixel, 4 channels)
       // to (4 pixels) x (16 channels), so that an atomic instruction carries 64 contiguous bytes per sample corner
-      // instead of four scattered words of sixteen samples (measured: 1.5 ms -> see DESIGN for a layer whose offsets
-      // had grown to tens of pixels)
+      // instead of four scattered words of sixteen samples (a layer whose offsets are tens of pixels: 1.5 -> 0.37 ms,
+      // the rate the column path's scatter kernel reaches on the same offsets)
       if (__builtin_amdgcn_ballot_w64(valid && !inwin) != 0) {
         *(f32x4*)(tb + l15 * 16 + 4 * lq) = g;
         df_wave_fence();
@@ -364,6 +392,7 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
   }
   __syncthreads();
   // flush: a wave adds whole cells (64 channels = 256 contiguous bytes per atomic instruction)
+#pragma unroll 4
   for (int cell = tid >> 6; cell < cells; cell += DF_BT / 64) {
     const int cy = cell / G.win_w;
     const int yy = t.wy0 + cy, xx = t.wx0 + (cell - cy * G.win_w);
@@ -429,28 +458,49 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_par_kernel(const float* _
     df_records(G, DEFORM ? offset : nullptr, t, dgu, srec);
     df_load_window(G, xb, c0, t, win);
     __syncthreads();
-    for (int tile = 0; tile < 4; ++tile) {
-      float aw[4];                                         // dpre[pixel 4*lq + kb of the tile][k0 + l15]
-      f32x4 bd[NS];                                        // dpre[pixel l15 of the tile][kq .. +3]
+    auto load_dpre = [&](int tile, float (&a)[4], f32x4 (&b)[NS]) {
       if (WANT_W) {
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
           const int px = tile * 16 + 4 * lq + kb;
           const int p = t.p0 + (px >> 3), q = t.q0 + (px & 7);
-          aw[kb] = (p < G.P && q < G.Q) ? dpre[(((int64_t)t.n * G.P + p) * G.Q + q) * G.C + k0 + l15] : 0.f;
+          a[kb] = (tile < 4 && p < G.P && q < G.Q) ? dpre[(((int64_t)t.n * G.P + p) * G.Q + q) * G.C + k0 + l15] : 0.f;
         }
       }
+      if (WANT_OFF) {
+        const int px = tile * 16 + l15;
+        const int p = t.p0 + (px >> 3), q = t.q0 + (px & 7);
+        const bool ok = tile < 4 && p < G.P && q < G.Q;
+        const int64_t m = ((int64_t)t.n * G.P + (ok ? p : 0)) * G.Q + (ok ? q : 0);
+#pragma unroll
+        for (int s = 0; s < NS; ++s) b[s] = ok ? *(const f32x4*)(dpre + m * G.C + kq[s]) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    };
+    float aw_next[4];
+    f32x4 bd_next[NS];
+    load_dpre(0, aw_next, bd_next);
+    for (int tile = 0; tile < 4; ++tile) {
+      float aw[4];                                         // dpre[pixel 4*lq + kb of the tile][k0 + l15]
+      f32x4 bd[NS];                                        // dpre[pixel l15 of the tile][kq .. +3]
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) aw[kb] = aw_next[kb];
+#pragma unroll
+      for (int s = 0; s < NS; ++s) bd[s] = bd_next[s];
+      load_dpre(tile + 1, aw_next, bd_next);               // in flight while this tile is worked on
       const int px = tile * 16 + l15;
       const int p = t.p0 + (px >> 3), q = t.q0 + (px & 7);
       const bool ok = p < G.P && q < G.Q;
       const int64_t m = ((int64_t)t.n * G.P + (ok ? p : 0)) * G.Q + (ok ? q : 0);
-      if (WANT_OFF) {
+      // the tile's records up front (the wave fences below keep the compiler from looking ahead) where registers allow
+      constexpr bool PRE = !(NS == 2 && WANT_W && WANT_OFF);
+      int4 recs[DF_TAPS];
+      if (PRE) {
 #pragma unroll
-        for (int s = 0; s < NS; ++s) bd[s] = ok ? *(const f32x4*)(dpre + m * G.C + kq[s]) : f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < DF_TAPS; ++tap) recs[tap] = srec[tap * DF_PX + px];
       }
 #pragma unroll
       for (int tap = 0; tap < DF_TAPS; ++tap) {
-        const int4 rec = srec[tap * DF_PX + px];
+        const int4 rec = PRE ? recs[tap] : srec[tap * DF_PX + px];
         const float lh = __int_as_float(rec.y), lw = __int_as_float(rec.z);
         const float hh = 1.f - lh, hw = 1.f - lw;
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
@@ -483,11 +533,16 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_par_kernel(const float* _
           }
         }
         if (WANT_OFF) {
-          gh += __shfl_xor(gh, 16, 64);
-          gw += __shfl_xor(gw, 16, 64);
-          gh += __shfl_xor(gh, 32, 64);
-          gw += __shfl_xor(gw, 32, 64);
-          if (lq == 0) *(float2*)(soff + ((slice * DF_TAPS + tap) * 16 + l15) * 2) = make_float2(gh, gw);
+          // the sum over the wave's four channel quads on the (idle) MFMA: D[px][j] = sum_quad partial[px][quad] * 1;
+          // lane (j, quad q) then holds the sums of pixels 4q .. 4q+3
+          const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 rh = __builtin_amdgcn_mfma_f32_16x16x4f32(gh, 1.f, z, 0, 0, 0);
+          const f32x4 rw = __builtin_amdgcn_mfma_f32_16x16x4f32(gw, 1.f, z, 0, 0, 0);
+          if (l15 < 4) {
+            const float vh = l15 == 0 ? rh[0] : l15 == 1 ? rh[1] : l15 == 2 ? rh[2] : rh[3];
+            const float vw = l15 == 0 ? rw[0] : l15 == 1 ? rw[1] : l15 == 2 ? rw[2] : rw[3];
+            *(float2*)(soff + ((slice * DF_TAPS + tap) * 16 + 4 * lq + l15) * 2) = make_float2(vh, vw);
+          }
         }
         if (WANT_W) {
           df_wave_fence();

@@ -8,6 +8,8 @@ its weight gradient are ONE grouped 1x1 problem each on the MFMA implicit-GEMM k
 bias / ReLU fused in the epilogue; `cpm_deform_col2im` / `cpm_deform_coord_grad` scatter the column gradient back
 to the input and the offsets.  `offset=None` runs the same path as a plain im2col: that is how ResNeXt's ordinary
 3x3 convs with 4..32 channels per group avoid zero-padding every group to a 32-deep MFMA k-step."""
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -50,6 +52,22 @@ def sample_columns(x, offset, geom):
 
 
 _fused = [True]
+# the fused backward is two kernels that do not depend on each other -- the data gradient (dx through an LDS window)
+# and the parameter gradients (dw, d offset from the x window) -- each of which holds a CU's LDS with two workgroups of
+# four waves: they run side by side, the second on a stream of its own, joined before the backward returns
+_OVERLAP = os.environ.get("CPM_DEFORM_OVERLAP", "1") != "0"
+_par_streams = {}
+
+
+def _par_stream(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _par_streams.get(idx)
+    if st is None:
+        t = torch.cuda.Stream(device=device)
+        st = _par_streams[idx] = (t, t.cuda_stream)
+    return st
+
+
 _capture = None          # tools/deform_capture.py: a list that receives the inputs of every fused backward
 
 
@@ -77,6 +95,32 @@ def _w1x1(w):
     """[K, C/g, R, S] in KRSC memory -> the same bytes as a [K, R*S*C/g, 1, 1] weight (no copy)."""
     k, cg, r, s = w.shape
     return w.permute(0, 2, 3, 1).reshape(k, r * s * cg, 1, 1)
+
+
+def _param_grads(ctx, need_w, params, cols, dpre, w, w1, doff, r, s, groups, dy):
+    """dw (in the parameter's sink, or returned) and -- fused -- d offset by the same kernel"""
+    dw = done_wp = None
+    if need_w:
+        wp = ctx.wparam
+        if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
+            if ctx.fused:
+                params(wp._cpm_grad_sink, doff)
+            else:
+                F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups, out=wp._cpm_grad_sink)
+            done_wp = wp                            # announced at the end: the data gradient still reads w
+        else:
+            if wp is not None:                      # this use reaches the parameter through autograd's accumulation
+                wp._cpm_uses -= 1
+            k, cg = w.shape[0], w.shape[1]
+            if ctx.fused:
+                dw1 = torch.zeros((k, r * s * cg, 1, 1), dtype=torch.float32, device=dy.device)
+                params(dw1, doff)
+            else:
+                dw1 = F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups)
+            dw = dw1.view(k, r, s, cg).permute(0, 3, 1, 2)
+    elif doff is not None:
+        params(None, doff)
+    return dw, done_wp
 
 
 class _ColsConvFn(Function):
@@ -153,26 +197,19 @@ class _ColsConvFn(Function):
         dx = doff = None
         if ctx.fused and need_off:
             doff = torch.empty_like(offset)
-        if need_w:
-            wp = ctx.wparam
-            if wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr():
-                if ctx.fused:
-                    params(wp._cpm_grad_sink, doff)
-                else:
-                    F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups, out=wp._cpm_grad_sink)
-                done_wp = wp                            # announced at the end: the data gradient below still reads w
-            else:
-                if wp is not None:                      # this use reaches the parameter through autograd's accumulation
-                    wp._cpm_uses -= 1
-                k, cg = w.shape[0], w.shape[1]
-                if ctx.fused:
-                    dw1 = torch.zeros((k, r * s * cg, 1, 1), dtype=torch.float32, device=dy.device)
-                    params(dw1, doff)
-                else:
-                    dw1 = F.conv2d_backward_weight(cols, dpre, w1, 1, 0, 1, groups)
-                dw = dw1.view(k, r, s, cg).permute(0, 3, 1, 2)
-        elif doff is not None:
-            params(None, doff)
+        side = None
+        wp = ctx.wparam
+        in_sink = wp is not None and wp._cpm_grad_sink.data_ptr() != 0 and w.data_ptr() == wp.data_ptr()
+        # (a dw that is returned is zero-filled by torch on the compute stream: that route stays on it)
+        if ctx.fused and _OVERLAP and need_x and (need_w or need_off) and (in_sink or not need_w) and dpre.numel():
+            side = _par_stream(dy.device)[1]
+            main_raw = H.stream_raw()
+            H.fork(main_raw, side)                  # dpre, the sink's earlier writers
+            params_on = H.use_stream(side)
+        else:
+            params_on = H._NoGuard()
+        with params_on:
+            dw, done_wp = _param_grads(ctx, need_w, params, cols, dpre, w, w1, doff, r, s, groups, dy)
         if ctx.fused:
             if need_x:
                 # the tap's column gradient in registers -> dx through an LDS window
@@ -182,6 +219,8 @@ class _ColsConvFn(Function):
                         rc = H.lib().cpm_deform_conv_backward_data(H.ptr(dpre), H.ptr(offset), H.ptr(w), *fargs,
                                                                    H.ptr(dx), H.stream())
                     H.check(rc, "deform_conv_backward_data")
+            if side is not None:
+                H.fork(side, main_raw)              # the compute stream waits for dw / d offset
         elif need_x or need_off:
             dcols = F.conv2d_backward_data(dpre, w1, (n, r * s * c, p, q), 1, 0, 1, groups)
             args = (n, h, wd, c, r, s, stride, pad, dil, groups, dg, p, q)

@@ -801,8 +801,11 @@ def test_chain_side_jobs_of_groupnorm(monkeypatch):
             y.backward(go)
             torch.cuda.synchronize()
             res[on] = (y.detach().clone(), t.grad.clone(), opt.flat_grad.clone())
+        # float atomics in both runs: the order of a split reduction's partial sums differs from run to run.  Measured
+        # 1e-6 .. 2.3e-5 over repeated runs (one in five crossed the 2e-5 this bound started at); a side job gone
+        # wrong -- a missing bias fill, a gradient not cleared -- is an error of order one
         for a, b in zip(res["1"], res["0"]):
-            assert relerr(a, b) < 2e-5
+            assert relerr(a, b) < 1e-4
     finally:
         H.set_conv_math(prev)
         config.reset_cfg()
