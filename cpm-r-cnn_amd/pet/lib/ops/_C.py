@@ -284,8 +284,17 @@ def deform_conv_forward(input, weight, offset, output, columns, ones, kW, kH, dW
     H.require_gpu(output)
     if output.numel() == 0:
         return 1
-    cols = sample_columns(F.nhwc(input), F.nhwc(offset), geom)
-    y = F.conv2d_forward(cols, _w1x1(F._wmem(weight)), None, None, None, 0, False, 1, 0, 1, int(group))
+    from .deform_conv import _fused_args, fused_ok
+    x, off, wm = F.nhwc(input), F.nhwc(offset), F._wmem(weight)
+    if fused_ok(geom, weight.size(0)):              # sampling inside the contraction (csrc/deform_fused.hip)
+        y = F.empty_nhwc((n, weight.size(0), p, q), x)
+        with H.guard(x.device):
+            rc = H.lib().cpm_deform_conv_forward(H.ptr(x), H.ptr(off), H.ptr(wm), None, None, 0,
+                                                 *_fused_args(geom, weight.size(0)), H.ptr(y), H.stream())
+        H.check(rc, "deform_conv_forward")
+    else:
+        cols = sample_columns(x, off, geom)
+        y = F.conv2d_forward(cols, _w1x1(wm), None, None, None, 0, False, 1, 0, 1, int(group))
     output.copy_(y)
     return 1
 
@@ -305,15 +314,25 @@ def deform_conv_backward_input(input, offset, gradOutput, gradInput, gradOffset,
         raise RuntimeError("deform_conv_backward_input: gradInput / gradOffset must match input / offset")
     if input.numel() == 0 or gradOutput.numel() == 0:
         return 1
-    x, off = F.nhwc(input), F.nhwc(offset)
-    dcols = F.conv2d_backward_data(F.nhwc(gradOutput), _w1x1(F._wmem(weight)), (n, r * s * c, p, q), 1, 0, 1, groups)
+    from .deform_conv import _fused_args, fused_ok
+    x, off, wm, dy = F.nhwc(input), F.nhwc(offset), F._wmem(weight), F.nhwc(gradOutput)
     dx = F.empty_nhwc((n, c, h, w), x).zero_()
     doff = torch.empty_like(off)
-    with H.guard(x.device):
-        rc = H.lib().cpm_deform_col2im(H.ptr(dcols), H.ptr(off), *geom, H.ptr(dx), H.stream())
-        H.check(rc, "deform_col2im")
-        rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(off), *geom, H.ptr(doff), H.stream())
-        H.check(rc, "deform_coord_grad")
+    if fused_ok(geom, weight.size(0)):
+        fa = _fused_args(geom, weight.size(0))
+        with H.guard(x.device):
+            rc = H.lib().cpm_deform_conv_backward_data(H.ptr(dy), H.ptr(off), H.ptr(wm), *fa, H.ptr(dx), H.stream())
+            H.check(rc, "deform_conv_backward_data")
+            rc = H.lib().cpm_deform_conv_backward_params(H.ptr(dy), H.ptr(x), H.ptr(off), H.ptr(wm), *fa, None,
+                                                         H.ptr(doff), H.stream())
+            H.check(rc, "deform_conv_backward_params")
+    else:
+        dcols = F.conv2d_backward_data(dy, _w1x1(wm), (n, r * s * c, p, q), 1, 0, 1, groups)
+        with H.guard(x.device):
+            rc = H.lib().cpm_deform_col2im(H.ptr(dcols), H.ptr(off), *geom, H.ptr(dx), H.stream())
+            H.check(rc, "deform_col2im")
+            rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(off), *geom, H.ptr(doff), H.stream())
+            H.check(rc, "deform_coord_grad")
     gradInput.copy_(dx)
     gradOffset.copy_(doff)
     return 1
@@ -335,9 +354,18 @@ def deform_conv_backward_filter(input, offset, gradOutput, gradWeight, columns, 
         raise RuntimeError("deform_conv_backward_filter: gradOutput must be [%d, %d, %d, %d]" % (n, k, p, q))
     if input.numel() == 0 or gradOutput.numel() == 0:
         return 1
-    cols = sample_columns(F.nhwc(input), F.nhwc(offset), geom)
-    w1_like = torch.empty((k, r * s * cg, 1, 1), dtype=torch.float32, device=input.device)
-    dw1 = F.conv2d_backward_weight(cols, F.nhwc(gradOutput), w1_like, 1, 0, 1, groups)       # [K, (r,s,c), 1, 1]
+    from .deform_conv import _fused_args, fused_ok
+    x, off, dy = F.nhwc(input), F.nhwc(offset), F.nhwc(gradOutput)
+    if fused_ok(geom, k):
+        dw1 = torch.zeros((k, r * s * cg, 1, 1), dtype=torch.float32, device=input.device)
+        with H.guard(x.device):
+            rc = H.lib().cpm_deform_conv_backward_params(H.ptr(dy), H.ptr(x), H.ptr(off), None, *_fused_args(geom, k),
+                                                         H.ptr(dw1), None, H.stream())
+        H.check(rc, "deform_conv_backward_params")
+    else:
+        cols = sample_columns(x, off, geom)
+        w1_like = torch.empty((k, r * s * cg, 1, 1), dtype=torch.float32, device=input.device)
+        dw1 = F.conv2d_backward_weight(cols, dy, w1_like, 1, 0, 1, groups)                    # [K, (r,s,c), 1, 1]
     gradWeight.add_(dw1.view(k, r, s, cg).permute(0, 3, 1, 2), alpha=float(scale))
     return 1
 

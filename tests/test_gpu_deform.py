@@ -60,7 +60,7 @@ def test_cols_conv_vs_oracle(oracle, case, with_offset, conv_math):
         assert _rel(og.grad.cpu().numpy(), want[2]) < 5 * TOL
 
 
-@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[6]])
+@pytest.mark.parametrize("case", [CASES[0], CASES[1], CASES[6], CASES[8], CASES[12]])
 def test_C_deform_conv_binding_as_the_reference_calls_it(oracle, case):
     """_C.deform_conv_forward / _backward_input / _backward_filter with the reference's caller-owned-buffer contract
     (csrc/Deformable/deform_conv.h:115-259, bound at vision.cpp:38-40), driven exactly as the reference's
