@@ -498,11 +498,22 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_par_kernel(const float* _
 #pragma unroll
         for (int tap = 0; tap < DF_TAPS; ++tap) recs[tap] = srec[tap * DF_PX + px];
       }
+      // one 16-channel block per tap (NS == 1): the NEXT tap's corners are requested before this tap's wave fences, so
+      // that their latency -- LDS for samples in the window, memory for the others: ~1.5 us each, 36 in a row per patch
+      // otherwise -- runs under this tap's work
+      constexpr bool PIPE = NS == 1;
+      f32x4 pa, pb, pd, pe;
+      bool pany = false;
+      if (PIPE) pany = df_corners<DEFORM>(win, recs[0], coff[0], G, xb, c0 + coff[0], pa, pb, pd, pe);
 #pragma unroll
       for (int tap = 0; tap < DF_TAPS; ++tap) {
         const int4 rec = PRE ? recs[tap] : srec[tap * DF_PX + px];
         const float lh = __int_as_float(rec.y), lw = __int_as_float(rec.z);
         const float hh = 1.f - lh, hw = 1.f - lw;
+        f32x4 na, nb, nd, ne;
+        bool nany = false;
+        if (PIPE && tap + 1 < DF_TAPS)
+          nany = df_corners<DEFORM>(win, recs[tap + 1], coff[0], G, xb, c0 + coff[0], na, nb, nd, ne);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         if (WANT_OFF) {
 #pragma unroll
@@ -517,7 +528,13 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_par_kernel(const float* _
         for (int s = 0; s < NS; ++s) {
           if (!WANT_W && s != s_own) continue;
           f32x4 a, b, d, e;
-          const bool any = df_corners<DEFORM>(win, rec, coff[s], G, xb, c0 + coff[s], a, b, d, e);
+          bool any;
+          if (PIPE) {
+            a = pa; b = pb; d = pd; e = pe;
+            any = pany;
+          } else {
+            any = df_corners<DEFORM>(win, rec, coff[s], G, xb, c0 + coff[s], a, b, d, e);
+          }
           if (WANT_W) {
             f32x4 v = a;
             if (DEFORM) v = (hh * hw) * a + (hh * lw) * b + (lh * hw) * d + (lh * lw) * e;
@@ -555,6 +572,10 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_par_kernel(const float* _
             }
           }
           df_wave_fence();
+        }
+        if (PIPE) {
+          pa = na; pb = nb; pd = nd; pe = ne;
+          pany = nany;
         }
       }
       if (WANT_OFF) {
