@@ -2748,7 +2748,12 @@ int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t
     // by their prologues); the accumulating data gradient (residual == output) and strided output rows are faster
     // through igemm_kernel's LDS-staged row-wise epilogue (256->128 stride 2: 30 vs 41 us) and stay there.
     const bool dense_out = a.osh == 1 && a.osw == 1 && a.OHp == a.OH && a.OWp == a.OW;
-    if (pt == 1 || (tiles > (int64_t)per_cu * num_cus() && dense_out && !(a.res && a.res == a.out))) {
+    // ... and at least two full rounds of them: a run length is a whole number, so 1056 tiles on 1024 slots would go to
+    // 528 workgroups of two tiles -- half the chip's slots -- where the plain grid runs one full round and a tail
+    // (1024 -> 1024 1x1 on 50x84, X-101 at bs=1: 59 us persistent, 51 plain)
+    static const int min_rounds = env_int("CPM_IGEMM_PT_MIN_ROUNDS", 2);
+    const int64_t slots = (int64_t)per_cu * num_cus();
+    if (pt == 1 || (tiles > slots && tiles >= min_rounds * slots && dense_out && !(a.res && a.res == a.out))) {
       if (bm == 128 && bn == 128) return launch_pt<128, 128, 2, 2>(a, per_cu, s);
       if (bm == 128 && bn == 64) return launch_pt<128, 64, 2, 2>(a, per_cu, s);
       if (bm == 64 && bn == 64) return launch_pt<64, 64, 2, 2>(a, per_cu, s);

@@ -42,6 +42,12 @@ LAYERS = [
     ("fc6_R1024", 1024, 256, 7, 7, 1024, 7, 1, 0, 1, 2),
     ("fc7_R1024", 1024, 1024, 1, 1, 1024, 1, 1, 0, 1, 2),
     ("iou_fc1_R64", 64, 576, 7, 7, 1024, 7, 1, 0, 1, 1),
+    # X-101-64x4d-FPN-DCN at bs=1 (BASELINE config #5): the dense convs around the grouped / deformable 3x3s
+    ("x_l1_1x1_256_256", 1, 256, 200, 336, 256, 1, 1, 0, 1, 5),
+    ("x_l2_1x1_512_512", 1, 512, 100, 168, 512, 1, 1, 0, 1, 7),
+    ("x_l3_1x1_1024_1024", 1, 1024, 50, 84, 1024, 1, 1, 0, 1, 45),
+    ("x_l4_1x1_2048_2048", 1, 2048, 25, 42, 2048, 1, 1, 0, 1, 5),
+    ("x_l3_offset_1024_18", 1, 1024, 50, 84, 18, 3, 1, 1, 1, 23),
 ]
 
 
