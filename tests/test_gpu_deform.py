@@ -24,6 +24,10 @@ CASES = [  # N, C, H, W, K, stride, pad, dil, groups, dg
     (1, 128, 12, 10, 128, 1, 1, 1, 16, 2),      # two deformable groups of one 64-channel slab each
     (1, 64, 17, 23, 64, 2, 1, 1, 4, 1),         # stride 2
     (1, 64, 16, 16, 64, 1, 2, 2, 4, 1),         # dilation 2
+    (3, 64, 5, 6, 64, 1, 1, 1, 16, 1),          # maps smaller than one 8x8 patch, three images, 4 per group
+    (1, 64, 12, 9, 64, 1, 0, 1, 8, 1),          # no padding (output 10x7)
+    (1, 64, 15, 13, 64, 2, 0, 1, 2, 1),         # stride 2 without padding, 32 per group
+    (1, 192, 11, 10, 192, 1, 3, 3, 12, 3),      # dilation 3, three slabs = three deformable groups
 ]
 
 
