@@ -129,6 +129,10 @@ class _ColsConvFn(Function):
     @staticmethod
     def forward(ctx, x, offset, w, scale, shift, stride, pad, dil, groups, dg, relu, out_tag=None):
         H.require_gpu(x, offset, w, scale, shift)
+        # the input may be a multi-consumer activation with an in-place gradient accumulator (conv.mark_shared_grad:
+        # DeformConvPack's input feeds this node and the offset predictor) and carry its producer's ReLU-gate tag
+        ctx.x_holder = getattr(x, "_cpm_gacc", None)
+        ctx.in_tag = getattr(x, "_cpm_epi", None)
         x = F.nhwc(x)
         w_in = w
         w = F._wmem(w)
@@ -236,6 +240,17 @@ class _ColsConvFn(Function):
                         rc = H.lib().cpm_deform_coord_grad(H.ptr(dcols), H.ptr(x), H.ptr(offset), *args, H.ptr(doff),
                                                            H.stream())
                         H.check(rc, "deform_coord_grad")
+        if dx is not None:
+            if ctx.in_tag is not None:
+                ctx.in_tag["applied"] = False       # a contribution without the producer's gate: a later consumer's
+            h = ctx.x_holder                        # data-gradient kernel masks the running sum, or the producer does
+            if h is not None:
+                if "acc" in h and tuple(h["acc"].shape) == tuple(dx.shape):
+                    F._wait_readers(h)
+                    h["acc"].add_(dx)
+                    dx = None
+                else:
+                    h["acc"] = dx                   # handed to autograd below; later consumers add into it in place
         if done_wp is not None:
             F._sink_done(done_wp)
         return dx, doff, dw, None, dshift, None, None, None, None, None, None, None
@@ -323,5 +338,9 @@ class DeformConvPack(DeformConv):
         self.conv_offset.bias.data.zero_()
 
     def forward(self, x, scale=None, shift=None, relu=False, sole_consumer=False):
+        # x has two consumers, both of this package: the offset predictor adds its data gradient INTO the tensor the
+        # sampled conv handed to autograd (and applies the gate of x's producer to the sum when x carries its tag)
+        # instead of autograd adding two tensors and the producer running a gate pass of its own
+        F.mark_shared_grad(x)
         offset = self.conv_offset(x)
         return self._run(x, offset, scale, shift, relu, sole_consumer)

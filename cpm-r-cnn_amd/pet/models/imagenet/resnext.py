@@ -50,7 +50,9 @@ class Bottleneck(nn.Module):
         # the downsample conv reads x only: its kernel runs on the second stream beside conv1 -> conv2 (ops.fwd_fork)
         forked = self.downsample is not None and ops.fwd_fork(x)
         s, b = _affine(self.bn1)
-        out = self.conv1(x, scale=s, shift=b, relu=True)
+        # conv1's output feeds conv2 alone, or -- a DeformConvPack -- its sampled conv and its offset predictor, whose
+        # data-gradient kernel (the last of the two to run) applies conv1's ReLU gate to their summed gradient
+        out = self.conv1(x, scale=s, shift=b, relu=True, gate_by_consumers=isinstance(self.conv2, ops.DeformConvPack))
         s, b = _affine(self.bn2)
         out = self.conv2(out, scale=s, shift=b, relu=True, sole_consumer=True)     # consumed by conv3 only
         residual = x
