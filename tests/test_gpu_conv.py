@@ -801,11 +801,23 @@ def test_chain_side_jobs_of_groupnorm(monkeypatch):
             y.backward(go)
             torch.cuda.synchronize()
             res[on] = (y.detach().clone(), t.grad.clone(), opt.flat_grad.clone())
-        # float atomics in both runs: the order of a split reduction's partial sums differs from run to run.  Measured
-        # 1e-6 .. 2.3e-5 over repeated runs (one in five crossed the 2e-5 this bound started at); a side job gone
-        # wrong -- a missing bias fill, a gradient not cleared -- is an error of order one
-        for a, b in zip(res["1"], res["0"]):
-            assert relerr(a, b) < 1e-4
+        # float atomics in both runs: the order of a split reduction's partial sums differs from run to run (1e-6 .. 2e-5
+        # per entry), and with it -- in about one run in eight of this fixture, side jobs on or off alike -- the sign of
+        # ONE pre-activation that lies within that noise of zero.  Its ReLU gate flips; through the GroupNorm sums of its
+        # group and the 3x3s below, that RoI's gradients and every weight gradient move a little: 1.6 % / 4.1 % of the
+        # entries by more than 1e-4 of the maximum, at most 6e-3 of it, L2 8.3e-4 (tools/chain_fill_stress.py: 60 runs
+        # against an ordered-reduction reference show exactly these two outcomes for either switch; with ordered
+        # reductions 200 runs are bit-identical, so it is the summation order and not a race).  The forward output has
+        # no gate between the compared runs and is held to 1e-4; the gradients to 5e-3 in L2 and 10 % of the entries
+        # beyond 1e-4.  A side job gone wrong -- a missing bias fill, a gradient buffer not cleared -- is an error of
+        # order one in every entry
+        assert relerr(res["1"][0], res["0"][0]) < 1e-4
+        for a, b in zip(res["1"][1:], res["0"][1:]):
+            a, b = a.double().cpu(), b.double().cpu()
+            diff = (a - b).abs()
+            assert bool(torch.isfinite(a).all())
+            assert float(diff.norm() / b.norm()) < 5e-3
+            assert float((diff > 1e-4 * b.abs().max()).double().mean()) < 0.1
     finally:
         H.set_conv_math(prev)
         config.reset_cfg()
