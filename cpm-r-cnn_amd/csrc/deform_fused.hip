@@ -621,7 +621,7 @@ constexpr size_t DF_LDS_MAX = 160 * 1024, DF_LDS_TWO = 80 * 1024;      // one / 
 
 // 0 when this path takes the layer; the reason otherwise
 const char* df_plan(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int dil, int groups, int dg,
-                    int P, int Q, DfPlan* out) {
+                    int P, int Q, DfPlan* out, bool deform = true) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || stride <= 0 || dil <= 0 || groups <= 0 || dg <= 0) return "bad geometry";
   if (R != 3 || S != 3) return "not a 3x3";
   if (K != C || C % groups) return "output channels differ from input channels";
@@ -644,7 +644,9 @@ const char* df_plan(int N, int H, int W, int C, int K, int R, int S, int stride,
   for (int kind = 0; kind < 3; ++kind) {
     // margin 2 when two workgroups per CU still fit (stride 1: 15 x 15 cells = 61 KB), else margin 1 if THAT gets two,
     // else the widest margin one workgroup can hold (stride 2: 22 x 22 cells = 132 KB)
-    int best = -1;
+    // (no offsets -- the plain narrow-group 3x3 -- : every sample sits on the footprint, no margin: 11 x 11 cells = 33 KB,
+    // three workgroups per CU)
+    int best = deform ? -1 : 0;
     for (int pass = 0; pass < 2 && best < 0; ++pass) {
       for (int mg = 2; mg >= (pass == 0 ? 1 : 0); --mg) {
         const int win = (DF_T - 1) * stride + 2 * dil + 2 + 2 * mg;
@@ -704,7 +706,7 @@ CPM_EXPORT int cpm_deform_conv_forward(const float* x, const float* offset, cons
                                        int stride, int pad, int dilation, int groups, int deformable_groups, int P,
                                        int Q, float* y, void* stream) {
   DfPlan p;
-  const char* why = df_plan(N, H, W, C, K, R, S, stride, pad, dilation, groups, deformable_groups, P, Q, &p);
+  const char* why = df_plan(N, H, W, C, K, R, S, stride, pad, dilation, groups, deformable_groups, P, Q, &p, offset != nullptr);
   CPM_REQUIRE(why == nullptr, why);
   CPM_REQUIRE(x && w && y, "null pointer");
   const dim3 grid((unsigned)(N * p.G[DF_FWD].tiles_p * p.G[DF_FWD].tiles_q), (unsigned)(C / DF_SLAB));
@@ -721,7 +723,7 @@ CPM_EXPORT int cpm_deform_conv_backward_data(const float* dpre, const float* off
                                              int groups, int deformable_groups, int P, int Q, float* dx,
                                              void* stream) {
   DfPlan p;
-  const char* why = df_plan(N, H, W, C, K, R, S, stride, pad, dilation, groups, deformable_groups, P, Q, &p);
+  const char* why = df_plan(N, H, W, C, K, R, S, stride, pad, dilation, groups, deformable_groups, P, Q, &p, offset != nullptr);
   CPM_REQUIRE(why == nullptr, why);
   CPM_REQUIRE(dpre && w && dx, "null pointer");
   const dim3 grid((unsigned)(N * p.G[DF_DX].tiles_p * p.G[DF_DX].tiles_q), (unsigned)(C / DF_SLAB));
@@ -737,7 +739,7 @@ CPM_EXPORT int cpm_deform_conv_backward_params(const float* dpre, const float* x
                                                int dilation, int groups, int deformable_groups, int P, int Q,
                                                float* dw, float* doffset, void* stream) {
   DfPlan p;
-  const char* why = df_plan(N, H, W, C, K, R, S, stride, pad, dilation, groups, deformable_groups, P, Q, &p);
+  const char* why = df_plan(N, H, W, C, K, R, S, stride, pad, dilation, groups, deformable_groups, P, Q, &p, offset != nullptr);
   CPM_REQUIRE(why == nullptr, why);
   CPM_REQUIRE(dpre && x, "null pointer");
   CPM_REQUIRE(dw || doffset, "nothing asked for");
