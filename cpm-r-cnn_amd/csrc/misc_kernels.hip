@@ -712,6 +712,12 @@ __global__ __launch_bounds__(256) void fill_rows4_kernel(float4* __restrict__ ou
     out[i] = bias4 ? bias4[i % c4] : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+__global__ __launch_bounds__(256) void fill_rows1_kernel(float* __restrict__ out, const float* __restrict__ bias,
+                                                         int64_t total, int c) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256)
+    out[i] = bias ? bias[i % c] : 0.f;
+}
+
 static int groupnorm_forward_impl(const float* x, const float* gamma, const float* beta, int N, int HW, int C, int G,
                                   float eps, int relu, float* y, float* mean, float* rstd, float* fill_out,
                                   const float* fill_bias, void* stream) {
@@ -740,10 +746,15 @@ static int groupnorm_forward_impl(const float* x, const float* gamma, const floa
   hipLaunchKernelGGL(gn_fwd_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, HW, C, G, eps, relu,
                      y, mean, rstd);
   if (fill_out) {                                            // (the general kernel has no side job: a launch of its own)
-    CPM_REQUIRE((C & 3) == 0 && ((((uintptr_t)fill_out | (uintptr_t)fill_bias) & 15) == 0), "fill: C % 4, 16-byte aligned");
-    const int64_t total4 = (int64_t)N * HW * C / 4;
-    hipLaunchKernelGGL(fill_rows4_kernel, dim3((unsigned)(total4 / 256 + 1 > 4096 ? 4096 : total4 / 256 + 1)), dim3(256), 0,
-                       (hipStream_t)stream, (float4*)fill_out, (const float4*)fill_bias, total4, C / 4);
+    if ((C & 3) == 0 && ((((uintptr_t)fill_out | (uintptr_t)fill_bias) & 15) == 0)) {
+      const int64_t total4 = (int64_t)N * HW * C / 4;
+      hipLaunchKernelGGL(fill_rows4_kernel, dim3((unsigned)(total4 / 256 + 1 > 4096 ? 4096 : total4 / 256 + 1)), dim3(256),
+                         0, (hipStream_t)stream, (float4*)fill_out, (const float4*)fill_bias, total4, C / 4);
+    } else {                                                 // any channel count / alignment: one element per thread
+      const int64_t total = (int64_t)N * HW * C;
+      hipLaunchKernelGGL(fill_rows1_kernel, dim3((unsigned)(total / 256 + 1 > 4096 ? 4096 : total / 256 + 1)), dim3(256), 0,
+                         (hipStream_t)stream, fill_out, fill_bias, total, C);
+    }
   }
   return cpm::check_launch("groupnorm_forward");
 }

@@ -177,6 +177,29 @@ class use_stream(object):
         return False
 
 
+# Tensors created inside a use_stream() section are compute-stream blocks to torch's caching allocator (torch's current
+# stream never changes), while the kernels that write them are queued on the override stream.  One that is dropped
+# before the compute stream has been made to wait for that stream would go back to the compute-stream pool with the side
+# kernel still pending, and the next compute-stream allocation could receive it.  keep() parks such tensors (RoIAlign's
+# level indices, layout / contiguity copies); release_kept() -- called by the joins, conv.fwd_join / conv._join_side --
+# drops them once the compute stream waits for the side stream.
+_side_keep = []
+
+
+def in_side_section():
+    return _override is not None
+
+
+def keep(*tensors):
+    """inside a use_stream() section: hold these tensors until the next join of the two streams"""
+    if _override is not None:
+        _side_keep.extend(t for t in tensors if t is not None)
+
+
+def release_kept():
+    del _side_keep[:]
+
+
 def fork(raw_from, raw_to):
     """stream `raw_to` waits for everything queued on `raw_from` so far (cpm_stream_fork)"""
     check(lib().cpm_stream_fork(c_void_p(raw_from), c_void_p(raw_to)), "stream_fork")

@@ -383,7 +383,9 @@ def wgrad_stream(device):
 # for them before their consumer is queued.  Only the KERNELS move: torch's current stream is untouched, so the autograd
 # nodes belong to the compute stream and the backward pass is what it was (in-place gradient accumulators, gradient
 # sinks and the weight-gradient fork / join assume one compute stream there); tensors allocated inside a side section
-# are compute-stream blocks that stay referenced past the join.  Results are bit-identical with the switch on or off.
+# are compute-stream blocks to the allocator: an op that creates one it does NOT return or save (RoIAlign's level
+# indices, a layout copy) parks it with H.keep() until the join, and an op that copies an input on the compute stream
+# inside a section orders the side stream behind the copy (H.fork).  Results are bit-identical with the switch on or off.
 _FWD_SIDE = os.environ.get("CPM_FWD_SIDE", "1") != "0"
 
 
@@ -409,6 +411,7 @@ def fwd_join(t):
     """the compute stream waits for the second stream"""
     idx = t.device.index
     H.fork(_side[idx][1], H._raw_stream(idx))
+    H.release_kept()            # temporaries of the side sections: compute-stream reuse is ordered behind the join now
 
 
 def _join_side():
@@ -417,6 +420,7 @@ def _join_side():
         H.fork(_side[idx][1], main_raw)
     _side_armed.clear()
     H.release_retired()         # side-stream workspaces replaced during this pass: the join above orders their reuse
+    H.release_kept()
 
 
 def _wgrad_on_side(x, dy, w, stride, pad, dil, groups, out, dbias, k_scale=None, want_event=False):
@@ -713,17 +717,24 @@ _RPN_SPARSE = int(os.environ.get("CPM_RPN_SPARSE", "1"))
 _rpn_sample = None
 
 
-def set_rpn_sample(out_ptrs, idx, cap, n_img):
-    """the loss over the head outputs at `out_ptrs` (data_ptr of every level's objectness map) is a sum over the anchors
-    listed in idx (int32 [cap], ascending flat positions, -1 behind the last): what _RPNHeadFn.backward may rely on"""
+class _RpnToken(object):
+    """one per forward pass of the RPN head"""
+    __slots__ = ()
+
+
+def set_rpn_sample(token, idx, cap, n_img):
+    """the loss over the head outputs of the forward pass identified by `token` (the `_cpm_rpn_sparse` attribute rpn_head
+    puts on every level's objectness map: one object per forward -- NOT an address, the caching allocator hands those
+    out again) is a sum over the anchors listed in idx (int32 [cap], ascending flat positions, -1 behind the last):
+    what _RPNHeadFn.backward may rely on"""
     global _rpn_sample
-    _rpn_sample = (tuple(out_ptrs), idx, int(cap), int(n_img))
+    _rpn_sample = (token, idx, int(cap), int(n_img))
 
 
-def _take_rpn_sample(out_ptrs):
+def _take_rpn_sample(token):
     global _rpn_sample
     s, _rpn_sample = _rpn_sample, None
-    return s if (s is not None and s[0] == tuple(out_ptrs)) else None
+    return s if (s is not None and token is not None and s[0] is token) else None
 
 
 def mask_compact(pos, neg, cap):
@@ -788,7 +799,7 @@ class _RPNHeadFn(Function):
             for i, (p, m) in enumerate(((w, wm), (b, b), (wc, wcm), (bc, bc), (wb, wbm), (bb, bb)))]
         ctx.holders = [getattr(f, "_cpm_gacc", None) for f in feats]
         ctx.n = len(xs)
-        ctx.out_ptrs = tuple(o.data_ptr() for o in outs_c)
+        ctx.token = _RpnToken()                     # identifies THIS forward pass to the loss (set_rpn_sample)
         ctx.save_for_backward(wm, wcm, wbm, *xs, *ts)
         return tuple(outs_c + outs_b)
 
@@ -808,7 +819,7 @@ class _RPNHeadFn(Function):
             return torch.zeros((x.shape[0], ch, x.shape[2], x.shape[3]), device=dev).contiguous(memory_format=CL)
         # (the sparse path reads <= cap elements of these maps: it takes them as they come -- slices of the loss's one
         # gradient tensor, dense inside an image -- instead of paying ten transposing copies; see _image_dense)
-        sample = _take_rpn_sample(ctx.out_ptrs)
+        sample = _take_rpn_sample(ctx.token)
         sparse = sample is not None and _RPN_SPARSE and (_RPN_SPARSE == 2 or not H.deterministic())
         raw = sparse and all(g is not None and _image_dense(g) for g in grads[:2 * n])
         dcs = [g if raw else (nhwc(g) if g is not None else zmap(x, a)) for g, x in zip(grads[:n], xs)]
@@ -948,11 +959,15 @@ def rpn_head(feats, w, b, wc, bc, wb, bb):
             or tuple(w.shape) != (c, c, 3, 3) or b is None or bc is None or bb is None
             or any(t.dim() != 4 or t.shape[1] != c for t in feats) or not torch.is_grad_enabled()):
         return None
+    global _rpn_sample
+    _rpn_sample = None                  # a sample announced for an earlier forward whose backward never ran is void
+    del H.deferred[:]                   # (likewise work a failed backward pass left parked)
     outs = _RPNHeadFn.apply(w, b, wc, bc, wb, bb, *feats)
     n = len(feats)
     lo, br = list(outs[:n]), list(outs[n:])
+    tok = getattr(outs[0].grad_fn, "token", None)      # (a Function's ctx IS its outputs' grad_fn)
     for o in lo:
-        o._cpm_rpn_sparse = True        # the loss that sums over a sample of these anchors may say so (set_rpn_sample)
+        o._cpm_rpn_sparse = tok         # the loss that sums over a sample of these anchors may say so (set_rpn_sample)
     return lo, br
 
 

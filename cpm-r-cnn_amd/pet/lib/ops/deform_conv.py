@@ -82,6 +82,11 @@ def set_fused(on):
 def fused_ok(geom, k):
     """the sampling-inside-the-contraction kernels (csrc/deform_fused.hip) take this layer"""
     n, h, w, c, r, s, stride, pad, dil, groups, dg, p, q = geom
+    # deterministic mode (cpm_set_deterministic / CPM_DETERMINISTIC: bit-identical weight gradients, cpmrcnn_hip.h): the
+    # fused parameter-gradient kernel adds its per-workgroup dw blocks with float atomics, so the layer takes the column
+    # path, whose weight gradient is conv2d_backward_weight's ordered slab reduction
+    if H.deterministic():
+        return False
     return _fused[0] and bool(n and p and q) and bool(H.lib().cpm_deform_conv_fused_supported(n, h, w, c, int(k), r, s, stride, pad,
                                                                                 dil, groups, dg, p, q))
 

@@ -27,6 +27,7 @@ def _nhwc(t):
 
 
 _GROUPED = os.environ.get("CPM_ROI_BWD_GROUP", "1") != "0"
+_GATHER_MAX_ROIS, _GATHER_MAX_SETS = 8192, 8      # cpm_roi_align_fpn_backward_gather_sets: per pass, all sets together
 
 
 class _RoiBackwardGroup(object):
@@ -91,6 +92,7 @@ class _RoIAlignFPN(Function):
         ctx.group = getattr(feats[0], "_cpm_roi_group", None) if any(ctx.needs_input_grad[7:]) else None
         if ctx.group is not None:
             ctx.group.registered += 1
+        given = feats
         feats = [_nhwc(f) for f in feats]
         B, C = feats[0].shape[:2]
         K = rois.shape[0]
@@ -99,6 +101,14 @@ class _RoIAlignFPN(Function):
                           memory_format=torch.channels_last)
         levels = torch.empty((max(K, 1),), dtype=torch.int32, device=rois.device)
         r = rois.contiguous().float()
+        if H.in_side_section():
+            # (conv.fwd_side) the kernel below is queued on the second stream, the tensors made here are compute-stream
+            # blocks: the level indices are dropped by most callers at once, so they are parked until the join; and a
+            # layout / dtype copy made just now ran on the COMPUTE stream behind the fork point -- order the second
+            # stream behind it
+            H.keep(levels, r, *feats)
+            if r is not rois or any(a is not b for a, b in zip(feats, given)):
+                H.fork(H._raw_stream(rois.device.index), H.stream_raw())
         n = len(feats)
         hs, ws, sc = _tables(feats, scales)
         ptrs = (ctypes.c_void_p * n)(*[f.data_ptr() for f in feats])
@@ -123,6 +133,11 @@ class _RoIAlignFPN(Function):
         r, = ctx.saved_tensors
         (ph, pw), scales, ratio, lvl_min, lvl_max, (s0, l0, eps), shapes = ctx.meta
         if grad_out is None:                   # nobody differentiated the pooled features
+            grp = ctx.group
+            if grp is not None:                # one call fewer to wait for: the group may be complete now
+                grp.registered -= 1
+                if grp.registered <= 0:
+                    grp.flush()
             return (None,) * (7 + len(shapes))
         g = _nhwc(grad_out)
         K = r.shape[0]
@@ -147,6 +162,12 @@ class _RoIAlignFPN(Function):
                     rets.append(t)
             if grp.meta is None:
                 grp.meta, grp.holders = meta, ctx.holders
+            # one pass takes at most _GATHER_MAX_SETS sets and _GATHER_MAX_ROIS RoIs IN ALL (roi_align.hip): a set that
+            # would push the parked ones over either limit sends them off first (larger per-GPU batches: 8 images x 512
+            # rows for the cls head and as many for the RSM head)
+            if grp.pending and (len(grp.pending) >= _GATHER_MAX_SETS
+                                or sum(int(p[1].shape[0]) for p in grp.pending) + K > _GATHER_MAX_ROIS):
+                grp.flush()
             first = not grp.pending
             grp.pending.append((g, r, int(ph), int(pw), int(ratio)))
             grp.registered -= 1

@@ -70,12 +70,13 @@ class RPNLossComputation(object):
                 lab = torch.where(vis, lab, -1.0)
         pos, neg, quota = ops.sample_pos_neg(lab, [per] * n_img, self.fg_bg_sampler.batch_size_per_image,
                                                self.fg_bg_sampler.positive_fraction)
-        if getattr(objectness[0], "_cpm_rpn_sparse", False):
+        token = getattr(objectness[0], "_cpm_rpn_sparse", None)
+        if token is not None:
             # the head is one autograd node (ops.rpn_head): tell it which anchors this loss sums over -- everywhere else
             # the gradient it receives is exactly zero -- as an index list built on the device
             cap = n_img * self.fg_bg_sampler.batch_size_per_image
             idx, _ = ops.mask_compact(pos, neg, cap)
-            ops.set_rpn_sample([o.data_ptr() for o in objectness], idx, cap, n_img)
+            ops.set_rpn_sample(token, idx, cap, n_img)
         objectness, box_regression = concat_box_prediction_layers(objectness, box_regression)
         # targets (BoxCoder.encode of the matched gt), smooth-L1 over the positives, BCE over the sample, and the
         # gradients of both: ONE launch (cpm_rpn_loss) instead of ~100 elementwise / reduction kernels

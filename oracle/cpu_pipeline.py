@@ -243,5 +243,8 @@ def infer_image(sd, image, layers=(3, 4, 6, 3), score_thresh=0.03, nms_thr=0.3):
         if st == 2:
             s = s * iou[:, 1].numpy()
     p = torch.softmax(M.cls_head(sd, feats, _rois([b]), "Head_rescore", "Output_rescore"), -1).numpy()
-    s = (np.abs(s) ** 0.8) * (p[np.arange(len(b)), l] ** 0.2)
+    # inference.py:62-76: `scores ** 0.8` as the reference writes it -- NaN where the ISM-merged score is negative (an
+    # untrained ISM branch; torch's pow does the same), no abs()
+    with np.errstate(invalid="ignore"):
+        s = (s.astype(np.float32) ** np.float32(0.8)) * (p[np.arange(len(b)), l] ** np.float32(0.2))
     return b, s, l

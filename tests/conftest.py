@@ -53,3 +53,16 @@ def deterministic_reductions():
     _hip.set_deterministic(True)
     yield
     _hip.set_deterministic(False)
+
+
+@pytest.fixture(params=["ordered", "atomic"])
+def reductions(request):
+    """A reference-fixture backward test under BOTH reduction modes: 'ordered' = cpm_set_deterministic(1) (slab planes
+    folded in order: the distance to the reference is a property of the arithmetic) and 'atomic' = the float-atomic
+    split reductions the benchmark runs by default (the default mode was held to the reference only
+    transitively).  Atomic sums differ from ordered ones in the last bits, which can flip a ReLU gate whose
+    pre-activation is zero to within rounding: tests state a second, wider bound for that mode where it applies."""
+    from pet.lib.ops import _hip
+    _hip.set_deterministic(request.param == "ordered")
+    yield request.param
+    _hip.set_deterministic(False)

@@ -54,3 +54,11 @@ def soften_heatmaps_(model, factor=0.05):
             out.deconv_2.bias.mul_(factor)
             s += 1
     return model
+
+
+def rpn_head_feature(level, shape):
+    """the feature map of FPN level `level` for the rpn_head fixture (make_golden.py rpn_head / test_gpu_rpn_reference):
+    numpy's legacy RandomState stream keyed by name, so generator and test build the same bits; signed values of unit
+    scale, as FPN outputs are"""
+    n, c, h, w = shape
+    return det_tensor("rpn_head_fixture.feat%d" % level, shape, "weight") * float(np.sqrt(c * h * w))

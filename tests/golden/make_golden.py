@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, HERE)
 REF = "/root/reference"
 
-from detfill import det_fill_, soften_heatmaps_  # noqa: E402
+from detfill import det_fill_, rpn_head_feature, soften_heatmaps_  # noqa: E402
 from oracle.build_ref import build as build_ref  # noqa: E402
 
 
@@ -786,6 +786,78 @@ def gen_rpn():
 
 
 
+def gen_rpn_head():
+    """Row a-3's HEAD in training, as a whole, against the REFERENCE: RPNHead.forward
+    (rpn/rpn.py:34-41) -> RPNLossComputation.__call__ (rpn/loss.py:88-126) with the reference's own sampler at its own
+    budget (RPN.BATCH_SIZE_PER_IMAGE = 256, POSITIVE_FRACTION 0.5; the draw is torch.randperm under a fixed seed and the
+    sampled masks are STORED, so that the test feeds the same sample instead of a seed) -> backward: the gradients of
+    the six head parameters and of the five feature maps.  This is what csrc/rpn_sparse.hip computes from the <= 512
+    sampled anchors; the fixture holds it to the reference directly, not through the dense formulation."""
+    import pet.utils.data.structures.boxlist_ops as ref_bl
+    from pet.rcnn.modeling.rpn.rpn import RPNModule
+    from pet.utils.data.structures.bounding_box import BoxList
+    from pet.utils.data.structures.image_list import ImageList
+    cfg = _cpm_cfg()
+    assert cfg.RPN.BATCH_SIZE_PER_IMAGE == 256 and cfg.RPN.POSITIVE_FRACTION == 0.5
+    H, W, N, C = 160, 224, 2, 256
+    torch.manual_seed(0)
+    rpn = RPNModule([C] * 5)
+    rpn.train()
+    det_fill_(rpn.head)
+    shapes = [((H + s - 1) // s, (W + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+    feats = [rpn_head_feature(i, (N, C, h, w)).requires_grad_(True) for i, (h, w) in enumerate(shapes)]
+    images = ImageList(torch.zeros(N, 3, H, W), [(H, W)] * N)
+    gts = [np.array([[12, 20, 96, 130], [100, 8, 215, 90], [60, 70, 180, 150], [150, 100, 200, 155], [5, 5, 40, 44]],
+                    np.float32),
+           np.array([[30, 30, 190, 140], [8, 90, 70, 156], [120, 12, 160, 60]], np.float32)]
+    targets = []
+    for g_ in gts:
+        t = BoxList(torch.from_numpy(g_.copy()), (W, H))
+        t.add_field("labels", torch.ones(len(g_), dtype=torch.int64))
+        targets.append(t)
+    obj, reg = rpn.head(feats)
+    anchors = rpn.anchor_generator(images, feats)
+    # record the sampler's masks as the loss draws them
+    drawn = {}
+    sampler = rpn.loss_evaluator.fg_bg_sampler
+    inner = sampler.__class__.__call__
+
+    def recording(self, matched):
+        pos, neg = inner(self, matched)
+        drawn["pos"] = torch.cat(pos).numpy().astype(bool)
+        drawn["neg"] = torch.cat(neg).numpy().astype(bool)
+        drawn["quota"] = np.array([[int(p.sum()), int(q.sum())] for p, q in zip(pos, neg)], np.int32)
+        return pos, neg
+    sampler.__class__.__call__ = recording
+    try:
+        torch.manual_seed(7)
+        l_obj, l_box = rpn.loss_evaluator(anchors, obj, reg, targets)
+    finally:
+        sampler.__class__.__call__ = inner
+    (l_obj + l_box).backward()
+    out = {"H": H, "W": W, "C": C, "loss_objectness": float(l_obj), "loss_rpn_box_reg": float(l_box),
+           "quota": drawn["quota"].tolist(), "grad_stats": {}}
+    assert all(q[0] > 0 and q[1] > 0 for q in out["quota"]), out["quota"]
+    arrs = {"pos": drawn["pos"], "neg": drawn["neg"], "quota": drawn["quota"]}
+    for n in range(N):
+        arrs["gt%d" % n] = gts[n]
+    for i in range(5):
+        arrs["obj%d" % i] = obj[i].detach().numpy()
+        arrs["reg%d" % i] = reg[i].detach().numpy()
+        g_ = feats[i].grad
+        out["grad_stats"]["feat%d" % i] = [float(g_.double().abs().sum()), float((g_.double() ** 2).sum())]
+        arrs["dfeat%d" % i] = g_[:, ::8].numpy() if i == 0 else g_.numpy()      # (the finest map: every 8th channel)
+    for k, q in rpn.head.named_parameters():
+        g_ = q.grad
+        out["grad_stats"][k] = [float(g_.double().abs().sum()), float((g_.double() ** 2).sum())]
+        arrs["dparam::" + k] = g_[::2, ::2].numpy() if k == "conv.weight" else g_.numpy()
+    np.savez_compressed(os.path.join(HERE, "rpn_head.npz"), **arrs)
+    with open(os.path.join(HERE, "rpn_head_meta.json"), "w") as f:
+        json.dump(out, f)
+    print("rpn_head:", {k: v for k, v in out.items() if k != "grad_stats"},
+          os.path.getsize(os.path.join(HERE, "rpn_head.npz")) // 1024, "KB")
+
+
 def gen_cocoeval():
     """Row f-3: the reference's vendored COCOeval (pet/rcnn/datasets/mycocoeval.py:62-423, bbox
     protocol) run here on a synthetic dataset.  Its only third-party call is pycocotools' compiled box IoU
@@ -1029,6 +1101,8 @@ def main():
         return gen_cpm_train()
     if sys.argv[1:] == ["rpn"]:
         return gen_rpn()
+    if sys.argv[1:] == ["rpn_head"]:
+        return gen_rpn_head()
     if sys.argv[1:] == ["cocoeval"]:
         return gen_cocoeval()
     cfg = load_cfg("cfgs/rcnn/mscoco/grid_cascade/iou_helper/rescore/e2e_grid_cascade@567_rcnn_R-50-FPN_2x.yaml")

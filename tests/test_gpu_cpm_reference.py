@@ -81,7 +81,7 @@ def _same_boxes(got, want, what, tol=0.05, flips_allowed=0):
 
 
 @pytest.mark.parametrize("fused", ["lists", True, False], ids=["device_lists", "fused_glue", "per_image"])
-def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fused, deterministic_reductions):
+def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fused, reductions):
     g = golden
     head = model.Grid_Cascade_RCNN
     saved = (head.fused_glue, head.cls_loss_evaluator.fused_glue, head.rescore_loss_evaluator.fused_glue)
@@ -143,12 +143,17 @@ def test_cpm_train_forward_matches_reference(model, golden, meta, conv_math, fus
             # different tensor each time): the test now runs with ordered reductions, which removes that noise.
             # deterministic reductions (fixture): measured 1.9e-4 (f32) / 5.1e-4 (bf16x3), no flips, identical on
             # all three paths and from run to run -- bounds at 1e-3 / 2e-3; a counted arg-max flip keeps the wide one
-            tol = 2e-2 if flips else (1e-3 if conv_math == "f32" else 2e-3)
+            # float-atomic reductions (`reductions` == "atomic", the benchmark's default): up to 2.4e-3 of a norm was
+            # seen run to run in round 2 -- stated bound 5e-3 in the split-bf16 arithmetic, 2e-3 in exact f32
+            if reductions == "ordered":
+                tol = 2e-2 if flips else (1e-3 if conv_math == "f32" else 2e-3)
+            else:
+                tol = 2e-2 if flips else (2e-3 if conv_math == "f32" else 5e-3)
             assert e1 < tol and e2 < tol, (k, e1, e2)
             checked += 1
         assert checked >= 150
         from test_gpu_model import _log
-        _log("cpm_reference[%s, %s, deterministic] flips %d, worst gradient-norm err %.2e" % (conv_math, fused, flips, worst))
+        _log("cpm_reference[%s, %s, %s] flips %d, worst gradient-norm err %.2e" % (conv_math, fused, reductions, flips, worst))
     finally:
         for h in hooks:
             h.remove()

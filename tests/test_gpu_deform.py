@@ -161,6 +161,36 @@ def test_fused_kernels_equal_column_path_at_full_size(shape):
             assert float((a - b).abs().max() / b.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [FULL_SIZE[2], FULL_SIZE[0]])
+def test_deterministic_mode_gives_bit_identical_weight_gradients_on_x101_layers(shape, deterministic_reductions):
+    """cpm_set_deterministic(1) / CPM_DETERMINISTIC=1 promise bit-identical weight gradients run to run
+    (include/cpmrcnn_hip.h).  The fused kernels of csrc/deform_fused.hip add their per-workgroup dw blocks with float
+    atomics, so under that switch a ResNeXt / DCN 3x3 takes the column path, whose weight gradient is
+    conv2d_backward_weight's ordered slab reduction: two runs on the same tensors, weight gradients equal
+    bit for bit -- layer3's deformable 3x3 and layer1's plain 4-per-group 3x3 at the benchmark's size."""
+    import sys
+    import pet.lib.ops as ops
+    dc = sys.modules["pet.lib.ops.deform_conv"]
+    C, H, W, groups, with_offset = shape
+    g = torch.Generator().manual_seed(3)
+    x = _cl(torch.randn(1, C, H, W, generator=g))
+    w = _cl(torch.randn(C, C // groups, 3, 3, generator=g) * (2.0 / (9 * C // groups)) ** 0.5)
+    off = _cl(torch.rand(1, 18, H, W, generator=g) * 3 - 1.5) if with_offset else None
+    dy = _cl(torch.randn(1, C, H, W, generator=g))
+    geom = dc._geom(x.shape, w.shape, 1, 1, 1, groups, 1)
+    assert not dc.fused_ok(geom, C), "the float-atomic kernels must stand down in deterministic mode"
+    grads = []
+    for _ in range(2):
+        xi, wi = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+        oi = off.clone().requires_grad_(True) if with_offset else None
+        y = ops.cols_conv(xi, oi, wi, None, None, 1, 1, 1, groups, 1, relu=False)
+        y.backward(dy)
+        torch.cuda.synchronize()
+        grads.append(wi.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert float(grads[0].abs().max()) > 0
+
+
 def test_zero_offset_equals_grouped_conv_kernel():
     """Known answer inside the HIP path: zero offsets through the sampler == the implicit-GEMM grouped conv."""
     import pet.lib.ops as ops

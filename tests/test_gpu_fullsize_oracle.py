@@ -7,7 +7,10 @@
   * FPN level indices of the REAL proposal set (the training-mode RPN's output on this batch) bit-equal to the
     oracle's LevelMapper;
   * NMS keep lists bit-equal to the oracle's greedy NMS on the real pre-NMS candidates of every (image, level): the
-    top-2000 sigmoid scores of the GPU's own logits, decoded and clipped by the oracle.
+    top-2000 sigmoid scores of the GPU's own logits, decoded and clipped by the oracle;
+  * the TEST-MODE forward (BASELINE config #1's workload: one 3 x 800 x 1333 image per forward) -- RPN test
+    post-processing, cls head, CLSPostProcessor + ml_nms, three grid stages, ISM, RSM -- against
+    oracle/cpu_pipeline.infer_image on the same weights: detections one to one (VERDICT r4 missing 2).
 
 The oracle (oracle/cpu_model.py: torch-CPU fp32 convs + the C RoIAlign, pinned to the reference as its header says)
 runs once per session: ~10 s on the GPU box's host cores."""
@@ -72,7 +75,7 @@ def setup():
         want = {"c": c, "p": p, "lo": lo, "br": br,
                 "cls": M.cls_head(sd, p, r_cls), "rsm": M.cls_head(sd, p, r_cls, "Head_rescore", "Output_rescore"),
                 "grid": [M.grid_stage(sd, p, r_grid, s, last=(s == 2)) for s in range(3)]}
-    yield dict(tr=tr, images=images, targets=targets, want=want, r_cls=r_cls, r_grid=r_grid)
+    yield dict(tr=tr, images=images, targets=targets, want=want, r_cls=r_cls, r_grid=r_grid, sd=sd)
     _hip.set_conv_math(prev)
     config.reset_cfg()
     torch.cuda.empty_cache()
@@ -239,3 +242,113 @@ def test_level_indices_and_nms_keep_lists_on_the_real_proposal_set(setup):
             assert np.array_equal(got, want_keep), "segment %d: %d vs %d kept" % (p_, len(got), len(want_keep))
             total_kept += len(got)
         assert total_kept > 2000
+
+
+def _match_detections(gb, gs, gl, ob, os_, ol, extent):
+    """one-to-one matching of two detection sets: same label, nearest box; -> (pairs, box deviation per pair)"""
+    used, pairs = set(), []
+    for i in range(len(gb)):
+        cand = [j for j in np.flatnonzero(ol == gl[i]) if j not in used]
+        if not cand:
+            continue
+        d = np.abs(ob[cand] - gb[i]).max(axis=1)
+        j = cand[int(np.argmin(d))]
+        # a box moved by arg-max flips -- one of a side's three voting points moved by one cell of a stage's window --
+        # stays within ~ (1 + ratio) * side / 56 per stage of its twin; anything further is another detection
+        side = max(ob[j, 2] - ob[j, 0], ob[j, 3] - ob[j, 1])
+        if d.min() <= 0.15 * side + 1.0:
+            used.add(j)
+            pairs.append((i, j, float(d.min())))
+    return pairs
+
+
+@pytest.mark.parametrize("math", ["f32", "bf16x3"])
+def test_test_mode_forward_at_full_size_matches_the_oracle(setup, math):
+    """BASELINE config #1's workload on the HIP path: Generalized_RCNN.forward in eval mode on ONE 3 x 800 x 1344 image
+    per forward (the reference's inference is per image: TEST.IMS_PER_GPU = 1) against
+    oracle/cpu_pipeline.infer_image on the same weights -- grid_cascade_rcnn.py:92-100,161-224 and inference.py:59-124,
+    145-298 of the reference: RPN test post-processing (1000 / 1000 / 1000), cls head, softmax, score > t & label != 0,
+    multi-label NMS 0.3, three grid stages refining the kept boxes, ISM (score x IoU logit), RSM (s^0.8 p^0.2).
+
+    The benchmark network's class scores are all ~1/81 (cls_score is initialised with std 0.01), so the reference's
+    threshold 0.03 would pass nothing: the test places the threshold inside the WIDEST gap of the GPU's own sorted
+    foreground scores around rank ~200, the same value for both sides -- candidates are then decided by a margin, not a
+    tie.  What is held:
+      * exact f32: the two detection sets pair off one to one (same label, same candidate) -- every detection except
+        a counted handful (<= 2 %: a proposal at an NMS / top-k tie decided differently by two fp32 sums); paired
+        boxes within 1e-3 of the image extent (1.3 px; measured ~1e-3 px), except counted arg-max flips of a heat map
+        whose two best cells tie to rounding (<= 2 %, bounded by a cell's size); scores within 1e-3 relative (NaN where
+        the reference's own s ** 0.8 is NaN: a negative ISM logit);
+      * bf16x3: the same pairing with the bars the arithmetic's 2e-3 end-to-end feature error on THIS network allows
+        (DESIGN section 5): >= 80 % of the detections paired, the paired ones judged as above with a 10 % flip budget;
+        printed."""
+    from oracle import cpu_pipeline as P
+    from pet.lib.ops import _hip
+    S = setup
+    model = S["tr"].model
+    G = model.Grid_Cascade_RCNN
+    _hip.set_conv_math(math)
+    model.eval()
+    post = G.cls_post_processor
+    saved = post.score_thresh
+    extent = float(max(H_IMG, W_IMG))
+    torch.set_num_threads(16)
+    try:
+        summary = []
+        for i in range(2):
+            x = S["images"].tensors[i:i + 1]
+            with torch.no_grad():
+                # the GPU's own class probabilities, to place the threshold
+                feats = model._features(x)
+                from pet.utils.data.structures.image_list import to_image_list
+                props, _ = model.RPN(to_image_list(x), feats, None)
+                assert len(props) == 1 and 500 <= len(props[0]) <= 1000, len(props[0])
+                prob = torch.softmax(G.Output_cls(G.Head_cls(feats, props)), -1)[:, 1:].reshape(-1)
+                top = torch.sort(prob, descending=True)[0][:400].cpu().numpy().astype(np.float64)
+                gaps = top[120:300] - top[121:301]
+                k = 120 + int(np.argmax(gaps))
+                thr = float(0.5 * (top[k] + top[k + 1]))
+                assert gaps.max() > 1e-7 * top[k], "no usable gap among the class scores"
+                post.score_thresh = thr
+                res = model(x)
+            assert len(res) == 1
+            r = res[0]
+            gb = r.bbox.cpu().numpy()
+            gs = r.get_field("scores").cpu().numpy()
+            gl = r.get_field("labels").cpu().numpy()
+            ob, os_, ol = P.infer_image(S["sd"], x.cpu().contiguous(), score_thresh=thr)
+            assert len(ob) >= 30 and len(gb) >= 30, (len(gb), len(ob))
+            assert (gl > 0).all() and (gl < 81).all()
+            pairs = _match_detections(gb, gs, gl, ob, os_, ol, extent)
+            n = max(len(gb), len(ob))
+            unpaired = n - len(pairs)
+            dev = np.array([d for _, _, d in pairs])
+            moved = dev > 1e-3 * extent
+            sc_bad = 0
+            for (a, b_, d) in pairs:
+                if d > 1e-3 * extent:
+                    continue
+                if np.isnan(os_[b_]) or np.isnan(gs[a]):
+                    sc_bad += int(np.isnan(os_[b_]) != np.isnan(gs[a]))
+                else:
+                    sc_bad += int(abs(gs[a] - os_[b_]) > (1e-3 if math == "f32" else 5e-3) * abs(os_[b_]) + 1e-9)
+            summary.append((i, len(gb), len(ob), unpaired, int(moved.sum()), sc_bad, thr))
+            if math == "f32":
+                assert unpaired <= max(1, int(0.02 * n)), summary[-1]
+                assert int(moved.sum()) <= max(1, int(0.02 * n)), summary[-1]
+                assert sc_bad <= max(1, int(0.02 * n)), summary[-1]
+            else:
+                assert unpaired <= int(0.2 * n), summary[-1]
+                assert int(moved.sum()) <= max(2, int(0.1 * n)), summary[-1]
+                assert sc_bad <= max(2, int(0.1 * n)), summary[-1]
+        import os
+        from conftest import ROOT
+        line = "test_mode_fullsize[%s] per image (gpu dets, oracle dets, unpaired, moved boxes, score mismatches, thr): %s" \
+            % (math, "; ".join("img%d %d %d %d %d %d %.6f" % t for t in summary))
+        print(line)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "parity_log.txt"), "a") as f:
+            f.write(line + "\n")
+    finally:
+        post.score_thresh = saved
+        model.train()

@@ -84,7 +84,7 @@ def test_forward_matches_reference(model, golden_model, conv_math):
                 assert iou is None
 
 
-def test_backward_matches_reference(model, golden_model, conv_math, deterministic_reductions):
+def test_backward_matches_reference(model, golden_model, conv_math, reductions):
     from pet.utils.data.structures.bounding_box import BoxList
     g = golden_model
     meta = json.load(open(os.path.join(ROOT, "tests", "golden", "model_r50_meta.json")))
@@ -116,9 +116,12 @@ def test_backward_matches_reference(model, golden_model, conv_math, deterministi
         # 2.2e-3 once in four runs, a different tensor each time); exact fp32 stays below 2e-4.  The larger fixture
         # (test_backward_big_matches_reference) holds 1e-3 in both arithmetics.
         # with ordered reductions (fixture) the distance is reproducible: measured 1e-6 (f32) / 1.3e-3 (bf16x3)
-        tol = 1e-4 if conv_math == "f32" else 2e-3
+        # float-atomic reductions (the benchmark's default): the sums differ from the ordered ones in the last bits, and
+        # on this 6-RoI fixture that is enough to flip a gate now and then (round 2 saw 2.2e-3 once in four runs) --
+        # stated bound 4e-3 there; exact f32 keeps 1e-4 in both modes
+        tol = 1e-4 if conv_math == "f32" else (2e-3 if reductions == "ordered" else 4e-3)
         assert e1 < tol and e2 < tol, (k, e1, e2)
-    _log("backward_small[%s, deterministic] worst norm err %.2e" % (conv_math, worst))
+    _log("backward_small[%s, %s] worst norm err %.2e" % (conv_math, reductions, worst))
     for key in g.files:
         if key.startswith("m_grad::"):
             k = key[len("m_grad::"):]
@@ -642,11 +645,19 @@ def test_grouped_roi_align_backward_equals_call_by_call(fresh_model, golden_mode
     try:
         g0, g1, g2 = run(False), run(True), run(True)
         h0, h1 = run(False, use=(0, 2)), run(True, use=(0, 2))       # one registered call is never differentiated
+        # a pass takes at most 8192 RoIs in all (roi_align.hip): with the limit lowered to 250 the third set (150 RoIs
+        # behind 200 + 30, in backward order 150 + 30 then 200) sends the parked ones off first -- two passes, same sums
+        limit = PF._GATHER_MAX_ROIS
+        PF._GATHER_MAX_ROIS = 250
+        try:
+            g3 = run(True)
+        finally:
+            PF._GATHER_MAX_ROIS = limit
     finally:
         PF._GROUPED = True
         _hip.set_conv_math(prev)
-    assert len(g0) > 50 and set(g0) == set(g1) == set(h1)
-    for a, b in ((g0, g1), (h0, h1)):
+    assert len(g0) > 50 and set(g0) == set(g1) == set(h1) == set(g3)
+    for a, b in ((g0, g1), (h0, h1), (g0, g3)):
         for k in a:
             torch.testing.assert_close(a[k], b[k], rtol=1e-4, atol=1e-5 * float(a[k].abs().max()) + 1e-12, msg=k)
     for k in g1:

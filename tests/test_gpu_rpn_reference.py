@@ -120,3 +120,121 @@ def test_rpn_proposals_equal_reference(golden, meta, rpn_cfg, monkeypatch, path)
         assert gb.shape == wb.shape, (n, gb.shape, wb.shape)
         assert np.array_equal(go, wo), (n, "objectness / order", float(np.abs(go - wo).max()))
         assert np.abs(gb - wb).max() <= 1e-3, (n, float(np.abs(gb - wb).max()))
+
+
+# ---- the head IN TRAINING against the reference: forward, loss and the backward pass the benchmark runs ---------------
+@pytest.fixture(scope="module")
+def golden_head():
+    return np.load(os.path.join(ROOT, "tests", "golden", "rpn_head.npz"))
+
+
+@pytest.fixture(scope="module")
+def meta_head():
+    with open(os.path.join(ROOT, "tests", "golden", "rpn_head_meta.json")) as f:
+        return json.load(f)
+
+
+@pytest.mark.parametrize("reductions", ["ordered", "atomic"])
+@pytest.mark.parametrize("backward", ["sparse", "dense"])
+def test_rpn_head_training_step_equals_reference(golden_head, meta_head, monkeypatch, conv_math, backward, reductions):
+    """tests/golden/rpn_head.npz (make_golden.py rpn_head): the REFERENCE's RPNHead.forward -> RPNLossComputation ->
+    backward on a 2-image batch over five 256-channel levels, with the reference sampler's own draw (256 per image)
+    stored as masks.  Held to it: logits / deltas of every level, both losses, and the gradients of the six head
+    parameters and the five feature maps -- through the backward pass over the sampled anchors only
+    (csrc/rpn_sparse.hip, the benchmark's default; forced on under ordered reductions too) and through the dense
+    formulation, each with ordered slab reductions and with the float-atomic ones the benchmark runs.
+    Bars: forward 1e-3 of the tensor maximum (measured 1e-6 f32 / 3e-5 bf16x3), losses 1e-4, every gradient entry
+    within 1e-3 of its tensor's maximum (north_star's bar; the atomic mode changes summation order only: same bar)."""
+    from detfill import det_fill_, rpn_head_feature
+    from pet.lib.ops import _hip, conv as C
+    from pet.rcnn.core import config
+    from pet.rcnn.modeling.rpn import loss as rpn_loss_mod
+    from pet.utils.data.structures.bounding_box import BoxList
+    from pet.utils.data.structures.image_list import ImageList
+    g, meta = golden_head, meta_head
+    config.reset_cfg()
+    config.merge_cfg_from_list(CPM_OPTS)
+    monkeypatch.setenv("CPM_FUSED_GLUE", "1")
+    monkeypatch.setenv("CPM_DEVICE_LISTS", "1")
+    prev_sparse = C._RPN_SPARSE
+    _hip.set_deterministic(reductions == "ordered")
+    C._RPN_SPARSE = 2 if backward == "sparse" else 0      # 2: the sparse pass also under ordered reductions
+    try:
+        from pet.rcnn.modeling.rpn.rpn import RPNModule
+        Hh, W, Cc = meta["H"], meta["W"], meta["C"]
+        rpn = RPNModule([Cc] * 5).cuda()
+        rpn.train()
+        det_fill_(rpn.head)
+        shapes = [((Hh + s - 1) // s, (W + s - 1) // s) for s in (4, 8, 16, 32, 64)]
+        feats = [rpn_head_feature(i, (2, Cc, h, w)).cuda().contiguous(memory_format=torch.channels_last)
+                 .requires_grad_(True) for i, (h, w) in enumerate(shapes)]
+        images = ImageList(torch.zeros(2, 3, Hh, W, device="cuda"), [(Hh, W)] * 2)
+        targets = []
+        for n in range(2):
+            t = BoxList(torch.from_numpy(g["gt%d" % n]).cuda(), (W, Hh))
+            t.add_field("labels", torch.ones(len(t), dtype=torch.int64, device="cuda"))
+            targets.append(t)
+        obj, reg = rpn.head(feats, sparse_backward=backward == "sparse")      # (RPNModule.forward's call in training)
+        if backward == "sparse":
+            assert getattr(obj[0], "_cpm_rpn_sparse", None) is not None, "the head did not run as one node"
+        for i in range(5):
+            assert rel(obj[i], g["obj%d" % i]) < 1e-3 and rel(reg[i], g["reg%d" % i]) < 1e-3, i
+        anchors = rpn.anchor_generator(images, feats)
+        # the reference's draw instead of this package's sampler (a different generator): same masks, same quota
+        pos = torch.from_numpy(g["pos"]).cuda()
+        neg = torch.from_numpy(g["neg"]).cuda()
+        quota = torch.from_numpy(g["quota"]).cuda()
+        seen = []
+
+        def stored_sample(lab, counts, per_image, frac, *a, **k):
+            assert lab.numel() == pos.numel() and per_image == 256
+            # the draw must be a legal one for the labels THIS package matched: positives among its positives
+            assert bool((lab[pos] >= 1).all()) and bool((lab[neg] == 0).all())
+            seen.append(1)
+            return pos, neg, quota
+        monkeypatch.setattr(rpn_loss_mod.ops, "sample_pos_neg", stored_sample)
+        l_obj, l_box = rpn.loss_evaluator(anchors, obj, reg, targets)
+        assert seen, "the fused loss path did not ask for a sample"
+        assert abs(float(l_obj) - meta["loss_objectness"]) <= 1e-4 * abs(meta["loss_objectness"]), float(l_obj)
+        assert abs(float(l_box) - meta["loss_rpn_box_reg"]) <= 1e-4 * abs(meta["loss_rpn_box_reg"]), float(l_box)
+        (l_obj + l_box).backward()
+        torch.cuda.synchronize()
+        worst = 0.0
+        for i in range(5):
+            got = feats[i].grad
+            assert got is not None, i
+            s1, s2 = meta["grad_stats"]["feat%d" % i]
+            gd = got.double()
+            assert abs(float((gd ** 2).sum()) ** 0.5 - s2 ** 0.5) <= 1e-3 * s2 ** 0.5, ("feat", i)
+            sub = (got[:, ::8] if i == 0 else got).cpu().numpy()
+            want = g["dfeat%d" % i]
+            e = float(np.abs(sub - want).max() / (np.abs(want).max() + 1e-30))
+            worst = max(worst, e)
+            assert e < 1e-3, ("dfeat", i, e)
+            # the support: a pixel no sampled anchor's 3x3 window reaches has an exactly zero gradient in the reference
+            if backward == "sparse":
+                assert np.array_equal(sub != 0, want != 0) or float(np.abs(sub[(want == 0)]).max()) == 0.0, i
+        for k, q in rpn.head.named_parameters():
+            got = q.grad
+            assert got is not None, k
+            s1, s2 = meta["grad_stats"][k]
+            assert abs(float((got.double() ** 2).sum()) ** 0.5 - s2 ** 0.5) <= 1e-3 * s2 ** 0.5, k
+            want = g["dparam::" + k]
+            sub = (got[::2, ::2] if k == "conv.weight" else got).cpu().numpy()
+            e = float(np.abs(sub - want).max() / (np.abs(want).max() + 1e-30))
+            worst = max(worst, e)
+            assert e < 1e-3, (k, e)
+        log = os.path.join(ROOT, "gpurun_out", "parity_log.txt")
+        os.makedirs(os.path.dirname(log), exist_ok=True)
+        with open(log, "a") as f:
+            f.write("rpn_head_training[%s, %s, %s] worst gradient entry error %.2e of the tensor maximum\n"
+                    % (conv_math, backward, reductions, worst))
+    finally:
+        C._RPN_SPARSE = prev_sparse
+        _hip.set_deterministic(False)
+        config.reset_cfg()
+
+
+def rel(a, b):
+    a = a.detach().float().cpu().numpy() if isinstance(a, torch.Tensor) else a
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
