@@ -2732,31 +2732,8 @@ int launch_pt(const IgemmArgs& a, int per_cu, hipStream_t s) {
   return cpm::check_launch("conv igemm (persistent tiles)");
 }
 
-// EXPERIMENT (CPM_IGEMM_FB): fragment-major weight images built inside the launcher and cached by weight address --
-// 1 = build once per address (timing runs on fixed weights), 2 = rebuild on every call (correctness runs)
-static const void* fb_image_for(const IgemmArgs& a, int mode, hipStream_t s) {
-  struct Ent { const float* p; int pre, rows, taps, cgr; void* img; };
-  static std::vector<Ent> cache;
-  const int taps = a.R * a.S;
-  for (auto& e : cache)
-    if (e.p == a.wm && e.pre == a.b_presplit && e.rows == a.OCg && e.taps == taps && e.cgr == a.CgR) {
-      if (mode == 2 && build_wfrag(a.wm, a.b_presplit, a.OCg, taps, a.CgR, e.img, s) != CPM_OK) return nullptr;
-      return e.img;
-    }
-  void* img = nullptr;
-  if (hipMalloc(&img, wfrag_bytes(a.OCg, taps, a.CgR)) != hipSuccess) return nullptr;
-  if (build_wfrag(a.wm, a.b_presplit, a.OCg, taps, a.CgR, img, s) != CPM_OK) return nullptr;
-  cache.push_back({a.wm, a.b_presplit, a.OCg, taps, a.CgR, img});
-  return img;
-}
-
 int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t s) {
   const int rows = a.M - a.m_base;
-  const int fbm = env_int("CPM_IGEMM_FB", 0);
-  if (fbm && vec && g_conv_split && wn == 2 && bn >= 64 && fb_supported(a, bm, bn)) {
-    const void* img = fb_image_for(a, fbm, s);
-    if (img) return launch_fb(a, bm, bn, img, s);
-  }
   // persistent tiles (igemm_pt_kernel): whenever the grid would not fit the chip at once.  CPM_IGEMM_PT: 0 off, 1 wherever
   // the kernel applies (tests), 2 by grid size.  Read per call: the tests switch it.
   const int pt = env_int("CPM_IGEMM_PT", 2);

@@ -96,10 +96,4 @@ struct IgemmArgs {
 
 struct Plan { int bm, bn, wm, wn, split; };
 
-// conv_igemm_fb.hip: the weight operand as a fragment-major image read straight into MFMA operand registers
-size_t wfrag_bytes(int rows, int taps, int cgr);
-int build_wfrag(const float* src, int presplit, int rows, int taps, int cgr, void* dst, hipStream_t s);
-bool fb_supported(const IgemmArgs& a, int bm, int bn);
-int launch_fb(const IgemmArgs& a, int bm, int bn, const void* fb, hipStream_t s);
-
 }  // namespace cpmconv
