@@ -53,6 +53,8 @@ X101_DCN_OPTS = [  # .../rescore/backbone/e2e_grid_cascade@567_rcnn_X-101b-64x4d
     "BACKBONE.RESNEXT.WIDTH", 4, "GRID_RCNN.MAX_SAMPLE_NUM_GRID", 32,
 ]
 
+LEG_WARMUP, LEG_STEPS = 5, 20      # side legs (full RoI counts, other bodies): untimed + timed steps, fixed
+
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # same guide: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), no sparsity
 
@@ -121,7 +123,12 @@ def calibrate_frozen_affine(model, images):
 class Trainer(object):
     """The reference's loop body (tools/rcnn/train_net.py:62-78) over the HIP model."""
 
-    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3), body="resnet", chunks=8):
+    def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3), body="resnet", chunks=8, hold_offsets=False,
+                 offset_bias_px=0.0):
+        """hold_offsets (x101dcn): the offset predictors of the deformable convs (DeformConvPack.conv_offset, zero-
+        initialised by the reference: deform_conv.py:497-498) keep their initial value -- a parameter group of their own
+        with lr_scale 0; their gradients are still computed.  offset_bias_px > 0: their biases are drawn from
+        U(-px, +px) first (offsets of a trained model's size, constant per tap)."""
         from pet.rcnn.core import config
         from pet.rcnn.modeling.model_builder import Generalized_RCNN
         from pet.utils.lr_scheduler import LearningRateScheduler
@@ -142,7 +149,14 @@ class Trainer(object):
         model = convert_bn2affine_model(model, merge=True)    # MODEL.BATCH_NORM == 'freeze'
         self.model = model.to(device).to(memory_format=torch.channels_last)
         self.model.train()
-        self.optimizer = Optimizer(self.model, self.cfg.SOLVER).build()
+        if offset_bias_px > 0:
+            g = torch.Generator().manual_seed(77)
+            with torch.no_grad():
+                for k, p in self.model.named_parameters():
+                    if k.endswith("conv_offset.bias"):
+                        p.copy_(((torch.rand(p.shape, generator=g) * 2 - 1) * offset_bias_px).to(p.device))
+        self.optimizer = Optimizer(self.model, self.cfg.SOLVER,
+                                   frozen_lr_keys=("conv_offset.",) if hold_offsets else ()).build()
         # this loop zeroes the gradients at the top of every step: let the SGD kernel clear them behind their use (the
         # 614 MB memset of zero_grad -- 0.3 ms in front of every forward pass -- becomes part of a pass that has the
         # lines anyway)
@@ -156,6 +170,7 @@ class Trainer(object):
         self.optimizer.zero_grad()
         self.reducer.begin_step()
         out = self.model(images, targets)
+        self.reducer.mark_backward_begin()
         if SUM_LOSSES:
             sum(out["losses"].values()).backward()
         else:
@@ -163,6 +178,72 @@ class Trainer(object):
         self.reducer.finish()
         self.optimizer.step()
         self.last_losses = out["losses"]
+
+
+def timed_leg(trainer, images, targets, warmup, steps, world, device, seed):
+    """`warmup` untimed + `steps` timed iterations of `trainer` on a fixed batch, with the step window and the RoI counts
+    of every timed step on record: the sampler / proposal seeds come from torch's CPU generator, re-seeded here, so the
+    leg's trajectory (which RoIs survive from step to step, hence the grid stages' sizes) is the same in every run up
+    to the float-atomic order of the gradient sums."""
+    torch.manual_seed(seed)
+    head = trainer.model.Grid_Cascade_RCNN
+    for _ in range(warmup):
+        trainer.step(images, targets)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    seen = {}
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        trainer.step(images, targets)
+        for k, v in head._last_counts.items():       # (host-side values: cls / grid stages of this step, RSM of the last)
+            lo, hi = seen.get(k, (v, v))
+            seen[k] = (min(lo, v), max(hi, v))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t1
+    if world > 1:
+        t = torch.tensor([el], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    n_img = images.tensors.shape[0] * world
+    losses = {k: float(v.detach()) for k, v in trainer.last_losses.items()}
+    return {"img_per_s": round(n_img * steps / el, 3), "ms_per_step": round(1000.0 * el / steps, 2), "steps": steps,
+            "warmup": warmup, "step_window": [warmup, warmup + steps], "seed": seed,
+            "roi_counts_min_max": {k: list(v) for k, v in sorted(seen.items())},
+            "roi_counts_last_step": dict(head.last_counts),
+            "finite_loss": all(v == v and abs(v) != float("inf") for v in losses.values())}
+
+
+def offset_statistics(trainer, images, targets):
+    """|offset| of every DeformConvPack's predictor on one more (untimed) step: mean and maximum over the body, and the
+    share of offsets beyond 4 pixels (samples the fused kernels' LDS window cannot hold: their direct-memory route)"""
+    import sys as _sys
+    dc = _sys.modules.get("pet.lib.ops.deform_conv")
+    if dc is None:
+        return None
+    acc = []
+
+    def hook(mod, args, out):
+        o = out.detach().abs()
+        fin = torch.isfinite(o)
+        o = torch.where(fin, o, torch.zeros_like(o))
+        acc.append((float(o.mean()), float(o.max()), float((o > 4).float().mean()), float((~fin).float().mean())))
+    hs = [m.conv_offset.register_forward_hook(hook) for m in trainer.model.modules() if isinstance(m, dc.DeformConvPack)]
+    trainer.step(images, targets)
+    torch.cuda.synchronize()
+    for h in hs:
+        h.remove()
+    if not acc:
+        return None
+    return {"layers": len(acc), "mean_abs_px": round(sum(a[0] for a in acc) / len(acc), 3),
+            "max_abs_px": round(max(a[1] for a in acc), 2),
+            "share_beyond_4px": round(sum(a[2] for a in acc) / len(acc), 4),
+            "worst_layer_mean_abs_px": round(max(a[0] for a in acc), 2),
+            # (SGD on noise images with random labels diverges sooner or later: non-finite activations in the body show
+            # up here as non-finite predictor outputs; 0 = the step the statistics were taken on was still sane)
+            "nonfinite_share": round(sum(a[3] for a in acc) / len(acc), 6)}
 
 
 def csrc_digest():
@@ -518,6 +599,24 @@ def main():
     losses = {k: float(v.detach()) for k, v in trainer.last_losses.items()}
     counts = dict(trainer.model.Grid_Cascade_RCNN.last_counts)
 
+    # N > 1: where the gradient all-reduce sits relative to the backward pass, from events on the communication stream
+    # (three more steps with the reducer's timing on; the headline above ran without it)
+    comm = None
+    if world > 1:
+        trainer.reducer.timing = True
+        for _ in range(3):
+            trainer.step(images, targets)
+        sync()
+        comm = trainer.reducer.comm_stats()
+        trainer.reducer.timing = False
+        if comm is not None:
+            comm["chunk_mbytes"] = [round((e - b) * 4 / 1e6, 1) for b, e, _ in trainer.reducer.chunks]
+            comm["wgrad_stream_reserved_cus"] = int(os.environ.get("CPM_WGRAD_RESERVE_CUS", "0"))
+            comm["note"] = ("events of rank 0's last step: backward_ms = the compute stream's data-gradient chain; "
+                            "per_chunk_ms = each chunk's all-reduce on the communication stream (+ its SGD update "
+                            "under CPM_OVERLAP_SGD); exposed_ms = what the compute stream waited for behind its "
+                            "backward pass")
+
     roof, cpu = None, None
     if not a.no_roofline:
         # every rank runs the two instrumented steps (they contain the gradient all-reduce); rank 0 reports its own
@@ -593,31 +692,24 @@ def main():
         trainer.reducer = FlatGradReducer(trainer.optimizer, num_chunks=a.chunks)
     full_rois = None
     if not a.no_full_rois and a.body == "resnet":
-        # every rank takes part (the gradient all-reduce is collective)
-        f_images, f_targets = synthetic_batch(a.batch, a.height, a.width, 96, 5678 + rank, device)
-        for _ in range(2):
-            trainer.step(f_images, f_targets)
-        sync()
-        k_f = max(1, min(a.steps, 8))
-        t1 = time.perf_counter()
-        for _ in range(k_f):
-            trainer.step(f_images, f_targets)
-        sync()
-        el_f = time.perf_counter() - t1
+        # A FRESH model (same initial state as the headline's), a fixed seed and a fixed step window: the leg no longer
+        # depends on how many steps the driver asked the headline for.  Every rank takes part (collective all-reduce).
+        tr_f = Trainer(device, layers=layers, chunks=a.chunks)
+        calibrate_frozen_affine(tr_f.model, cal_img.tensors)
         if world > 1:
-            t = torch.tensor([el_f], device=device, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el_f = float(t.item())
-        f_counts = dict(trainer.model.Grid_Cascade_RCNN.last_counts)
-        f_roof = conv_roofline(trainer, f_images, f_targets, steps=1, math=a.conv_math) if not a.no_roofline else None
-        full_rois = {"img_per_s": round(a.batch * world * k_f / el_f, 3), "ms_per_step": round(1000.0 * el_f / k_f, 2),
-                     "steps": k_f, "gt_boxes_per_image": 96, "roi_counts_last_step": f_counts,
-                     "conv_gflop_per_step": None if f_roof is None else round(
-                         sum(v["gflop"] for v in f_roof["per_step"].values()), 1),
-                     "conv_tflops": None if f_roof is None else f_roof["all_conv_kernels"]["tflops"]}
-        for _ in range(2):
-            trainer.step(images, targets)
-        sync()
+            from pet.utils.parallel import broadcast_initial_state
+            broadcast_initial_state(tr_f.model, tr_f.optimizer, src=0)
+        f_images, f_targets = synthetic_batch(a.batch, a.height, a.width, 96, 5678 + rank, device)
+        full_rois = timed_leg(tr_f, f_images, f_targets, LEG_WARMUP, LEG_STEPS, world, device, seed=101)
+        f_roof = conv_roofline(tr_f, f_images, f_targets, steps=1, math=a.conv_math) if not a.no_roofline else None
+        full_rois.update({"gt_boxes_per_image": 96,
+                          "conv_gflop_per_step": None if f_roof is None else round(
+                              sum(v["gflop"] for v in f_roof["per_step"].values()), 1),
+                          "conv_tflops": None if f_roof is None else f_roof["all_conv_kernels"]["tflops"]})
+        tr_f.reducer.close()
+        del tr_f, f_images, f_targets
+        torch.cuda.empty_cache()
+        _hip.set_conv_math(a.conv_math)
     host_input = None
     if a.host_input and world == 1:
         from pet.utils.data.collate_batch import DeferredBatch
@@ -653,26 +745,35 @@ def main():
                       "cpm_image_prep (resize to %dx%d, BGR, normalise, pad) -> training step" % (a.batch, oh, ow)}
     other_bodies = None
     if not a.no_other_bodies and world == 1 and a.body == "resnet" and layers == (3, 4, 6, 3):
-        # BASELINE configs #4 / #5 on one GPU, in the headline arithmetic: a fresh model each, 3 warm-up + 8 timed steps
+        # BASELINE configs #4 / #5 on one GPU, in the headline arithmetic: a fresh model each, a fixed seed, LEG_WARMUP
+        # untimed + LEG_STEPS timed steps, RoI counts of every timed step on record.
+        # Config #5 in three offset regimes.  The reference zero-initialises every offset predictor
+        # (deform_conv.py:497-498) and trains it from a pre-trained body on real images: offsets start at 0 and stay
+        # within a few pixels.  SGD on noise images with random labels instead drives the untrained predictors to tens
+        # of pixels within ten steps (profiles/round4_x101_offset_stats.txt), a regime no trained model shows -- so the
+        # leg is timed (a) with the predictors held at their zero initialisation (lr_scale 0 for conv_offset.*; their
+        # gradients are still computed), (b) held at offsets of a trained model's size (biases ~ U(-1.5, 1.5) px), and
+        # (c) as before, predictors trained on the noise, with the offset statistics of each beside its number.
         other_bodies = {}
-        for name, kw, bs in (("R-101-FPN", dict(layers=(3, 4, 23, 3)), 2), ("X-101-64x4d-FPN-DCN", dict(body="x101dcn"), 1)):
+        legs = [("R-101-FPN", dict(layers=(3, 4, 23, 3)), 2, 102),
+                ("X-101-64x4d-FPN-DCN", dict(body="x101dcn", hold_offsets=True), 1, 103),
+                ("X-101-64x4d-FPN-DCN offsets within 1.5 px", dict(body="x101dcn", hold_offsets=True, offset_bias_px=1.5), 1, 103),
+                ("X-101-64x4d-FPN-DCN offsets after SGD on noise", dict(body="x101dcn"), 1, 103)]
+        for name, kw, bs, seed in legs:
             tr2 = Trainer(device, chunks=a.chunks, **kw)
             im2, tg2 = synthetic_batch(bs, a.height, a.width, 16, 1234, device)
             cal2, _ = synthetic_batch(bs, a.height, a.width, 1, 4321, device)
             calibrate_frozen_affine(tr2.model, cal2.tensors)
-            for _ in range(3):
-                tr2.step(im2, tg2)
-            sync()
-            t1 = time.perf_counter()
-            for _ in range(8):
-                tr2.step(im2, tg2)
-            sync()
-            el2 = time.perf_counter() - t1
-            l2 = {k: float(v.detach()) for k, v in tr2.last_losses.items()}
-            other_bodies[name] = {"img_per_s": round(bs * 8 / el2, 3), "ms_per_step": round(1000.0 * el2 / 8, 2),
-                                  "batch": bs, "steps": 8, "warmup": 3,
-                                  "roi_counts_last_step": dict(tr2.model.Grid_Cascade_RCNN.last_counts),
-                                  "finite_loss": all(v == v and abs(v) != float("inf") for v in l2.values())}
+            rec = timed_leg(tr2, im2, tg2, LEG_WARMUP, LEG_STEPS, world, device, seed=seed)
+            rec["batch"] = bs
+            if kw.get("body") == "x101dcn":
+                rec["offset_predictors"] = ("held at the reference's zero initialisation (lr_scale 0)" if kw.get("hold_offsets")
+                                            and not kw.get("offset_bias_px") else
+                                            "held at biases ~ U(-1.5, 1.5) px (lr_scale 0)" if kw.get("hold_offsets") else
+                                            "trained by SGD on the synthetic noise batch")
+                rec["offsets_after_the_timed_steps"] = offset_statistics(tr2, im2, tg2)
+            other_bodies[name] = rec
+            tr2.reducer.close()
             del tr2, im2, tg2, cal2
             torch.cuda.empty_cache()
         _hip.set_conv_math(a.conv_math)
@@ -716,6 +817,7 @@ def main():
                        **({"full_rois": full_rois} if full_rois else {}),
                        **({"other_bodies": other_bodies} if other_bodies else {}),
                        "grad_allreduce_chunks": a.chunks, **({"chunk_sweep": chunk_sweep} if chunk_sweep else {}),
+                       **({"comm": comm} if comm else {}),
                        "overlap_sgd": os.environ.get("CPM_OVERLAP_SGD", "0") != "0",
                        "static_part_as_hipgraph": bool(a.graph),
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")

@@ -54,3 +54,37 @@ CPM_EXPORT int cpm_stream_fork(void* from, void* to) {
   if (hipStreamWaitEvent((hipStream_t)to, ev, 0) != hipSuccess) return cpm::check_launch("stream wait");
   return CPM_OK;
 }
+
+// A stream whose kernels stay off `reserve_cus` of the chip's compute units (hipExtStreamCreateWithCUMask): the
+// weight-gradient stream of a data-parallel run can leave those CUs to the RCCL kernels that all-reduce finished
+// gradient chunks beside the backward pass (pet/utils/parallel.py, CPM_WGRAD_RESERVE_CUS).  The reserved units are
+// taken evenly from the ends of the eight 32-bit words of the mask (one word per 32 CUs).  *out: a hipStream_t the
+// caller owns (cpm_stream_destroy).
+CPM_EXPORT int cpm_stream_create_cu_reserve(int reserve_cus, void** out) {
+  CPM_REQUIRE(out, "null pointer");
+  hipDeviceProp_t prop;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return cpm::check_launch("device properties");
+  const int cus = prop.multiProcessorCount;
+  CPM_REQUIRE(reserve_cus >= 0 && reserve_cus < cus, "reserve must leave at least one compute unit");
+  const int words = (cus + 31) / 32;
+  uint32_t mask[32];
+  CPM_REQUIRE(words <= 32, "more than 1024 compute units");
+  for (int w = 0; w < words; ++w) {
+    const int bits = cus - 32 * w >= 32 ? 32 : cus - 32 * w;
+    mask[w] = bits == 32 ? 0xFFFFFFFFu : ((1u << bits) - 1u);
+  }
+  for (int i = 0; i < reserve_cus; ++i) {          // round-robin over the words, highest bits first
+    const int w = i % words, b = 31 - i / words;
+    mask[w] &= ~(1u << b);
+  }
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask) != hipSuccess) return cpm::check_launch("stream with CU mask");
+  *out = (void*)st;
+  return CPM_OK;
+}
+
+CPM_EXPORT int cpm_stream_destroy(void* stream) {
+  if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return cpm::check_launch("stream destroy");
+  return CPM_OK;
+}

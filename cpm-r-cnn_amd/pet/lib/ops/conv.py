@@ -369,7 +369,16 @@ def wgrad_stream(device):
         # CPM_WGRAD_PRIO: queue priority of the second stream (lower number = higher priority; out-of-range values map to
         # the nearest valid one): the weight gradients are leaves nothing waits for until the optimizer step, the
         # data-gradient chain on the compute stream is the critical path
-        t = torch.cuda.Stream(device=device, priority=int(os.environ.get("CPM_WGRAD_PRIO", "0")))
+        # CPM_WGRAD_RESERVE_CUS=n: the stream's kernels stay off n compute units (cpm_stream_create_cu_reserve), which
+        # a data-parallel run leaves to the RCCL kernels reducing finished gradient chunks beside the backward pass
+        reserve = int(os.environ.get("CPM_WGRAD_RESERVE_CUS", "0"))
+        if reserve > 0:
+            out = H.c_void_p()
+            with H.guard(device):
+                H.check(H.lib().cpm_stream_create_cu_reserve(reserve, H.ctypes.byref(out)), "stream_create_cu_reserve")
+            t = torch.cuda.ExternalStream(out.value, device=device)
+        else:
+            t = torch.cuda.Stream(device=device, priority=int(os.environ.get("CPM_WGRAD_PRIO", "0")))
         st = _side[idx] = (t, t.cuda_stream)
     return st[0]
 

@@ -299,8 +299,12 @@ class FlatSGD(torch.optim.Optimizer):
 
 
 class Optimizer(object):
-    def __init__(self, model, solver, local_rank=0):
+    def __init__(self, model, solver, local_rank=0, frozen_lr_keys=()):
+        """frozen_lr_keys: parameters whose name contains one of these strings form a fourth group with lr_scale 0 and no
+        weight decay -- their gradients are computed, their values stay (bench.py holds config #5's offset predictors
+        at their initialisation this way; the reference has no such group: pet/utils/optimizer.py:40-65)."""
         self.model, self.solver, self.local_rank = model, solver, local_rank
+        self.frozen_lr_keys = tuple(frozen_lr_keys)
 
     def build(self):
         S = self.solver
@@ -315,9 +319,13 @@ class Optimizer(object):
             if not p.requires_grad:
                 continue
             gi = 1 if "bias" in key else (2 if key in gn_names else 0)      # optimizer.py:30-38 order of tests
+            if any(f in key for f in self.frozen_lr_keys):
+                gi = 3
             named.append((key, p, gi))
         named.reverse()                      # reverse registration (~forward) order: backward fills front to back
         groups = [dict(weight_decay=S.WEIGHT_DECAY, lr_scale=1),
                   dict(weight_decay=S.WEIGHT_DECAY if S.BIAS_WEIGHT_DECAY else 0, lr_scale=S.BIAS_DOUBLE_LR + 1),
                   dict(weight_decay=S.WEIGHT_DECAY_GN * S.WEIGHT_DECAY, lr_scale=1)]
+        if self.frozen_lr_keys:
+            groups.append(dict(weight_decay=0.0, lr_scale=0))
         return FlatSGD(named, groups, S.MOMENTUM)

@@ -53,6 +53,10 @@ class FlatGradReducer(object):
         self._done = set()
         self._handles = []
         self._hook_handles, self._hooked = [], []
+        # timing (bench.py at N > 1; off in training runs): events on the communication stream around every chunk's
+        # collective and on the compute stream where the backward pass starts and ends -- comm_stats()
+        self.timing = False
+        self._ev = None
         if self.overlap or self.local_sgd:
             params = [p for g in optimizer.param_groups for p in g["params"]]
             by_id = {id(p): p for p in params}
@@ -109,6 +113,29 @@ class FlatGradReducer(object):
         self._done = set()
         self._next = 0
         self._handles = []
+        self._ev = None
+        if self.timing and self.stream is not None:
+            E = lambda: torch.cuda.Event(enable_timing=True)
+            self._ev = {"chunks": [None] * len(self.chunks), "bwd_begin": E(), "bwd_end": E(), "comm_end": E()}
+
+    def mark_backward_begin(self):
+        """timing runs: the trainer calls this right before it starts the backward pass"""
+        if self._ev is not None:
+            self._ev["bwd_begin"].record(torch.cuda.current_stream(self.flat.device))
+
+    def comm_stats(self):
+        """after a synchronize: {backward_ms, per_chunk_ms[], comm_busy_ms, exposed_ms} of the LAST step --
+        per_chunk_ms: each chunk's collective on the communication stream (plus its SGD update under CPM_OVERLAP_SGD);
+        exposed_ms: how long the compute stream waited for the communication stream behind the end of its backward
+        pass (0 = the collectives were hidden completely)"""
+        ev = self._ev
+        if ev is None or any(c is None for c in ev["chunks"]):
+            return None
+        per = [a.elapsed_time(b) for a, b in ev["chunks"]]
+        return {"backward_ms": round(ev["bwd_begin"].elapsed_time(ev["bwd_end"]), 3),
+                "per_chunk_ms": [round(x, 3) for x in per], "comm_busy_ms": round(sum(per), 3),
+                "first_chunk_start_ms_into_backward": round(ev["bwd_begin"].elapsed_time(ev["chunks"][0][0]), 3),
+                "exposed_ms": round(max(0.0, ev["bwd_end"].elapsed_time(ev["comm_end"])), 3)}
 
     def _launch(self, ci):
         b, e, _ = self.chunks[ci]
@@ -117,20 +144,30 @@ class FlatGradReducer(object):
         if side is not None:
             self.stream.wait_stream(side)
         with torch.cuda.stream(self.stream):
+            if self._ev is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self._ev["chunks"][ci] = (e0, e1)
+                e0.record(self.stream)
             if self.world > 1:
                 dist.all_reduce(self.flat[b:e], op=dist.ReduceOp.SUM)
             if self.local_sgd:
                 # (chunks end on tensor ends, tensors start on 64-element boundaries: the gap belongs to nobody)
                 self.opt.step_range((b + 63) // 64 * 64, (e + 63) // 64 * 64)
+            if self._ev is not None:
+                self._ev["chunks"][ci][1].record(self.stream)
 
     def finish(self):
         """Call after backward: reduce whatever is left and make the compute stream wait for the reductions."""
         if self.world == 1 and not self.local_sgd:
             return
         if self.overlap or self.local_sgd:
+            if self._ev is not None:
+                self._ev["bwd_end"].record(torch.cuda.current_stream(self.flat.device))
             while self._next < len(self.chunks):   # incl. chunks with tensors that got no gradient this step
                 self._launch(self._next)
                 self._next += 1
+            if self._ev is not None:
+                self._ev["comm_end"].record(self.stream)
             torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
         else:
             for b, e, _ in self.chunks:

@@ -573,6 +573,12 @@ int cpm_rescore_gather(const float* s_boxes, const float* s_obj, const int64_t* 
  * from a ring per device (the current device's: both streams must belong to it); safe to call from the autograd
  * engine's per-device worker threads. */
 int cpm_stream_fork(void* from, void* to);
+/* A stream whose kernels stay off `reserve_cus` compute units (hipExtStreamCreateWithCUMask); *out is a hipStream_t the
+ * caller owns.  No reference counterpart: DistributedDataParallel (tools/rcnn/train_net.py:134-136) leaves the overlap of
+ * NCCL kernels with the backward pass to the device scheduler; here the weight-gradient stream can leave CUs to RCCL
+ * (pet/utils/parallel.py, CPM_WGRAD_RESERVE_CUS). */
+int cpm_stream_create_cu_reserve(int reserve_cus, void** out);
+int cpm_stream_destroy(void* stream);
 
 /* ---- a chain of RoI-head layers (conv + bias -> [GroupNorm] -> [ReLU]) from one call --------------------------------
  * The CMM grid head (8 x conv3x3 -> GroupNorm -> ReLU, pet/rcnn/modeling/grid_rcnn/heads/grid_heads.py:41-57,146-152),
