@@ -161,6 +161,10 @@ class Trainer(object):
         # 614 MB memset of zero_grad -- 0.3 ms in front of every forward pass -- becomes part of a pass that has the
         # lines anyway)
         self.optimizer.clear_grads_in_step = os.environ.get("CPM_CLEAR_GRADS_IN_STEP", "1") != "0"
+        # the SGD kernel (HBM streaming) and the weight-image transform run on the optimizer stream beside the next
+        # step's frozen stem / layer1; the forward pass waits at its first trainable tensor (tools/rcnn/train_net.py
+        # does the same)
+        self.optimizer.overlap_next_forward = os.environ.get("CPM_SGD_BESIDE_FORWARD", "1") != "0"
         self.scheduler = LearningRateScheduler(self.optimizer, self.cfg.SOLVER, start_iter=0)
         self.reducer = FlatGradReducer(self.optimizer, num_chunks=chunks)
         self.last_losses = None
@@ -819,6 +823,7 @@ def main():
                        "grad_allreduce_chunks": a.chunks, **({"chunk_sweep": chunk_sweep} if chunk_sweep else {}),
                        **({"comm": comm} if comm else {}),
                        "overlap_sgd": os.environ.get("CPM_OVERLAP_SGD", "0") != "0",
+                       "sgd_beside_next_forward": os.environ.get("CPM_SGD_BESIDE_FORWARD", "1") != "0",
                        "static_part_as_hipgraph": bool(a.graph),
                        "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},

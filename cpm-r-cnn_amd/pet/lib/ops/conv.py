@@ -1285,6 +1285,7 @@ class _LayerChainFn(Function):
     @staticmethod
     def forward(ctx, x, plan):
         H.require_gpu(x)
+        H.wait_pending_sgd(x.device)            # (the chain's parameters travel as raw pointers in its plan)
         x = nhwc(x) if x.dim() == 4 else x.contiguous()
         n = x.shape[0]
         fwd_floats, _, ws_bytes = plan.sizes_for(n)

@@ -100,6 +100,8 @@ class Generalized_RCNN(nn.Module):
         x = sample.detach().clone()
         from pet.lib.ops import conv as _conv
         _conv.wait_pending_wt(x.device)          # (the capture must not record a wait for an event of the eager step)
+        from pet.lib.ops import _hip as _H
+        _H.wait_pending_sgd(x.device)            # (nor for an optimizer update queued beside the next forward pass)
         graphed = torch.cuda.make_graphed_callables(part, (x,), allow_unused_input=True)
         self._graphed = getattr(self, "_graphed", {})
         self._graphed[tuple(sample.shape)] = graphed
@@ -113,8 +115,9 @@ class Generalized_RCNN(nn.Module):
         if graphed is not None:
             # a replayed backward pass issues no Python-side waits: the once-per-step weight-image transform on the
             # second stream (FlatSGD._refresh_dgrad_weights) is ordered in front of the replay here
-            from pet.lib.ops import conv as _conv
+            from pet.lib.ops import _hip as _H, conv as _conv
             _conv.wait_pending_wt(images.tensors.device)
+            _H.wait_pending_sgd(images.tensors.device)        # (an optimizer update queued beside this forward pass)
             outs = graphed(images.tensors)
             nf = nl = len(outs) // 3                 # feature maps, objectness maps, delta maps: one each per level
             # the replayed outputs are fresh tensor objects: the RoI heads' RoIAlign calls share ONE gradient
@@ -124,6 +127,11 @@ class Generalized_RCNN(nn.Module):
                                                   head_out=(list(outs[nf:nf + nl]), list(outs[nf + nl:])))
         else:
             feats = self._features(images.tensors)
+            if feats and feats[0].is_cuda:
+                # FlatSGD.overlap_next_forward: the first op on a trainable tensor has waited for the update already
+                # (H.require_gpu); this is the net under a body without one
+                from pet.lib.ops import _hip as _H
+                _H.wait_pending_sgd(feats[0].device)
             proposals, proposal_losses = self.RPN(images, feats, targets)
         roi_losses = {}
         if not cfg.MODEL.RPN_ONLY:

@@ -132,6 +132,10 @@ class CheckPointer(object):
 
     @staticmethod
     def _blob(model, optimizer, scheduler):
+        # (an optimizer update queued beside the next forward pass -- FlatSGD.overlap_next_forward -- must have landed
+        # before the parameters are copied out)
+        from pet.lib.ops import _hip as _H
+        _H.wait_pending_sgd()
         blob = {"model": OrderedDict((k, v.detach().cpu().contiguous()) for k, v in model.state_dict().items())}
         if optimizer is not None:
             blob["optimizer"] = optimizer.state_dict()

@@ -96,6 +96,7 @@ class FlatSGD(torch.optim.Optimizer):
         return out
 
     def state_dict(self):
+        self.wait()
         begins, ends = self.seg_begin.tolist(), self.seg_end.tolist()
         state, groups, idx = {}, [], 0
         for g, segs in zip(self.param_groups, self._canonical()):
@@ -114,6 +115,7 @@ class FlatSGD(torch.optim.Optimizer):
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, state_dict):
+        self.wait()
         saved = [g for g in state_dict["param_groups"] if len(g["params"])]
         mine = self._canonical()
         if [len(g["params"]) for g in saved] != [len(s) for s in mine]:
@@ -144,6 +146,11 @@ class FlatSGD(torch.optim.Optimizer):
         # with a zero buffer momentum*0 + d is the same value, so a partially filled state is still exact)
         self._steps = 1 if loaded else 0
 
+    def wait(self):
+        """the current stream waits for an update queued beside it (overlap_next_forward): call before reading parameters
+        or optimizer state with anything but this package's ops (they wait by themselves)"""
+        H.wait_pending_sgd(self.flat_param.device if self.flat_param.is_cuda else None)
+
     def zero_grad(self, set_to_none=False):
         # one memset; .grad views stay attached.  With `clear_grads_in_step` (a trainer's choice: gradients are then zero
         # after step(), unlike torch.optim's) the SGD kernel has already cleared every element behind its use.
@@ -153,6 +160,7 @@ class FlatSGD(torch.optim.Optimizer):
         from pet.lib.ops import conv as C
         if not (self.clear_grads_in_step and self._grads_cleared
                 and C.grad_write_generation() == self._write_gen_at_step):
+            self.wait()                              # (the update reads the gradients it is about to clear)
             self.flat_grad.zero_()
         self._grads_cleared = False
         for g in self.param_groups:
@@ -190,7 +198,25 @@ class FlatSGD(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        if self._stepped_end < self.total:
+        # overlap_next_forward (a training loop's choice, off by default): the update -- HBM streaming, nothing for the
+        # matrix cores -- and the weight-image transform behind it go to the optimizer stream; the next forward pass
+        # starts at once and waits where it first touches a trainable tensor (H.wait_pending_sgd), i.e. behind the frozen
+        # stem / layer1.  Readers of parameters outside this package's ops call wait() first.
+        ov = bool(getattr(self, "overlap_next_forward", False)) and self.flat_param.is_cuda
+        self._opt_stream = None
+        if ov:
+            dev = self.flat_param.device
+            H.wait_pending_sgd(dev)                  # (an earlier update nobody waited for: keep them in order)
+            st = H.optimizer_stream(dev)
+            H.fork(H._raw_stream(dev.index if dev.index is not None else torch.cuda.current_device()), st.cuda_stream)
+            self._opt_stream = st
+            with H.use_stream(st.cuda_stream):
+                if self._stepped_end < self.total:
+                    self.step_range(self._stepped_end, self.total)
+            ev = torch.cuda.Event()
+            ev.record(st)
+            H.set_pending_sgd_event(ev, dev)
+        elif self._stepped_end < self.total:
             self.step_range(self._stepped_end, self.total)
         self._stepped_end = 0
         self._steps += 1
@@ -273,13 +299,17 @@ class FlatSGD(torch.optim.Optimizer):
         from pet.lib.ops import conv as C
         dev = self.flat_param.device
         side = C.wgrad_stream(dev) if os.environ.get("CPM_WT_ON_SIDE", "1") != "0" else None
+        own = getattr(self, "_opt_stream", None)         # step() put the update on the optimizer stream: stay behind it
+        if own is not None:
+            side = own
         # under bf16x3 the images are written pre-split (weights with K / groups % 4 == 0; conv._prepared_call)
         w4 = C._W4 and C.bf16x3()
         transform = H.lib().cpm_weights_to_dgrad_batched_w4 if w4 else H.lib().cpm_weights_to_dgrad_batched
         with H.guard(dev):
             if side is not None:
-                main_raw = H._raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
-                H.fork(main_raw, side.cuda_stream)
+                if own is None:
+                    main_raw = H._raw_stream(dev.index if dev.index is not None else torch.cuda.current_device())
+                    H.fork(main_raw, side.cuda_stream)
                 with H.use_stream(side.cuda_stream):
                     rc = transform(H.ptr(self._wt_table), len(self._wt_params), H.c_int64(self._wt_tiles),
                                    H.ptr(self.flat_param), H.ptr(self.flat_wt), H.stream())

@@ -99,6 +99,8 @@ def main(argv=None):
     model = convert_bn2affine_model(model, merge=not checkpointer.resume)
     model = model.to(device).to(memory_format=torch.channels_last)
     optimizer = checkpointer.load_optimizer(Optimizer(model, cfg.SOLVER, local_rank=rank).build())
+    # the SGD update streams beside the next iteration's frozen stem / layer1 (FlatSGD.step); checkpoints wait for it
+    optimizer.overlap_next_forward = os.environ.get("CPM_SGD_BESIDE_FORWARD", "1") != "0"
     log.info("The mismatch keys: %s", mismatch_params_filter(sorted(checkpointer.mismatch_keys)))
     scheduler = checkpointer.load_scheduler(LearningRateScheduler(optimizer, cfg.SOLVER, start_iter=0, local_rank=rank))
     if distributed:

@@ -20,8 +20,12 @@ def main():
     sgd = [i for i, e in enumerate(ev) if "sgd_kernel" in e[2]]
     k = int(sys.argv[2]) if len(sys.argv) > 2 else len(sgd) - 3
     step = ev[sgd[k]:sgd[k + 1] + 1]
-    t0 = end = step[0][1]
+    # times count from the START of the previous step's SGD kernel (it may run beside this step's frozen layers:
+    # FlatSGD.overlap_next_forward); gaps are device idle time (no kernel of any stream running)
+    t0 = step[0][0]
+    end = step[0][1]
     busy = idle = 0.0
+    print("%8.3f  gap %6.1f  dur %7.1f  %s" % (0.0, 0.0, (step[0][1] - step[0][0]) / 1e3, short(step[0][2])))
     for s, e, n in step[1:]:
         gap = (s - end) / 1e3
         idle += max(gap, 0.0)
