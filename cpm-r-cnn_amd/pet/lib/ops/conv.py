@@ -468,6 +468,19 @@ def _wait_readers(h):
         torch.cuda.current_stream().wait_event(ev)
 
 
+def _side_copies(*pairs):
+    """(given, used) tensor pairs of an op that may run inside a forward side section (fwd_side): a layout / contiguity
+    copy made just now ran on the COMPUTE stream behind the fork point and is a compute-stream block to the allocator --
+    order the second stream behind it and park it until the join (H.keep); no-op outside a section or without copies"""
+    if not H.in_side_section():
+        return
+    made = [u for g, u in pairs if u is not None and u is not g]
+    if made:
+        H.keep(*made)
+        idx = made[0].device.index
+        H.fork(H._raw_stream(idx if idx is not None else torch.cuda.current_device()), H.stream_raw())
+
+
 class _ConvFn(Function):
     """y = relu?( conv(x, w) * scale + shift + residual )   (scale/shift/residual optional).
     scale is a frozen per-channel factor (AffineChannel2d) and never receives a gradient; shift receives one
@@ -481,6 +494,7 @@ class _ConvFn(Function):
         w_in = w
         w = _wmem(w)
         res = nhwc(residual) if residual is not None else None
+        _side_copies((x_in, x), (w_in, w), (residual, res))
         # a parameter owned by the flat optimizer carries `_cpm_grad_sink` (its slice of the flat gradient buffer):
         # the weight-gradient kernel then accumulates straight into it (no temporary, no autograd add) and the
         # data-parallel reducer is told when the last use of the step has been accumulated

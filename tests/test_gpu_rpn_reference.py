@@ -165,6 +165,11 @@ def test_rpn_head_training_step_equals_reference(golden_head, meta_head, monkeyp
         rpn = RPNModule([Cc] * 5).cuda()
         rpn.train()
         det_fill_(rpn.head)
+        if backward == "sparse":
+            # (the dense cases keep the module's weights NCHW-contiguous on purpose: every conv call then makes a KRSC
+            # copy of its weight, inside the forward side sections too -- the copy must be ordered in front of the side
+            # stream's kernel and outlive it: conv._side_copies)
+            rpn = rpn.to(memory_format=torch.channels_last)
         shapes = [((Hh + s - 1) // s, (W + s - 1) // s) for s in (4, 8, 16, 32, 64)]
         feats = [rpn_head_feature(i, (2, Cc, h, w)).cuda().contiguous(memory_format=torch.channels_last)
                  .requires_grad_(True) for i, (h, w) in enumerate(shapes)]
