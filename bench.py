@@ -562,7 +562,10 @@ def main():
     layers = tuple(int(x) for x in a.layers.split(","))
     chunk_list = [max(1, int(c)) for c in str(a.chunks).split(",") if c.strip()]
     a.chunks = chunk_list[0]
-    trainer = Trainer(device, layers=layers, body=a.body, chunks=a.chunks)
+    # (--body x101dcn as the headline: the offset predictors are held at the reference's zero initialisation, as in the
+    # X-101 leg of the default run -- see config.other_bodies; CPM_BENCH_HOLD_OFFSETS=0 trains them on the noise)
+    trainer = Trainer(device, layers=layers, body=a.body, chunks=a.chunks,
+                      hold_offsets=a.body == "x101dcn" and os.environ.get("CPM_BENCH_HOLD_OFFSETS", "1") != "0")
     images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
     cal_img, _ = synthetic_batch(a.batch, a.height, a.width, 1, 4321, device)     # same on every rank
     calibrate_frozen_affine(trainer.model, cal_img.tensors)

@@ -44,7 +44,13 @@ namespace {
 // SPLIT: 0 = exact f32 MFMA, 1 = bf16x3 with both operands split in the kernel, 2 = bf16x3 with the WEIGHT operand given
 // as a pre-split image (a.wm points at it; cpm_split_w4: per four consecutive reduction elements 8 bytes of hi and 8
 // bytes of lo in place of their 16 bytes of f32 -- the same offsets, no conversion work on that side).
-template <int BM, int BN, int WM, int WN, bool VEC, int SPLIT>
+// TAIL (vector path): the reduction channel count is not a multiple of 4 (the data gradient of an 18-channel conv -- the
+// offset predictors of DeformConvPack): rows are then 4- or 8-byte aligned only, which buffer_load_dwordx4 serves at
+// full width (tools/probes/round5/unaligned_probe.hip), and the components of a 16-byte load that reach past the row's
+// channels -- the next tap's / pixel's first values -- are zeroed in registers (past the tensor's end the descriptor's
+// per-dword range check returns zeros by itself: range_probe.hip).  Before: the scalar path, 40.8 us against 26.3 for
+// the same layer padded to 20 channels.
+template <int BM, int BN, int WM, int WN, bool VEC, int SPLIT, bool TAIL = false>
 __global__ __launch_bounds__(64 * WM * WN)
     __attribute__((amdgpu_waves_per_eu(2, (BM * BN >= 128 * 128 ? 2 : (BM * BN >= 128 * 64 ? 3 : 4))))) void igemm_kernel(
         IgemmArgs a) {
@@ -151,6 +157,15 @@ __global__ __launch_bounds__(64 * WM * WN)
       }
 #pragma unroll
       for (int i = 0; i < BP; ++i) rb[i] = bload4(rs_wm, c_ok ? b_off[i] + wtap : OOB_OFF);
+      if (TAIL) {
+        const int rem = a.CgR - (cb + lcol);                  // channels of this lane's 4 that exist (<= 0: all masked above)
+        if (rem < 4) {
+#pragma unroll
+          for (int i = 0; i < AP; ++i) { if (rem < 2) ra[i].y = 0.f; if (rem < 3) ra[i].z = 0.f; ra[i].w = 0.f; }
+#pragma unroll
+          for (int i = 0; i < BP; ++i) { if (rem < 2) rb[i].y = 0.f; if (rem < 3) rb[i].z = 0.f; rb[i].w = 0.f; }
+        }
+      }
       return;
     }
     const int c0 = cb + lcol;
@@ -1665,6 +1680,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(WgradArgs a) {
         const int ocl = oc0 + cv;
         const bool ok = pr < 32 && m < a.M && ocl < a.OCg;
         v = bload4(rs_dy, ok ? (unsigned)(m * a.OCtot + g * a.OCg + ocl) * 4u : OOB_OFF);
+        // an output channel count that is not a multiple of 4 (18: DeformConvPack's offset predictor): the row's last
+        // 16-byte load reaches into the next pixel's row (4-byte aligned loads are served at full width) -- zero those
+        // components; never taken otherwise
+        if (ocl + 3 >= a.OCg) {
+          if (ocl + 1 >= a.OCg) v.y = 0.f;
+          if (ocl + 2 >= a.OCg) v.z = 0.f;
+          v.w = 0.f;
+        }
       } else if (pr < 32 && m < a.M) {
         const int ocl = oc0 + cv;
         const size_t off = (size_t)m * a.OCtot + g * a.OCg + ocl;
@@ -2774,7 +2797,9 @@ int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t
 #define LAUNCH(BM, BN, WM, WN)                                                                       \
   do {                                                                                               \
     dim3 grid((unsigned)(cpm::cdiv(rows, BM) * cpm::cdiv(a.OCg, BN)), a.groups, a.split_k);          \
-    if (vec && g_conv_split && a.b_presplit)                                                               \
+    if (vec && g_conv_split && a.tail)                                                                     \
+      hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, 1, true>), grid, dim3(64 * WM * WN), 0, s, a); \
+    else if (vec && g_conv_split && a.b_presplit)                                                          \
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, 2>), grid, dim3(64 * WM * WN), 0, s, a);      \
     else if (vec && g_conv_split)                                                                          \
       hipLaunchKernelGGL((igemm_kernel<BM, BN, WM, WN, true, 1>), grid, dim3(64 * WM * WN), 0, s, a);      \
@@ -2795,8 +2820,16 @@ int launch_one(const IgemmArgs& a, int bm, int bn, int wn, bool vec, hipStream_t
 }
 
 int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
-  const bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
-                   (((uintptr_t)a.wm & 15) == 0);
+  bool vec = (a.CgR % 4 == 0) && (a.Ctot % 4 == 0) && (((uintptr_t)a.in & 15) == 0) &&
+             (((uintptr_t)a.wm & 15) == 0);
+  // ragged reduction channels (18): the vector path with masked tails (igemm_kernel<.., TAIL>), bf16x3 only
+  static const int tail_on = env_int("CPM_IGEMM_TAIL_VEC", 1);
+  a.tail = 0;
+  if (!vec && tail_on && g_conv_split && !a.b_presplit && a.groups == 1 && a.CgR == a.Ctot && a.CgR >= 4 &&
+      (((uintptr_t)a.in & 15) == 0) && (((uintptr_t)a.wm & 15) == 0)) {
+    vec = true;
+    a.tail = 1;
+  }
   if (a.b_presplit && !(vec && g_conv_split)) {
     cpm::set_error("conv igemm: a pre-split weight image outside the bf16x3 vector path");
     return CPM_EINVAL;
@@ -3422,8 +3455,12 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
     }
     return rc1;
   }
-  const bool wvec = (a.OCtot % 4 == 0) && (a.OCg % 4 == 0) && (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) &&
-                    (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
+  // wvec_x: the input side is vector-loadable; wvec: the gradient side too (the bf16x3 kernels need both).  The f32
+  // tile kernel takes ragged output channel counts on its vector path by masking the tail of a row's last load.
+  static const int tail_on = env_int("CPM_WGRAD_TAIL_VEC", 1);
+  const bool wvec_x = (a.Ctot % 4 == 0) && (a.Cg % 4 == 0) && (((uintptr_t)a.x & 15) == 0) && (((uintptr_t)a.dy & 15) == 0);
+  const bool wvec = wvec_x && (a.OCtot % 4 == 0) && (a.OCg % 4 == 0);
+  const bool wvec_f32 = wvec || (wvec_x && tail_on && a.groups == 1 && a.OCg >= 4);
   const WgradPlan p = plan_wgrad(a, wvec);
   a.split_k = p.split;
   // Deterministic mode (cpm_set_deterministic / CPM_DETERMINISTIC / CPM_WGRAD_SLAB=1): a split reduction lands in one
@@ -3467,7 +3504,7 @@ static int run_wgrad(const cpm_conv_desc* d, const float* x, const float* dy, fl
     else if (p.bf16)                                                                                 \
       hipLaunchKernelGGL((wgrad_split_kernel<(BM) % 64 == 0 ? BM : 64, (BN) % 64 == 0 ? BN : 64, 2, 2>), grid, \
                          dim3(256), 0, s, a);                                                        \
-    else if (wvec)                                                                                   \
+    else if (wvec_f32)                                                                               \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, true>), grid, dim3(256), 0, s, a);            \
     else                                                                                             \
       hipLaunchKernelGGL((wgrad_kernel<BM, BN, WM, WN, false>), grid, dim3(256), 0, s, a);           \

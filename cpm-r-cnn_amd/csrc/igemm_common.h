@@ -91,6 +91,7 @@ struct IgemmArgs {
                        //   null: float atomics into the zeroed output (no workspace)
   int staged_epi;      // finish every non-atomic epilogue row-wise through LDS (16-byte accesses), not only residual ones
   int b_presplit;      // wm is a pre-split weight image (cpm_split_w4): bf16x3 arithmetic, vector path only
+  int tail;            // reduction channels % 4 != 0 on the vector path: igemm_kernel<.., TAIL> masks the rows' last loads
   int dbg;             // timing-only experiments (CPM_IGEMM_DBG): 8 zero-record descriptors (nothing fetched), 16 no epilogue
 };
 

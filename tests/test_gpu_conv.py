@@ -46,6 +46,8 @@ CASES = [
     ("iou_pred", 5, 1024, 1, 1, 2, 1, 1, 0, 1),
     ("grouped", 2, 64, 8, 8, 128, 3, 1, 1, 4),
     ("odd_c", 2, 36, 5, 6, 20, 3, 1, 1, 1),
+    ("offset_pred", 1, 64, 12, 17, 18, 3, 1, 1, 1),        # DeformConvPack.conv_offset: 18 output channels -- ragged rows on
+                                                             # the vector paths (igemm_kernel<.., TAIL>, wgrad tail mask)
     ("depthwise", 2, 32, 9, 11, 64, 3, 1, 1, 32),          # one input channel per group: wgrad_cg1_kernel, incl. the
                                                              # frozen scale at its stores (epi affine_res_relu)
     ("7x7_s2", 1, 32, 20, 24, 64, 7, 2, 3, 1),

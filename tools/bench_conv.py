@@ -48,6 +48,10 @@ LAYERS = [
     ("x_l3_1x1_1024_1024", 1, 1024, 50, 84, 1024, 1, 1, 0, 1, 45),
     ("x_l4_1x1_2048_2048", 1, 2048, 25, 42, 2048, 1, 1, 0, 1, 5),
     ("x_l3_offset_1024_18", 1, 1024, 50, 84, 18, 3, 1, 1, 1, 23),
+    ("x_l3_offset_1024_20", 1, 1024, 50, 84, 20, 3, 1, 1, 1, 0),      # (the same padded to a multiple of 4 / to an MFMA tile)
+    ("x_l3_offset_1024_32", 1, 1024, 50, 84, 32, 3, 1, 1, 1, 0),
+    ("x_l2_offset_512_20", 1, 512, 100, 168, 20, 3, 1, 1, 1, 0),
+    ("x_l4_offset_2048_20", 1, 2048, 25, 42, 20, 3, 1, 1, 1, 0),
 ]
 
 
