@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * WM * WN)
 }
 
 // ---- the same kernel with ONE LDS stage and one register set of loads (bf16x3, vector path, direct epilogues) --------
-// Measured with in-kernel stamps (DESIGN.md 8.3): a k-step of igemm_kernel costs a wave ~2 900 cycles for 768 cycles of
+// Measured with in-kernel stamps (DESIGN.md 11.3, round 2): a k-step of igemm_kernel costs a wave ~2 900 cycles for 768 cycles of
 // MFMA work whether or not it shares its SIMD, and two waves per SIMD overlap 1.84x -- what bounds the kernel is the
 // number of instruction streams per SIMD, which its 72 KB of LDS and ~240 VGPRs hold at two.  Here a k-step is
 //   barrier (every wave has its operands of tile t-1 in registers) -> split + store tile t into THE stage, issue the

@@ -25,12 +25,16 @@ using namespace cpmconv;
 
 namespace {
 
-template <int BM, int BN, bool BPRE>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void igemm_ws_kernel(IgemmArgs a) {
-  constexpr int WM = 2, WN = 2;
-  constexpr int NL = 256;                       // loader threads (waves 4-7)
+template <int BM, int BN, bool BPRE, int LW = 4, int WTN_ = 64>
+__global__ __launch_bounds__(64 * ((BM / 64) * (BN / WTN_) + LW))
+    __attribute__((amdgpu_waves_per_eu((((BM / 64) * (BN / WTN_) + LW) == 12 ? 3 : (((BM / 64) * (BN / WTN_) + LW) == 10 ? 5 : 4)),
+                                       (((BM / 64) * (BN / WTN_) + LW) == 12 ? 3 : (((BM / 64) * (BN / WTN_) + LW) == 10 ? 5 : 4))))) void igemm_ws_kernel(IgemmArgs a) {
+  constexpr int WM = BM / 64, WN = BN / WTN_;   // MFMA waves: one 64 x WTN_ tile each
+  constexpr int NW = WM * WN;
+  constexpr int NT = 64 * (NW + LW);
+  constexpr int NL = 64 * LW;                   // loader threads (the last LW waves)
   constexpr int RPP = NL / 8;                   // rows per load pass
-  constexpr int WTM = BM / WM, WTN = BN / WN;
+  constexpr int WTM = 64, WTN = WTN_;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   constexpr int AP = BM / RPP, BP = BN / RPP;
   static_assert(WTM % 32 == 0 && WTN % 32 == 0 && BM % RPP == 0 && BN % RPP == 0 && RPP % 16 == 0, "tile shape");
@@ -41,7 +45,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   constexpr int PA_HI = 0, PA_LO = 2 * BM * 16, PB_HI = 4 * BM * 16, PB_LO = 4 * BM * 16 + 2 * BN * 16;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const bool loader = wave >= 4;
+  const bool loader = wave >= NW;
   const int tiles_n = (a.OCg + BN - 1) / BN;
   int bid = blockIdx.x;
   if (a.xcd_swizzle) {
@@ -58,13 +62,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int k_end = min(a.ksteps, k_begin + per);
   const int nk = k_end - k_begin;
 
-  const int wq = wave & 3;                      // MFMA wave position in the 2 x 2 grid (loader waves: unused)
+  const int wq = wave % NW;                     // MFMA wave position in the WM x WN grid (loader waves: unused)
   const int wm = wq / WN, wn = wq % WN;
   f32x16 acc[TM][TN];
 
   if (loader) {
     // ---- loader waves ------------------------------------------------------------------------------------------------
-    const int lt = tid - 256;
+    const int lt = tid - 64 * NW;
     const int lrow = lt >> 3, lcol = (lt & 7) * 4;
     unsigned a_off[AP];
     int a_h[AP], a_w[AP];
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
     __syncthreads();
     constexpr int CV = BN / 4;
-    constexpr int RPS = 512 / CV;
+    constexpr int RPS = NT / CV;
     const int cv = (tid % CV) * 4, r0 = tid / CV;
     const int ocl = n0 + cv;
     const bool vec_out = (a.OCg & 3) == 0 && (a.OCtot & 3) == 0 && ocl + 3 < a.OCg;
@@ -380,6 +384,19 @@ int launch_ws(const IgemmArgs& a, int bm, int bn, hipStream_t s) {
   if (bm == 128 && bn == 128) {
     if (a.b_presplit) hipLaunchKernelGGL((igemm_ws_kernel<128, 128, true>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((igemm_ws_kernel<128, 128, false>), grid, dim3(512), 0, s, a);
+  } else if (bm == 256 && bn == 128) {
+    static const char* lwv = getenv("CPM_IGEMM_WS_LOADERS");
+    const int lw = lwv ? atoi(lwv) : 8;
+    if (lw == 8) {
+      if (a.b_presplit) hipLaunchKernelGGL((igemm_ws_kernel<256, 128, true, 8>), grid, dim3(1024), 0, s, a);
+      else hipLaunchKernelGGL((igemm_ws_kernel<256, 128, false, 8>), grid, dim3(1024), 0, s, a);
+    } else {
+      if (a.b_presplit) hipLaunchKernelGGL((igemm_ws_kernel<256, 128, true>), grid, dim3(768), 0, s, a);
+      else hipLaunchKernelGGL((igemm_ws_kernel<256, 128, false>), grid, dim3(768), 0, s, a);
+    }
+  } else if (bm == 128 && bn == 96) {
+    if (a.b_presplit) hipLaunchKernelGGL((igemm_ws_kernel<128, 96, true, 4, 32>), grid, dim3(640), 0, s, a);
+    else hipLaunchKernelGGL((igemm_ws_kernel<128, 96, false, 4, 32>), grid, dim3(640), 0, s, a);
   } else {
     return CPM_EINVAL;
   }
