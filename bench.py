@@ -591,9 +591,13 @@ def main():
         for _ in range(2):                                  # (zero_grad of these steps clears what the capture left)
             trainer.step(images, targets)
     sync()
+    head_counts = {}                  # min / max RoI count of every timed step (host-side values: no extra sync)
     t0 = time.perf_counter()
     for i in range(a.steps):
         trainer.step(images, targets)
+        for k_, v_ in trainer.model.Grid_Cascade_RCNN._last_counts.items():
+            lo_, hi_ = head_counts.get(k_, (v_, v_))
+            head_counts[k_] = (min(lo_, v_), max(hi_, v_))
         if a.verbose and rank == 0:
             print("step %d lr=%.5f %s" % (i, trainer.scheduler.new_lr, {k: round(float(v.detach()), 4)
                                                                     for k, v in trainer.last_losses.items()}), flush=True)
@@ -828,7 +832,9 @@ def main():
                        "overlap_sgd": os.environ.get("CPM_OVERLAP_SGD", "0") != "0",
                        "sgd_beside_next_forward": os.environ.get("CPM_SGD_BESIDE_FORWARD", "1") != "0",
                        "static_part_as_hipgraph": bool(a.graph),
-                       "roi_counts_last_step": counts, "finite_loss": all(v == v and abs(v) != float("inf")
+                       "roi_counts_last_step": counts,
+                       "roi_counts_min_max": {k: list(v) for k, v in sorted(head_counts.items())},
+                       "finite_loss": all(v == v and abs(v) != float("inf")
                                                                          for v in losses.values())},
             "roofline": roof, "hbm_kernels": hbm, "cpu_baseline": cpu,
         }
