@@ -147,6 +147,7 @@ _cur_device = torch._C._cuda_getDevice
 
 
 _override = None        # raw hipStream_t the ops launch on instead of torch's current stream (see use_stream)
+_override_ts = None     # its torch.cuda.Stream object when the section ALLOCATES on that stream's behalf (side_alloc)
 
 
 def stream_raw():
@@ -161,20 +162,41 @@ def stream():
 
 class use_stream(object):
     """`with use_stream(raw):` -- every op launched inside goes to that raw stream (cheaper than torch.cuda.stream,
-    and invisible to torch: tensors allocated inside still belong to torch's current stream)."""
-    __slots__ = ("raw", "prev")
+    and invisible to torch: tensors allocated inside still belong to torch's current stream).  `alloc_on`: the torch
+    stream object of `raw` -- tensors the ops create inside are then allocated from THAT stream's pool (side_alloc)."""
+    __slots__ = ("raw", "ts", "prev")
 
-    def __init__(self, raw):
-        self.raw = raw
+    def __init__(self, raw, alloc_on=None):
+        self.raw, self.ts = raw, alloc_on
 
     def __enter__(self):
-        global _override
-        self.prev, _override = _override, self.raw
+        global _override, _override_ts
+        self.prev = (_override, _override_ts)
+        _override, _override_ts = self.raw, self.ts
 
     def __exit__(self, *exc):
-        global _override
-        _override = self.prev
+        global _override, _override_ts
+        _override, _override_ts = self.prev
         return False
+
+
+def side_alloc(fn):
+    """Run the allocation(s) `fn()` makes for an op.  Inside a forward side section (conv.fwd_side) the op's kernel runs
+    on the second stream, forked from the compute stream some way back: a block the caching allocator hands out from
+    the COMPUTE stream's pool may have been freed by a tensor that compute-stream kernels queued behind the fork point
+    are still reading (a bottleneck's conv1 output, dropped when conv2 returned, became its downsample conv's output:
+    the X-101 body read garbage whenever the pool offered that block).  So such tensors come from the second stream's
+    own pool, and the compute stream is recorded as a user (their consumers run there behind the join), which makes
+    the allocator wait for it before the block is handed on."""
+    if _override is None or _override_ts is None or torch.cuda.is_current_stream_capturing():
+        return fn()             # (under a hipGraph capture every allocation belongs to the capture's private pool)
+    main = torch.cuda.current_stream(_override_ts.device)
+    with torch.cuda.stream(_override_ts):
+        out = fn()
+    for t in (out if isinstance(out, (tuple, list)) else (out,)):
+        if t is not None:
+            t.record_stream(main)
+    return out
 
 
 # Tensors created inside a use_stream() section are compute-stream blocks to torch's caching allocator (torch's current
@@ -234,6 +256,18 @@ def guard(device):
 # dicts, graph replays).
 _pending_sgd = {}        # device index -> [events]
 _opt_streams = {}
+_aux_streams = {}        # device index -> [torch streams this package launches kernels on besides the compute stream]
+
+
+def register_aux_stream(device, stream):
+    """a stream kernels of this package may be queued on beside torch's current one (the second / weight-gradient
+    stream, the deformable parameter-gradient stream): whoever orders "everything that reads parameters" behind an
+    event -- wait_pending_sgd -- orders these too.  (A side section forked BEFORE the first trainable op of a forward
+    pass would otherwise run its trainable conv -- a stage's downsample -- without the wait the compute stream made.)"""
+    idx = device.index if device.index is not None else _cur_device()
+    lst = _aux_streams.setdefault(idx, [])
+    if all(s is not stream for s in lst):
+        lst.append(stream)
 
 
 def optimizer_stream(device):
@@ -258,9 +292,9 @@ def wait_pending_sgd(device=None):
     for idx in idxs:
         evs = _pending_sgd.pop(idx, None)
         if evs:
-            st = torch.cuda.current_stream(idx)
-            for ev in evs:
-                st.wait_event(ev)
+            for st in [torch.cuda.current_stream(idx)] + _aux_streams.get(idx, []):
+                for ev in evs:
+                    st.wait_event(ev)
 
 
 def require_gpu(*tensors):
@@ -308,7 +342,7 @@ def workspace(nbytes, device):
         if buf is not None and _override is not None:
             _ws_retired.append(buf)
             want = max(want, 2 * buf.numel())
-        buf = torch.empty(want, dtype=torch.uint8, device=device)
+        buf = side_alloc(lambda: torch.empty(want, dtype=torch.uint8, device=device))
         _ws[key] = buf
     return buf
 

@@ -38,7 +38,7 @@ def nhwc(t):
 
 
 def empty_nhwc(shape, like):
-    return torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=CL)
+    return H.side_alloc(lambda: torch.empty(shape, dtype=torch.float32, device=like.device, memory_format=CL))
 
 
 def out_size(h, k, stride, pad, dil=1):
@@ -62,7 +62,7 @@ def _ws(desc, device):
 
 def split_w4(w, out=None):
     """The pre-split (bf16 hi / lo) image of a dense float tensor (cpm_split_w4): same shape / strides / bytes."""
-    out = torch.empty_like(w) if out is None else out
+    out = H.side_alloc(lambda: torch.empty_like(w)) if out is None else out
     assert w.numel() % 4 == 0 and out.numel() == w.numel()
     with H.guard(w.device):
         rc = H.lib().cpm_split_w4(H.ptr(w), H.ptr(out), H.ctypes.c_int64(w.numel()), H.stream())
@@ -90,7 +90,7 @@ def w4_of(w_in, w, cg):
         return t
     src = own.detach()
     if t is None or t.numel() != src.numel() or t.device != src.device:
-        t = torch.empty(src.numel(), dtype=torch.float32, device=src.device)
+        t = H.side_alloc(lambda: torch.empty(src.numel(), dtype=torch.float32, device=src.device))
     split_w4(src if src.dim() != 4 else _wmem(src), out=t)
     own._cpm_w4, own._cpm_w4_version, own._cpm_w4_ptr = t, own._version, own.data_ptr()
     return t
@@ -380,6 +380,7 @@ def wgrad_stream(device):
         else:
             t = torch.cuda.Stream(device=device, priority=int(os.environ.get("CPM_WGRAD_PRIO", "0")))
         st = _side[idx] = (t, t.cuda_stream)
+        H.register_aux_stream(device, t)
     return st[0]
 
 
@@ -398,9 +399,13 @@ def wgrad_stream(device):
 _FWD_SIDE = os.environ.get("CPM_FWD_SIDE", "1") != "0"
 
 
-def fwd_fork(t):
+_FWD_SIDE_MASK = int(os.environ.get("CPM_FWD_SIDE_MASK", "31"))     # debugging: which callers may fork (1 body downsample,
+#                                                                      2 FPN output convs, 4 RPN levels, 8 cls head, 16 RSM head)
+
+
+def fwd_fork(t, who=31):
     """the second stream waits for everything queued on the compute stream so far; False when the switch is off"""
-    if not (_FWD_SIDE and _SIDE_WGRAD and t.is_cuda):
+    if not (_FWD_SIDE and _SIDE_WGRAD and t.is_cuda and (_FWD_SIDE_MASK & who)):
         return False
     idx = t.device.index
     st = _side.get(idx)
@@ -412,8 +417,10 @@ def fwd_fork(t):
 
 
 def fwd_side(t):
-    """`with fwd_side(t):` -- ops inside are queued on the second stream (call fwd_fork first, fwd_join afterwards)"""
-    return H.use_stream(_side[t.device.index][1])
+    """`with fwd_side(t):` -- ops inside are queued on the second stream (call fwd_fork first, fwd_join afterwards);
+    the tensors they create come from that stream's allocator pool (H.side_alloc)"""
+    st = _side[t.device.index]
+    return H.use_stream(st[1], alloc_on=st[0])
 
 
 def fwd_join(t):
@@ -804,7 +811,7 @@ class _RPNHeadFn(Function):
         c = xs[0].shape[1]
         w4, w4c, w4b = w4_of(w, wm, c), w4_of(wc, wcm, c), w4_of(wb, wbm, c)
         # the shared conv on the coarser levels runs on the second stream beside the finest level's (fwd_fork)
-        forked = len(xs) > 1 and fwd_fork(xs[0])
+        forked = len(xs) > 1 and fwd_fork(xs[0], 4)
         ts = []
         for li, x in enumerate(xs):
             if forked and li > 0:
@@ -1300,14 +1307,17 @@ class _LayerChainFn(Function):
     def forward(ctx, x, plan):
         H.require_gpu(x)
         H.wait_pending_sgd(x.device)            # (the chain's parameters travel as raw pointers in its plan)
+        x_in = x
         x = nhwc(x) if x.dim() == 4 else x.contiguous()
+        _side_copies((x_in, x))
         n = x.shape[0]
         fwd_floats, _, ws_bytes = plan.sizes_for(n)
-        fbuf = torch.empty((fwd_floats,), dtype=torch.float32, device=x.device)
+        fbuf = H.side_alloc(lambda: torch.empty((fwd_floats,), dtype=torch.float32, device=x.device))
         if plan.flat_out:
-            y = torch.empty((n, plan.out_chw[0]), dtype=torch.float32, device=x.device)
+            y = H.side_alloc(lambda: torch.empty((n, plan.out_chw[0]), dtype=torch.float32, device=x.device))
         else:
-            y = torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device, memory_format=CL)
+            y = H.side_alloc(lambda: torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device,
+                                                 memory_format=CL))
         for p_ in plan.params:
             _note_use(p_)
         plan.refresh_w4()

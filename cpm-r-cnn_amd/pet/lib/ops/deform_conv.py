@@ -65,6 +65,7 @@ def _par_stream(device):
     if st is None:
         t = torch.cuda.Stream(device=device)
         st = _par_streams[idx] = (t, t.cuda_stream)
+        H.register_aux_stream(device, t)
     return st
 
 

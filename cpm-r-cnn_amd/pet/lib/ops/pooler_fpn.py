@@ -97,9 +97,9 @@ class _RoIAlignFPN(Function):
         B, C = feats[0].shape[:2]
         K = rois.shape[0]
         ph, pw = output_size
-        out = torch.empty((K, C, ph, pw), dtype=torch.float32, device=rois.device,
-                          memory_format=torch.channels_last)
-        levels = torch.empty((max(K, 1),), dtype=torch.int32, device=rois.device)
+        out, levels = H.side_alloc(lambda: (
+            torch.empty((K, C, ph, pw), dtype=torch.float32, device=rois.device, memory_format=torch.channels_last),
+            torch.empty((max(K, 1),), dtype=torch.int32, device=rois.device)))
         r = rois.contiguous().float()
         if H.in_side_section():
             # (conv.fwd_side) the kernel below is queued on the second stream, the tensors made here are compute-stream

@@ -45,7 +45,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         ops.mark_shared_grad(x)       # consumers: conv1, the downsample conv or conv3's residual -- all in-package
         # the downsample conv reads x only: its kernel runs on the second stream beside conv1 -> conv2 (ops.fwd_fork)
-        forked = self.downsample is not None and ops.fwd_fork(x)
+        forked = self.downsample is not None and ops.fwd_fork(x, 1)
         s, b = _affine(self.bn1)
         out = self.conv1(x, scale=s, shift=b, relu=True, sole_consumer=True)       # consumed by conv2 only
         s, b = _affine(self.bn2)

@@ -48,7 +48,7 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         ops.mark_shared_grad(x)       # consumers: conv1, the downsample conv or conv3's residual -- all in-package
         # the downsample conv reads x only: its kernel runs on the second stream beside conv1 -> conv2 (ops.fwd_fork)
-        forked = self.downsample is not None and ops.fwd_fork(x)
+        forked = self.downsample is not None and ops.fwd_fork(x, 1)
         s, b = _affine(self.bn1)
         # conv1's output feeds conv2 alone, or -- a DeformConvPack -- its sampled conv and its offset predictor, whose
         # data-gradient kernel (the last of the two to run) applies conv1's ReLU gate to their summed gradient

@@ -56,7 +56,7 @@ class fpn(nn.Module):
 
         def out_conv(conv, t, last):
             nonlocal sided
-            if not last and ops.fwd_fork(t):
+            if not last and ops.fwd_fork(t, 2):
                 sided = True
                 with ops.fwd_side(t):
                     return conv(t)

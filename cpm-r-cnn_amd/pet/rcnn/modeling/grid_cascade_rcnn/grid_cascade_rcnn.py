@@ -234,7 +234,7 @@ class GridCascadeRCNN(nn.Module):
         # stage's convolutions on ~100 RoIs (ops.fwd_fork); the loss -- framework ops, which follow torch's current
         # stream -- is formed behind the join at the end.  The RSM head does the same beside the last grid stage.
         loss = {}
-        cls_forked = ops.fwd_fork(features[0])
+        cls_forked = ops.fwd_fork(features[0], 8)
         if cls_forked:
             with ops.fwd_side(features[0]):
                 cls_logits = _head_logits(self.Head_cls, self.Output_cls, features, _capacity_rows(sample))
@@ -315,7 +315,7 @@ class GridCascadeRCNN(nn.Module):
             self._count_reads[-1].start(counts_all)
         result = _LazyViews(self, rs, sizes)
         self._pending = result
-        forked = ops.fwd_fork(features[0])
+        forked = ops.fwd_fork(features[0], 16)
         if forked:
             with ops.fwd_side(features[0]):
                 logits = _head_logits(self.Head_rescore, self.Output_rescore, features, _capacity_rows(rs))

@@ -39,7 +39,7 @@ class RPNHead(nn.Module):
         # over each level's map) become one launch that also applies this conv's ReLU gate (ops.conv._RPNPredFn)
         # the shared conv on the coarser levels runs on the second stream beside the finest level's (ops.fwd_fork)
         ts = []
-        forked = len(x) > 1 and ops.fwd_fork(x[0])
+        forked = len(x) > 1 and ops.fwd_fork(x[0], 4)
         for li, feature in enumerate(x):
             if forked and li > 0:
                 with ops.fwd_side(feature):

@@ -102,3 +102,48 @@ def test_x101_dcn_full_size_training_step(math):
     finally:
         _hip.set_conv_math(prev)
     assert len(losses) == 2
+
+
+def test_x101_body_forward_repeats_with_side_sections(deterministic_reductions):
+    """The forward side sections (ops.fwd_fork / fwd_side / fwd_join) queue a branch's kernels on the second stream,
+    forked from the compute stream some way back.  A tensor such an op creates must not come out of the compute
+    stream's allocator pool: that pool may hand out a block whose previous owner -- a bottleneck's conv1 output, dropped
+    when conv2 returned -- compute-stream kernels behind the fork point are still reading (round 5: the X-101 body's
+    layer1.0 read garbage whenever the pool offered that block; R-50 never hit it).  H.side_alloc takes them from the
+    second stream's pool.  Held here: the X-101-64x4d-DCN body at full size (bs = 1), forward repeated without and with
+    autograd -- immediate frees in the first two -- gives the SAME C2..C5 every time (ordered reductions: bit for bit),
+    equal to the run with the side sections switched off."""
+    import __graft_entry__ as entry
+    entry.ensure_built()
+    from bench import Trainer, calibrate_frozen_affine, synthetic_batch
+    from pet.lib.ops import _hip, conv as C
+    from pet.rcnn.core import config
+    device = torch.device("cuda", 0)
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    try:
+        tr = Trainer(device, body="x101dcn", hold_offsets=True)
+        images, _ = synthetic_batch(1, 800, 1333, 16, 1234, device)
+        cal, _ = synthetic_batch(1, 800, 1333, 1, 4321, device)
+        calibrate_frozen_affine(tr.model, cal.tensors)
+        body = tr.model.Conv_Body
+        assert C._FWD_SIDE and C._SIDE_WGRAD
+        runs = []
+        for rep in range(4):
+            with torch.set_grad_enabled(rep >= 2):
+                runs.append([t.detach().clone() for t in body(images.tensors)])
+            torch.cuda.synchronize()
+        C._FWD_SIDE = False
+        try:
+            with torch.no_grad():
+                plain = [t.detach().clone() for t in body(images.tensors)]
+        finally:
+            C._FWD_SIDE = True
+        for rep, outs in enumerate(runs):
+            for lvl, (a, b) in enumerate(zip(outs, plain)):
+                assert torch.equal(a, b), "repetition %d, C%d: max diff %g of %g" % (
+                    rep, lvl + 2, float((a - b).abs().max()), float(b.abs().max()))
+    finally:
+        _hip.set_conv_math(prev)
+        config.reset_cfg()
+        torch.cuda.empty_cache()
