@@ -124,8 +124,10 @@ class Trainer(object):
     """The reference's loop body (tools/rcnn/train_net.py:62-78) over the HIP model."""
 
     def __init__(self, device, seed_weights=0, layers=(3, 4, 6, 3), body="resnet", chunks=8, hold_offsets=False,
-                 offset_bias_px=0.0):
-        """hold_offsets (x101dcn): the offset predictors of the deformable convs (DeformConvPack.conv_offset, zero-
+                 offset_bias_px=0.0, lr_scale=1.0):
+        """lr_scale: SOLVER.BASE_LR of the yaml (0.02, written for 16 images per step) times this factor -- the linear
+        scaling rule for a job with fewer images per step (lr_scale = images / 16).
+        hold_offsets (x101dcn): the offset predictors of the deformable convs (DeformConvPack.conv_offset, zero-
         initialised by the reference: deform_conv.py:497-498) keep their initial value -- a parameter group of their own
         with lr_scale 0; their gradients are still computed.  offset_bias_px > 0: their biases are drawn from
         U(-px, +px) first (offsets of a trained model's size, constant per tap)."""
@@ -143,6 +145,8 @@ class Trainer(object):
             config.merge_cfg_from_list(X101_DCN_OPTS)
         else:
             config.merge_cfg_from_list(["BACKBONE.RESNET.LAYERS", tuple(layers)])
+        if lr_scale != 1.0:
+            config.merge_cfg_from_list(["SOLVER.BASE_LR", 0.02 * lr_scale])
         self.cfg = config.cfg
         torch.manual_seed(seed_weights)                       # identical weights on every rank
         model = Generalized_RCNN(is_train=True)
@@ -562,10 +566,13 @@ def main():
     layers = tuple(int(x) for x in a.layers.split(","))
     chunk_list = [max(1, int(c)) for c in str(a.chunks).split(",") if c.strip()]
     a.chunks = chunk_list[0]
-    # (--body x101dcn as the headline: the offset predictors are held at the reference's zero initialisation, as in the
-    # X-101 leg of the default run -- see config.other_bodies; CPM_BENCH_HOLD_OFFSETS=0 trains them on the noise)
+    # (--body x101dcn as the headline: the offset predictors train from the reference's zero initialisation at the
+    # linearly scaled learning rate, as in the third X-101 leg of the default run -- see config.other_bodies;
+    # CPM_BENCH_HOLD_OFFSETS=1 holds them at zero)
+    x101 = a.body == "x101dcn"
     trainer = Trainer(device, layers=layers, body=a.body, chunks=a.chunks,
-                      hold_offsets=a.body == "x101dcn" and os.environ.get("CPM_BENCH_HOLD_OFFSETS", "1") != "0")
+                      hold_offsets=x101 and os.environ.get("CPM_BENCH_HOLD_OFFSETS", "0") == "1",
+                      lr_scale=min(1.0, a.batch * world / 16.0) if x101 else 1.0)
     images, targets = synthetic_batch(a.batch, a.height, a.width, 16, 1234 + rank, device)
     cal_img, _ = synthetic_batch(a.batch, a.height, a.width, 1, 4321, device)     # same on every rank
     calibrate_frozen_affine(trainer.model, cal_img.tensors)
@@ -759,17 +766,21 @@ def main():
         # BASELINE configs #4 / #5 on one GPU, in the headline arithmetic: a fresh model each, a fixed seed, LEG_WARMUP
         # untimed + LEG_STEPS timed steps, RoI counts of every timed step on record.
         # Config #5 in three offset regimes.  The reference zero-initialises every offset predictor
-        # (deform_conv.py:497-498) and trains it from a pre-trained body on real images: offsets start at 0 and stay
-        # within a few pixels.  SGD on noise images with random labels instead drives the untrained predictors to tens
-        # of pixels within ten steps (profiles/round4_x101_offset_stats.txt), a regime no trained model shows -- so the
-        # leg is timed (a) with the predictors held at their zero initialisation (lr_scale 0 for conv_offset.*; their
-        # gradients are still computed), (b) held at offsets of a trained model's size (biases ~ U(-1.5, 1.5) px), and
-        # (c) as before, predictors trained on the noise, with the offset statistics of each beside its number.
+        # (deform_conv.py:497-498) and trains it: offsets start at 0 and stay within a few pixels.  The leg is timed
+        # (a) with the predictors held at their zero initialisation (lr_scale 0 for conv_offset.*; their gradients are
+        # still computed), (b) held at constant offsets of a trained model's size (biases ~ U(-1.5, 1.5) px), and (c) as
+        # the reference runs it: predictors trained by SGD from zero, with the offset statistics of each beside its
+        # number.  One image per step, so the yaml's learning rate (written for 16 images) is scaled by 1/16, the
+        # linear rule: at the unscaled 0.02 a randomly initialised X-101 on one noise image diverges within five steps
+        # in regime (b) and drives the predictors to tens of pixels in (c) (tools/probes/round5/x101_trajectory.py;
+        # DESIGN.md 8.7) -- dynamics of the learning rate, not of the kernels: the step's gradient agrees with finite
+        # differences in both regimes (tools/probes/round5/x101_fd_check.py).
         other_bodies = {}
         legs = [("R-101-FPN", dict(layers=(3, 4, 23, 3)), 2, 102),
-                ("X-101-64x4d-FPN-DCN", dict(body="x101dcn", hold_offsets=True), 1, 103),
-                ("X-101-64x4d-FPN-DCN offsets within 1.5 px", dict(body="x101dcn", hold_offsets=True, offset_bias_px=1.5), 1, 103),
-                ("X-101-64x4d-FPN-DCN offsets after SGD on noise", dict(body="x101dcn"), 1, 103)]
+                ("X-101-64x4d-FPN-DCN", dict(body="x101dcn", hold_offsets=True, lr_scale=1 / 16.0), 1, 103),
+                ("X-101-64x4d-FPN-DCN offsets within 1.5 px",
+                 dict(body="x101dcn", hold_offsets=True, offset_bias_px=1.5, lr_scale=1 / 16.0), 1, 103),
+                ("X-101-64x4d-FPN-DCN offsets trained from zero", dict(body="x101dcn", lr_scale=1 / 16.0), 1, 103)]
         for name, kw, bs, seed in legs:
             tr2 = Trainer(device, chunks=a.chunks, **kw)
             im2, tg2 = synthetic_batch(bs, a.height, a.width, 16, 1234, device)
@@ -781,7 +792,8 @@ def main():
                 rec["offset_predictors"] = ("held at the reference's zero initialisation (lr_scale 0)" if kw.get("hold_offsets")
                                             and not kw.get("offset_bias_px") else
                                             "held at biases ~ U(-1.5, 1.5) px (lr_scale 0)" if kw.get("hold_offsets") else
-                                            "trained by SGD on the synthetic noise batch")
+                                            "trained by SGD from the reference's zero initialisation")
+                rec["base_lr"] = 0.02 * kw["lr_scale"]
                 rec["offsets_after_the_timed_steps"] = offset_statistics(tr2, im2, tg2)
             other_bodies[name] = rec
             tr2.reducer.close()
