@@ -392,10 +392,16 @@ def wgrad_stream(device):
 # stream (the one the weight gradients use in backward, idle in forward); `fwd_join(t)` makes the compute stream wait
 # for them before their consumer is queued.  Only the KERNELS move: torch's current stream is untouched, so the autograd
 # nodes belong to the compute stream and the backward pass is what it was (in-place gradient accumulators, gradient
-# sinks and the weight-gradient fork / join assume one compute stream there); tensors allocated inside a side section
-# are compute-stream blocks to the allocator: an op that creates one it does NOT return or save (RoIAlign's level
-# indices, a layout copy) parks it with H.keep() until the join, and an op that copies an input on the compute stream
-# inside a section orders the side stream behind the copy (H.fork).  Results are bit-identical with the switch on or off.
+# sinks and the weight-gradient fork / join assume one compute stream there).
+# THE RULE for code that can run inside a side section (three live bugs came from breaking it):
+#  * it creates tensors only through H.side_alloc(): the block then comes from the SECOND stream's allocator pool and
+#    has the compute stream recorded on it.  A plain torch.empty would ask the compute stream's pool, which may hand out
+#    a block that compute-stream kernels queued behind the fork point are still reading;
+#  * a tensor it creates and does NOT return or save (RoIAlign's level indices, a layout copy) is parked with H.keep()
+#    until the join;
+#  * a copy of an input made on the compute stream inside a section (a weight that is not KRSC in memory) goes through
+#    _side_copies(): the side stream is ordered behind the copy and the copy is parked.
+# Results are bit-identical with the switch on or off.
 _FWD_SIDE = os.environ.get("CPM_FWD_SIDE", "1") != "0"
 
 
