@@ -388,6 +388,74 @@ __global__ __launch_bounds__(256) void l2_pairs_kernel(const float2* __restrict_
   if (threadIdx.x == 0) *loss = s_red[0] * inv;
 }
 
+// F.cross_entropy(logits [R, C], labels [R], reduction = mean, ignore_index) -- log_softmax + nll_loss -- as ONE launch
+// for value and gradient (the cls and RSM heads' losses, grid_cascade_rcnn/loss.py:103-112): the framework formulation is
+// two launches forward and two backward per head, all four queued where the device waits for the host (the end of the
+// forward pass, the start of the backward pass).  A wave per row, lanes over the classes, four rows per workgroup
+// (a row is one dependent chain of a load, two cross-lane reductions, an exp and a log: one workgroup walking 1024
+// rows took 0.3 ms).  Every workgroup counts the valid rows itself (R labels from L2); the row losses go to
+// `row_loss` and the workgroup that arrives last (ticket) sums them in a fixed order: the same bits every run.
+// Rows whose label is ignore_index add nothing and get a zero gradient; the mean is over the others.
+__device__ __forceinline__ float ce_wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float ce_wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float ce_block_sum(float v, float* s_red) {     // 256 threads, fixed order
+  v = ce_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__global__ __launch_bounds__(256) void softmax_ce_kernel(const float* __restrict__ x, const int64_t* __restrict__ labels,
+                                                         int R, int C, int64_t ignore_index, float* __restrict__ loss,
+                                                         float* __restrict__ grad, float* __restrict__ row_loss,
+                                                         int* __restrict__ ticket) {
+  __shared__ float s_red[4];
+  __shared__ int s_last;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float cnt = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) cnt += labels[r] != ignore_index ? 1.f : 0.f;
+  const float n = ce_block_sum(cnt, s_red);
+  const float inv = n > 0.f ? 1.f / n : 0.f;
+  const int r = blockIdx.x * 4 + wave;
+  if (r < R) {
+    const int64_t lab = labels[r];
+    const float* xr = x + (size_t)r * C;
+    float* gr = grad + (size_t)r * C;
+    if (lab == ignore_index) {                               // (wave-uniform)
+      for (int c = lane; c < C; c += 64) gr[c] = 0.f;
+      if (lane == 0) row_loss[r] = 0.f;
+    } else {
+      float m = -INFINITY;
+      for (int c = lane; c < C; c += 64) m = fmaxf(m, xr[c]);
+      m = ce_wave_max(m);
+      float e = 0.f;
+      for (int c = lane; c < C; c += 64) e += expf(xr[c] - m);
+      const float lse = m + logf(ce_wave_sum(e));
+      for (int c = lane; c < C; c += 64) gr[c] = (expf(xr[c] - lse) - (c == (int)lab ? 1.f : 0.f)) * inv;
+      if (lane == 0) row_loss[r] = lse - xr[lab];
+    }
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(ticket, 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  float part = 0.f;
+  for (int i = threadIdx.x; i < R; i += 256) part += __builtin_nontemporal_load(row_loss + i);
+  const float t = ce_block_sum(part, s_red);
+  if (threadIdx.x == 0) {
+    *loss = t / n;                                           // no valid row: 0 / 0, as the framework's mean
+    *ticket = 0;                                             // ready for the next call
+  }
+}
+
 int fill_geom(GridGeom& G, int points, int map_size, const int* sub_xy, const int64_t* strides) {
   if (points <= 0 || points > MAX_POINTS) return -1;
   int gs = 1;
@@ -652,4 +720,13 @@ CPM_EXPORT int cpm_l2_loss_pairs(const float* x, const float* iou, const float* 
   hipLaunchKernelGGL(l2_pairs_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float2*)x, iou,
                      (const float2*)target, R, loss, (float2*)grad);
   return cpm::check_launch("l2_loss_pairs");
+}
+
+CPM_EXPORT int cpm_softmax_ce(const float* logits, const int64_t* labels, int R, int C, int64_t ignore_index,
+                              float* loss, float* grad, float* row_loss, int* ticket, void* stream) {
+  CPM_REQUIRE(R >= 1 && C >= 1, "at least one row and one class");
+  CPM_REQUIRE(logits && labels && loss && grad && row_loss && ticket, "null pointer");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                     R, C, ignore_index, loss, grad, row_loss, ticket);
+  return cpm::check_launch("softmax_ce");
 }

@@ -88,3 +88,34 @@ CPM_EXPORT int cpm_stream_destroy(void* stream) {
   if (stream && hipStreamDestroy((hipStream_t)stream) != hipSuccess) return cpm::check_launch("stream destroy");
   return CPM_OK;
 }
+
+// RoI counts to the host without a copy command: the kernel stores the n counts and then a sequence number into PINNED
+// host memory that the device has mapped (cpm_host_device_pointer), with system-scope release in between; the host
+// polls the sequence word (pet/lib/ops/roi_lists.py: Counts).  A copy + event + hipEventSynchronize costs the host a
+// blit kernel, an event and a wake-up per read (60-90 us from the counts' kernel to the host's next launch, three times
+// per training step); the stores land a few microseconds behind the kernel.
+namespace {
+__global__ void publish_counts_kernel(const int32_t* __restrict__ src, int n, int32_t* __restrict__ dst, int32_t seq) {
+  const int i = threadIdx.x;
+  if (i < n) __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  if (i == 0) {
+    __threadfence_system();
+    __hip_atomic_store(dst + n, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace
+
+CPM_EXPORT int cpm_host_device_pointer(void* host_pinned, void** out) {
+  CPM_REQUIRE(host_pinned && out, "null pointer");
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, host_pinned, 0) != hipSuccess || !d) return cpm::check_launch("hipHostGetDevicePointer");
+  *out = d;
+  return CPM_OK;
+}
+
+CPM_EXPORT int cpm_publish_counts(const int32_t* counts, int n, int32_t* host_mapped, int32_t seq, void* stream) {
+  CPM_REQUIRE(counts && host_mapped && n >= 1 && n <= 255, "1..255 counts, non-null pointers");
+  hipLaunchKernelGGL(publish_counts_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, n, host_mapped, seq);
+  return cpm::check_launch("publish_counts");
+}

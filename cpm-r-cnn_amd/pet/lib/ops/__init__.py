@@ -4,7 +4,7 @@ from .nms import nms, ml_nms, nms_segments, soft_nms, ml_soft_nms, soft_nms_segm
 from .roi_align import roi_align, ROIAlign
 from .pooler_fpn import roi_align_fpn, roi_backward_group
 from .affine import AffineChannel2d
-from .losses import smooth_l1_loss, l2_loss, l2_loss_nosync, l2_loss_fused
+from .losses import smooth_l1_loss, l2_loss, l2_loss_nosync, l2_loss_fused, cross_entropy_fused
 from .modules import Conv2d, Linear, ConvTranspose2d, GroupNorm, ReLU
 from .conv import conv2d, linear, conv_transpose2d, group_norm, stem_forward, mark_shared_grad, rpn_predictors
 from .conv import fwd_fork, fwd_side, fwd_join, rpn_head, set_rpn_sample, mask_compact

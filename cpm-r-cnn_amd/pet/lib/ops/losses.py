@@ -1,5 +1,9 @@
 """Loss helpers on the hot path (counterparts of pet/lib/ops/smooth_l1_loss.py:4-28, l2_loss.py:4-11)."""
+import os
+
 import torch
+
+_FUSED_CE = os.environ.get("CPM_FUSED_CE", "1") != "0"
 
 
 def smooth_l1_loss(x, target, beta=1. / 9, reduction="none"):
@@ -70,3 +74,45 @@ def l2_loss_fused(x, target=None, iou=None):
     if iou is not None:
         iou = iou.detach().contiguous()
     return _L2PairsFn.apply(x, iou, target)
+
+
+_ce_tickets = {}
+
+
+class _SoftmaxCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, ignore_index):
+        import ctypes
+        from . import _hip as H
+        H.require_gpu(logits, labels)
+        x = logits.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x)
+        rows = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+        key = (x.device.index, H.stream_raw())
+        ticket = _ce_tickets.get(key)
+        if ticket is None:                   # one per (device, stream): calls that share a ticket must be ordered
+            ticket = _ce_tickets[key] = torch.zeros((1,), dtype=torch.int32, device=x.device)
+        with H.guard(x.device):
+            rc = H.lib().cpm_softmax_ce(H.ptr(x), H.ptr(labels), x.shape[0], x.shape[1], ctypes.c_int64(ignore_index),
+                                        H.ptr(loss), H.ptr(grad), H.ptr(rows), H.ptr(ticket), H.stream())
+        H.check(rc, "softmax_ce")
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        grad, = ctx.saved_tensors
+        from . import _hip as H
+        return H.scaled_by(grad, g), None, None
+
+
+def cross_entropy_fused(logits, labels, ignore_index=-100):
+    """F.cross_entropy(logits, labels) (mean over the rows not labelled ignore_index) as ONE launch for value and
+    gradient (cpm_softmax_ce) instead of log_softmax + nll_loss forward and their two backward kernels: the cls and RSM
+    heads' losses sit at the very end of the forward pass and the very start of the backward pass, where the device
+    waits for the host.  Anything but [R >= 1, C] fp32 logits with int64 labels on the GPU goes to the framework."""
+    if (not _FUSED_CE or logits.dim() != 2 or logits.shape[0] < 1 or logits.dtype != torch.float32 or not logits.is_cuda
+            or labels.dtype != torch.int64 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]):
+        return torch.nn.functional.cross_entropy(logits, labels, ignore_index=ignore_index)
+    return _SoftmaxCEFn.apply(logits, labels.detach().contiguous(), int(ignore_index))

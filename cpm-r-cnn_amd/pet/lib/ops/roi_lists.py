@@ -7,6 +7,7 @@ proposal NMS and the heads (pet/rcnn/modeling/rpn/inference.py:101-196, grid_cas
 pet/rcnn/utils/misc.py:54-94, grid_cascade_rcnn.py:231-245) becomes one launch per list; the host only reads the
 counts back (`Counts.start` / `Counts.wait`) when it must size the next head launch."""
 import ctypes
+import os
 
 import torch
 
@@ -51,26 +52,64 @@ class RoIList(object):
         return getattr(self, name)[:self.total]
 
 
+_COUNTS_MAPPED = os.environ.get("CPM_COUNTS_MAPPED", "1") != "0"
+
+
 class Counts(object):
-    """One pinned staging buffer per call site: device counts -> host with a single copy and an event."""
+    """Device counts -> host, one per call site.  Default: ONE small launch stores the counts and then a sequence number
+    into pinned host memory the device has mapped (cpm_publish_counts) and the host polls the sequence word -- no copy
+    command, no event wait, no wake-up.  An event is recorded behind the launch all the same: a poll that has not seen
+    the word after two seconds waits for the event instead (visibility is then the runtime's business).
+    CPM_COUNTS_MAPPED=0: a copy into a pinned staging buffer and an event."""
 
     def __init__(self):
         self._pin = None
         self._event = None
+        self._np = None
+        self._dptr = None
+        self._seq = 0
+
+    def _alloc(self, n):
+        self._pin = torch.zeros(max(n + 1, 64), dtype=torch.int32).pin_memory()
+        self._np = self._pin.numpy()
+        self._dptr = None
+        if _COUNTS_MAPPED:
+            out = ctypes.c_void_p()
+            rc = H.lib().cpm_host_device_pointer(ctypes.c_void_p(self._pin.data_ptr()), ctypes.byref(out))
+            self._dptr = out if rc == 0 and out.value else None      # (not mapped on this system: the copy path)
 
     def start(self, dev_counts):
         n = dev_counts.numel()
-        if self._pin is None or self._pin.numel() < n:
-            self._pin = torch.empty(max(n, 64), dtype=torch.int32).pin_memory()
-        self._view = self._pin[:n]
-        self._view.copy_(dev_counts, non_blocking=True)
+        if self._pin is None or self._pin.numel() < n + 1:
+            self._alloc(n)
+        self._n = n
         if self._event is None:
             self._event = torch.cuda.Event()
+        if self._dptr is not None and dev_counts.dtype == torch.int32 and dev_counts.is_contiguous() and n <= 255:
+            self._seq = (self._seq % 0x3fffffff) + 1
+            self._np[n] = 0
+            with H.guard(dev_counts.device):
+                rc = H.lib().cpm_publish_counts(H.ptr(dev_counts), n, self._dptr, self._seq, H.stream())
+            H.check(rc, "publish_counts")
+            self._polled = True
+        else:
+            self._pin[:n].copy_(dev_counts, non_blocking=True)
+            self._polled = False
         self._event.record()
 
     def wait(self):
+        if self._polled:
+            a, n, seq = self._np, self._n, self._seq
+            spins = 0
+            while a[n] != seq:
+                spins += 1
+                if not (spins & 0xfff) and self._event.query():
+                    # the launch is complete: whatever the stores' path, they are visible behind the event
+                    self._event.synchronize()
+                    break
+            return a[:n].tolist()
         self._event.synchronize()
-        return self._view.tolist()
+        return self._np[:self._n].tolist()
 
 
 def gt_pack(targets):

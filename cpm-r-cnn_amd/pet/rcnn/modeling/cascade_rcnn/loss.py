@@ -6,7 +6,7 @@ matched proposals of prepare_targets (before sampling) and paired with the logit
 import torch
 from torch.nn import functional as F
 
-from pet.lib.ops import l2_loss, smooth_l1_loss
+from pet.lib.ops import cross_entropy_fused, l2_loss, smooth_l1_loss
 from pet.rcnn.core.config import cfg
 from pet.rcnn.utils.balanced_positive_negative_sampler import BalancedPositiveNegativeSampler
 from pet.rcnn.utils.box_coder import BoxCoder
@@ -60,7 +60,7 @@ class CascadeRCNNLossComputation(object):
             raise RuntimeError("subsample needs to be called before")
         labels = cat([p.get_field("labels") for p in self._proposals], dim=0)
         regression_targets = cat([p.get_field("regression_targets") for p in self._proposals], dim=0)
-        classification_loss = F.cross_entropy(class_logits, labels)
+        classification_loss = cross_entropy_fused(class_logits, labels)
         pos = torch.nonzero(labels > 0).squeeze(1)
         if self.cls_agnostic_bbox_reg:
             map_inds = torch.tensor([4, 5, 6, 7], device=class_logits.device)

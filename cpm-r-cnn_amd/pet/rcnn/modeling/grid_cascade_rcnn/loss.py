@@ -109,7 +109,8 @@ class CLSLossComputation(object):
         labels = self._packed_labels
         if labels is None:
             labels = cat([p.get_field("labels") for p in self._proposals], dim=0)
-        return F.cross_entropy(class_logits, labels)
+        # value and gradient from one launch on the GPU (cpm_softmax_ce); F.cross_entropy elsewhere
+        return ops.cross_entropy_fused(class_logits, labels)
 
 
 def grid_targets(pos_bboxes, pos_gt_bboxes, mapping_ratio, grid_points, map_size, radius, sub_regions):

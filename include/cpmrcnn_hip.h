@@ -520,6 +520,23 @@ int cpm_rpn_labels(const int64_t* matched, const uint8_t* visible, int64_t total
 int cpm_l2_loss_pairs(const float* x, const float* iou, const float* target, int R, float* loss, float* grad,
                       void* stream);
 
+/* RoI counts to the host without a copy command (the training step's three count reads, SURVEY 8f-1: the reference
+ * reads its counts through nonzero() / .item() on every BoxList operation).  cpm_host_device_pointer: the device's
+ * address of a pinned host allocation.  cpm_publish_counts: one launch stores counts[0..n) and then `seq` at index n of
+ * the mapped buffer, system-scope release between; the host polls host_mapped[n] == seq. */
+int cpm_host_device_pointer(void* host_pinned, void** out);
+int cpm_publish_counts(const int32_t* counts, int n, int32_t* host_mapped, int32_t seq, void* stream);
+
+/* Classification loss of the cls and RSM heads: F.cross_entropy(logits [R, C], labels [R]) with the default mean
+ * reduction and ignore_index (CLSLossComputation.__call__, pet/rcnn/modeling/grid_cascade_rcnn/loss.py:103-112;
+ * cascade_rcnn/loss.py:63) = log_softmax + nll_loss.  *loss and grad [R, C] (d loss / d logits) from one launch; rows
+ * labelled ignore_index add nothing and get a zero gradient; labels outside [0, C) other than ignore_index are the
+ * caller's error (as in the framework: not checked on the device).  fp32, rows contiguous.  row_loss: R floats of
+ * scratch; ticket: one int that is ZERO before the first call and left zero by every call (calls that share it must
+ * be ordered on one stream).  The sum over the rows is taken in a fixed order. */
+int cpm_softmax_ce(const float* logits, const int64_t* labels, int R, int C, int64_t ignore_index, float* loss,
+                   float* grad, float* row_loss, int* ticket, void* stream);
+
 /* ---- device-resident RoI lists of the training step -----------------------------------------
  * Packed lists with a fixed capacity and a per-image count ON THE DEVICE replace the reference's per-image BoxList
  * surgery (nonzero / boolean index / randperm / cat, each a launch and a device->host round trip).  Every call is one

@@ -363,3 +363,44 @@ def test_l2_loss_fused_equals_reference_formulation(R):
     (want * 3).backward()
     (got * 3).backward()
     np.testing.assert_allclose(xb.grad.cpu().numpy(), xa.grad.cpu().numpy(), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("R,C", [(1, 81), (5, 2), (64, 81), (1024, 81), (3001, 7), (40, 300)])
+def test_cross_entropy_fused_equals_the_framework_formulation(R, C):
+    """cpm_softmax_ce (value + gradient of the cls / RSM heads' loss in one launch) against F.cross_entropy -- the
+    reference's call (grid_cascade_rcnn/loss.py:103-112) -- in float64 and its autograd gradient; every third row carries
+    the ignore index, as the rows beyond a capacity-sized sample's count do."""
+    import torch.nn.functional as F
+    import pet.lib.ops as ops
+    g = torch.Generator().manual_seed(R * 1000 + C)
+    x = (torch.randn(R, C, generator=g) * 4).cuda()
+    lab = torch.randint(0, C, (R,), generator=g)
+    if R > 2:
+        lab[2::3] = -100
+    lab = lab.cuda()
+    xa = x.double().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    want = F.cross_entropy(xa, lab)
+    got = ops.cross_entropy_fused(xb, lab)
+    assert got.dtype == torch.float32 and got.dim() == 0
+    assert abs(float(got.detach()) - float(want.detach())) <= 2e-6 * abs(float(want.detach())) + 1e-7
+    (want * 0.5).backward()
+    (got * 0.5).backward()
+    ga, gb = xa.grad.cpu().numpy(), xb.grad.cpu().numpy()
+    assert np.abs(gb - ga).max() <= 2e-6 * np.abs(ga).max() + 1e-9
+    if R > 2:
+        assert not gb[2::3].any()
+    # the unit seed of backward_losses passes the stored gradient through untouched
+    from pet.lib.ops import _hip as H
+    xc = x.clone().requires_grad_(True)
+    torch.autograd.backward([ops.cross_entropy_fused(xc, lab)], [H.unit_seed(x.device)])
+    np.testing.assert_array_equal(xc.grad.cpu().numpy() * np.float32(0.5), gb)
+
+
+def test_cross_entropy_fused_with_no_valid_row_is_the_frameworks_nan_and_zero_gradient():
+    import pet.lib.ops as ops
+    x = torch.randn(6, 81).cuda().requires_grad_(True)
+    lab = torch.full((6,), -100, dtype=torch.int64).cuda()
+    got = ops.cross_entropy_fused(x, lab)
+    got.backward()
+    assert torch.isnan(got) and not x.grad.any()
