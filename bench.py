@@ -443,7 +443,55 @@ def hbm_kernel_rooflines(device, batch, h, w, rois_per_head):
     return res
 
 
-def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3), batch=2):
+def inference_leg(trainer, images, device, forwards=20, rank_cut=200):
+    """BASELINE config #1 on the GPU: Generalized_RCNN.forward in eval mode, one image per forward (the reference's
+    inference is per image: TEST.IMS_PER_GPU = 1) -- RPN test post-processing (1000 proposals), cls head, softmax,
+    score threshold, multi-label NMS 0.3, three grid stages refining the kept boxes, ISM, RSM -- on the trainer's current
+    weights.  A randomly initialised cls head scores every class ~1/81, under the yaml's threshold of 0.03: nothing would
+    reach the grid stages.  The threshold is therefore placed behind the `rank_cut`-th foreground score of the first
+    image (a trained model passes a few hundred candidates per image), and the same value goes to the CPU leg
+    (cpu_baseline: forward_only_config1).  Parity of this path: tests/test_gpu_fullsize_oracle.py."""
+    from pet.utils.data.structures.image_list import to_image_list
+    model = trainer.model
+    G = model.Grid_Cascade_RCNN
+    post = G.cls_post_processor
+    saved = post.score_thresh
+    model.eval()
+    try:
+        with torch.no_grad():
+            x0 = images.tensors[0:1]
+            feats = model._features(x0)
+            props, _ = model.RPN(to_image_list(x0), feats, None)
+            prob = torch.softmax(G.Output_cls(G.Head_cls(feats, props)), -1)[:, 1:].reshape(-1)
+            top = torch.sort(prob, descending=True)[0][:rank_cut + 1]
+            thr = float(0.5 * (top[rank_cut - 1] + top[rank_cut]))
+            if not (thr == thr) or thr <= 0.0:
+                return None
+            post.score_thresh = thr
+            b = images.tensors.shape[0]
+            dets = []
+            for i in range(3):
+                model(images.tensors[i % b:i % b + 1])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(forwards):
+                res = model(images.tensors[i % b:i % b + 1])
+                if i < b:
+                    dets.append(res)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / forwards
+            n_det = [len(r[0]) for r in dets]
+    finally:
+        post.score_thresh = saved
+        model.train()
+    return {"img_per_s": round(1.0 / dt, 2), "ms_per_image": round(1e3 * dt, 2), "forwards": forwards,
+            "score_thresh": thr, "score_thresh_rule": "behind the %d-th foreground class score of the first image" % rank_cut,
+            "detections_per_image": n_det,
+            "what": "BASELINE config #1 on the GPU: test-time forward, one 3x%dx%d image per forward: RPN 1000 proposals, "
+                    "cls head, multi-label NMS, 3 grid stages, ISM, RSM" % tuple(images.tensors.shape[2:])}
+
+
+def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3), batch=2, score_thresh=None):
     """oracle/cpu_pipeline.py on the host cores, a bounded sample of the SAME workload:
     (b) whole training iterations at this run's batch size -- backbone / FPN / RPN, proposal NMS, matching, sampling,
         cls head, three grid stages with rasterised targets and the grid decoder, ISM, RSM, backward; torch-CPU fp32
@@ -489,10 +537,13 @@ def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3), batch=2):
         n += 1
     dt = (time.time() - t0) / n
     sd = state(False)
-    P.infer_image(sd, images[:1], layers)
-    m, t1 = 0, time.time()
+    kw = {} if score_thresh is None else {"score_thresh": score_thresh}
+    P.infer_image(sd, images[:1], layers, **kw)
+    m, t1, n_det = 0, time.time(), []
     while m < batch or (time.time() - t1 < 6.0 and m < 3 * batch):
-        P.infer_image(sd, images[m % batch:m % batch + 1], layers)
+        det = P.infer_image(sd, images[m % batch:m % batch + 1], layers, **kw)
+        if m < batch:
+            n_det.append(int(len(det[0])))
         m += 1
     di = (time.time() - t1) / m
     return {"value": round(batch / dt, 4), "unit": "img/s", "cores": cores, "kind": "port",
@@ -502,7 +553,8 @@ def cpu_baseline(trainer, h, w, seed, layers=(3, 4, 6, 3), batch=2):
             "forward_only_config1": {"value": round(1.0 / di, 4), "unit": "img/s", "what": "BASELINE config #1: "
                                      "test-time forward, one image per forward (%d forwards after 1 warm-up, %.2f s "
                                      "each): RPN 1000 proposals, cls head, multi-label NMS, 3 grid stages, ISM, RSM"
-                                     % (m, di)}}
+                                     % (m, di), "score_thresh": score_thresh if score_thresh is not None else 0.03,
+                                     "detections_per_image": n_det}}
 
 
 def main():
@@ -511,6 +563,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-inference", action="store_true", help="skip the test-time forward leg (BASELINE config #1)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
@@ -803,8 +856,12 @@ def main():
     hbm = None
     if not a.no_roofline and rank == 0:
         hbm = hbm_kernel_rooflines(device, a.batch, a.height, a.width, counts.get("cls", 512 * a.batch))
+    infer = None
+    if not a.no_inference and rank == 0 and world == 1 and a.body == "resnet":
+        infer = inference_leg(trainer, images, device)
     if not a.no_cpu_baseline and rank == 0 and world == 1 and a.body == "resnet":
-        cpu = cpu_baseline(trainer, a.height, a.width, 99, layers, a.batch)   # (the scalar deformable-conv oracle is
+        cpu = cpu_baseline(trainer, a.height, a.width, 99, layers, a.batch,
+                           score_thresh=infer["score_thresh"] if infer else None)   # (the scalar deformable-conv oracle is
         #                                                              too slow to be a bounded sample for x101dcn)
 
     if rank == 0:
@@ -838,6 +895,7 @@ def main():
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "backend": a.backend,
                        **({"host_input": host_input} if host_input else {}),
                        **({"full_rois": full_rois} if full_rois else {}),
+                       **({"inference_config1": infer} if infer else {}),
                        **({"other_bodies": other_bodies} if other_bodies else {}),
                        "grad_allreduce_chunks": a.chunks, **({"chunk_sweep": chunk_sweep} if chunk_sweep else {}),
                        **({"comm": comm} if comm else {}),

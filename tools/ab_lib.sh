@@ -2,7 +2,7 @@
 # usage (GPU box): tools/ab_lib.sh BASE.so [bench args]: alternates the training bench between a saved build of the
 # library (CPM_LIB=BASE.so) and the in-tree one
 BASE=$1; shift
-F="--no-cpu-baseline --no-roofline --no-other-math --no-full-rois --steps 30 --warmup 8 $@"
+F="--no-cpu-baseline --no-inference --no-roofline --no-other-math --no-full-rois --steps 30 --warmup 8 $@"
 for i in 1 2 3; do
 for v in base new; do
 if [ $v = base ]; then export CPM_LIB=$BASE; else unset CPM_LIB; fi

@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   N=$(echo $C | cut -d' ' -f1)
-  CPM_WGRAD_STREAM=0 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_$N -o p -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-other-math --no-full-rois --no-other-bodies --steps 3 --warmup 2 > $R/gpurun_out/${TAG}_$N.log 2>&1
+  CPM_WGRAD_STREAM=0 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/${TAG}_$N -o p -- python3 $R/bench.py --no-cpu-baseline --no-inference --no-roofline --no-other-math --no-full-rois --no-other-bodies --steps 3 --warmup 2 > $R/gpurun_out/${TAG}_$N.log 2>&1
   echo "pass $N done"
 done
 cd $R
