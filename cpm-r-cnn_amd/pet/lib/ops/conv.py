@@ -1031,9 +1031,17 @@ def conv2d(x, w, scale=None, shift=None, residual=None, stride=1, pad=0, dil=1, 
     sole_consumer: exactly one consumer (bottleneck conv1 -> conv2 -> conv3); gate_by_consumers: several (a bottleneck's
     output: the next block's conv1, its downsample conv or residual add, an FPN lateral)."""
     tag = None
+    if not torch.is_grad_enabled():
+        # inference: no autograd node, no context (the test-time forward is bound by the host: ~100 conv calls per image)
+        H.require_gpu(x, w, scale, shift, residual)
+        xn, wm = nhwc(x), _wmem(w)
+        res = nhwc(residual) if residual is not None else None
+        _side_copies((x, xn), (w, wm), (residual, res))
+        return conv2d_forward(xn, wm, scale, shift, res, res_mode, relu, stride, pad, dil, groups,
+                              w4=w4_of(w, wm, xn.shape[1] // groups))
     if gate_by_consumers and not _GATE_BY_CONSUMERS:
         gate_by_consumers = False
-    if relu and torch.is_grad_enabled() and ((sole_consumer and residual is None) or gate_by_consumers):
+    if relu and ((sole_consumer and residual is None) or gate_by_consumers):
         tag = {"applied": False}
     y = _ConvFn.apply(x, w, scale, shift, residual, stride, pad, dil, groups, relu, res_mode, tag)
     if tag is not None:

@@ -54,6 +54,9 @@ class CLSPostProcessor(nn.Module):
         return boxlist_ml_nms(boxlist[keep], self.nms)
 
 
+_DECODE_CONSTS = {}
+
+
 def first_argmax(flat):
     """max over dim 1 and the FIRST index attaining it (deterministic on the GPU)."""
     mx = flat.max(dim=1, keepdim=True)[0]
@@ -70,7 +73,20 @@ def decode_grid_boxes(det_bboxes, grid_pred, mapping_ratio, grid_points, sub_reg
     assert h == w == half and c == grid_points
     prob = grid_pred.sigmoid().reshape(R * c, h * w)
     pred_scores, pos = first_argmax(prob)
-    sub = torch.as_tensor(sub_regions, dtype=torch.int64, device=grid_pred.device)
+    # the window origins and the four sides' point indices live on the device (built once per geometry): a Python list
+    # used as an index or handed to as_tensor is a blocking host-to-device copy per use -- seven per stage, 0.6 ms each
+    # behind a busy stream (the test-time forward spent 4 of its 11 ms there)
+    key = (grid_pred.device, grid_points, tuple(map(tuple, sub_regions)) if not torch.is_tensor(sub_regions) else id(sub_regions))
+    cached = _DECODE_CONSTS.get(key)
+    if cached is None:
+        dev = grid_pred.device
+        cached = _DECODE_CONSTS[key] = (
+            torch.as_tensor(sub_regions, dtype=torch.int64, device=dev),
+            torch.as_tensor(list(range(gs)), dtype=torch.int64, device=dev),
+            torch.as_tensor([i * gs for i in range(gs)], dtype=torch.int64, device=dev),
+            torch.as_tensor([grid_points - gs + i for i in range(gs)], dtype=torch.int64, device=dev),
+            torch.as_tensor([(i + 1) * gs - 1 for i in range(gs)], dtype=torch.int64, device=dev))
+    sub, x1_inds, y1_inds, x2_inds, y2_inds = cached
     xs = (pos % w).view(R, c) + sub[:, 0][None]
     ys = torch.div(pos, w, rounding_mode="floor").view(R, c) + sub[:, 1][None]
     pred_scores = pred_scores.view(R, c)
@@ -80,10 +96,6 @@ def decode_grid_boxes(det_bboxes, grid_pred, mapping_ratio, grid_points, sub_reg
     y1 = det_bboxes[:, 1, None] - mapping_ratio * (heights / 2)
     abs_xs = (xs.float() + 0.5) / (2 * w) * (1 + mapping_ratio) * widths + x1
     abs_ys = (ys.float() + 0.5) / (2 * h) * (1 + mapping_ratio) * heights + y1
-    x1_inds = list(range(gs))
-    y1_inds = [i * gs for i in range(gs)]
-    x2_inds = [grid_points - gs + i for i in range(gs)]
-    y2_inds = [(i + 1) * gs - 1 for i in range(gs)]
 
     def vote(coord, inds):
         s = pred_scores[:, inds]

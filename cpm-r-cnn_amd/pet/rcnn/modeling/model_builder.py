@@ -107,6 +107,63 @@ class Generalized_RCNN(nn.Module):
         self._graphed[tuple(sample.shape)] = graphed
         return graphed
 
+    # ---- the static part of the TEST-time forward as a hipGraph --------------------------------------------------------
+    # One image per forward (the reference's inference): ~100 convolutions of backbone, FPN and RPN head issued by Python
+    # take the host 4-5 ms, the device ~2.  For every padded input shape seen (up to CPM_EVAL_GRAPH_SHAPES, 8) the static
+    # part is captured once -- two eager warm-up runs, then a capture on the same tensors -- and replayed afterwards: the
+    # input is copied into the captured buffer, the outputs are the captured buffers (valid until the next replay of
+    # that shape; box_net hands them out, so it stays eager).  The captured kernels read parameters through their
+    # addresses, but the bf16x3 weight images of parameters OUTSIDE a flat optimizer are re-split by Python when a
+    # parameter changes (ops.conv.w4_of): a graph is therefore keyed by the parameters' version counters too and
+    # re-captured when they move.  CPM_EVAL_GRAPH=0: eager.
+    def _eval_static(self, x):
+        import os
+        import torch
+        if os.environ.get("CPM_EVAL_GRAPH", "1") == "0" or not x.is_cuda or torch.is_grad_enabled() \
+                or torch.cuda.is_current_stream_capturing():
+            return None
+        from pet.lib.ops import _hip as _H, conv as _conv
+        graphs = self.__dict__.setdefault("_eval_graphs", {})
+        params = self.__dict__.get("_eval_graph_params")
+        if params is None:
+            params = self.__dict__["_eval_graph_params"] = [
+                p for p in list(self.Conv_Body.parameters()) + list(self.RPN.head.parameters()) +
+                (list(self.Conv_Body_FPN.parameters()) if cfg.MODEL.FPN_ON else [])]
+        epoch = 0
+        for p_ in params:
+            epoch += p_._version
+        key = (tuple(x.shape), x.device.index, _H.get_conv_math(), _H.deterministic(), x.is_contiguous())
+        rec = graphs.get(key)
+        if rec is not None and rec[0] != epoch:
+            rec = None
+        if rec is False:
+            return None
+        if rec is None:
+            if len(graphs) >= int(os.environ.get("CPM_EVAL_GRAPH_SHAPES", "8")) and key not in graphs:
+                return None
+            part = self._static_part()
+            static_in = x.detach().clone()
+            try:
+                _conv.wait_pending_wt(x.device)
+                _H.wait_pending_sgd(x.device)
+                for _ in range(2):                       # warm-up: weight images, plans, workspaces, allocator blocks
+                    part(static_in)
+                torch.cuda.current_stream(x.device).synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    outs = part(static_in)
+            except Exception as e:                       # (a capture that cannot be made: stay eager for this shape)
+                import warnings
+                warnings.warn("test-time hipGraph of the static part not captured for %s: %s" % (key[0], e))
+                graphs[key] = False
+                return None
+            rec = graphs[key] = (epoch, g, static_in, outs)
+        _, g, static_in, outs = rec
+        static_in.copy_(x)
+        g.replay()
+        self.__dict__["_eval_graphs_last"] = outs
+        return outs
+
     def forward(self, images, targets=None):
         if self.training and targets is None:
             raise ValueError("In training mode, targets should be passed")
@@ -123,6 +180,12 @@ class Generalized_RCNN(nn.Module):
             # the replayed outputs are fresh tensor objects: the RoI heads' RoIAlign calls share ONE gradient
             # accumulator per level again (ops.mark_shared_grad, as FPN.forward does for the eager tensors)
             feats = [ops.mark_shared_grad(o) for o in outs[:nf]]
+            proposals, proposal_losses = self.RPN(images, feats, targets,
+                                                  head_out=(list(outs[nf:nf + nl]), list(outs[nf + nl:])))
+        elif not self.training and not cfg.MODEL.RPN_ONLY and self._eval_static(images.tensors) is not None:
+            outs = self._eval_graphs_last
+            nf = nl = len(outs) // 3
+            feats = list(outs[:nf])
             proposals, proposal_losses = self.RPN(images, feats, targets,
                                                   head_out=(list(outs[nf:nf + nl]), list(outs[nf + nl:])))
         else:

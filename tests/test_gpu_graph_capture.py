@@ -67,3 +67,74 @@ def test_gradients_left_by_a_capture_are_cleared_by_the_next_zero_grad():
         assert bool(torch.isfinite(opt.flat_param).all())
     finally:
         _hip.set_conv_math(prev)
+
+
+def _dets(res):
+    r = res[0]
+    return r.bbox.clone(), r.get_field("scores").clone(), r.get_field("labels").clone()
+
+
+def _same(a, b):
+    """bit-equal, NaN == NaN (the reference's s ** 0.8 of a negative ISM-merged score is NaN, and so is ours)"""
+    if a.shape != b.shape:
+        return False
+    if a.dtype.is_floating_point:
+        a, b = torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)
+    return bool(torch.equal(a, b))
+
+
+def test_test_time_forward_replays_the_static_part_as_a_graph_with_identical_detections(monkeypatch):
+    """Generalized_RCNN._eval_static: in eval mode under no_grad the backbone, FPN and RPN head run as one hipGraph per
+    input shape.  Held: the detections of the replayed forward equal the eager ones bit for bit, on a second image too
+    (the input is copied into the captured buffer), and a parameter changed in place (its version counter moves, as
+    load_state_dict does) is seen by the next forward (the graph is re-captured: a replay of the old one would read the
+    stale bf16x3 weight image)."""
+    import __graft_entry__ as entry
+    entry.ensure_built()
+    from bench import Trainer, calibrate_frozen_affine, inference_leg, synthetic_batch
+    from pet.lib.ops import _hip
+    from pet.rcnn.core import config
+    device = torch.device("cuda", 0)
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    _hip.set_deterministic(True)
+    try:
+        tr = Trainer(device)
+        images, _ = synthetic_batch(2, 320, 448, 5, 11, device)
+        calibrate_frozen_affine(tr.model, images.tensors)
+        model = tr.model
+        monkeypatch.setenv("CPM_EVAL_GRAPH", "0")
+        thr = inference_leg(tr, images, device, forwards=2, rank_cut=80)["score_thresh"]
+        model.eval()
+        post = model.Grid_Cascade_RCNN.cls_post_processor
+        post.score_thresh = thr                          # behind the 80-th class score of the untrained cls head
+        a, b = images.tensors[0:1], images.tensors[1:2]
+        with torch.no_grad():
+            monkeypatch.setenv("CPM_EVAL_GRAPH", "0")
+            eager_a, eager_b = _dets(model(a)), _dets(model(b))
+            assert not model.__dict__.get("_eval_graphs")
+            monkeypatch.setenv("CPM_EVAL_GRAPH", "1")
+            first = _dets(model(a))                      # captures
+            assert len(model._eval_graphs) == 1 and all(model._eval_graphs.values())
+            again_a, again_b = _dets(model(a)), _dets(model(b))      # replays
+            assert len(model._eval_graphs) == 1
+            assert len(eager_a[0]) >= 5
+            for got, want in ((first, eager_a), (again_a, eager_a), (again_b, eager_b)):
+                for g, w in zip(got, want):
+                    assert _same(g, w)
+            assert not _same(eager_a[0], eager_b[0])
+            # a parameter of the static part changes in place
+            w = model.RPN.head.conv.weight
+            w.mul_(1.5)                                  # (under no_grad: the version counter moves, as in copy_)
+            w.add_(0.01)
+            changed = _dets(model(a))
+            monkeypatch.setenv("CPM_EVAL_GRAPH", "0")
+            changed_eager = _dets(model(a))
+            for g, e in zip(changed, changed_eager):
+                assert _same(g, e)
+            assert not _same(changed[0], eager_a[0])
+    finally:
+        _hip.set_deterministic(False)
+        _hip.set_conv_math(prev)
+        config.reset_cfg()
+        torch.cuda.empty_cache()
