@@ -118,8 +118,11 @@ def test_backward_matches_reference(model, golden_model, conv_math, reductions):
         # with ordered reductions (fixture) the distance is reproducible: measured 1e-6 (f32) / 1.3e-3 (bf16x3)
         # float-atomic reductions (the benchmark's default): the sums differ from the ordered ones in the last bits, and
         # on this 6-RoI fixture that is enough to flip a gate now and then (round 2 saw 2.2e-3 once in four runs) --
-        # stated bound 4e-3 there; exact f32 keeps 1e-4 in both modes
-        tol = 1e-4 if conv_math == "f32" else (2e-3 if reductions == "ordered" else 4e-3)
+        # stated bound 4e-3 there.  Exact f32 keeps 1e-4 with ordered reductions; with float atomics a gate whose
+        # pre-activation is zero to rounding flips there too, rarely (round 5: 2.3e-4 on one GroupNorm weight's squared
+        # norm, once in three full runs): north_star's 1e-3 is the stated bound for that mode
+        tol = ((1e-4 if reductions == "ordered" else 1e-3) if conv_math == "f32"
+               else (2e-3 if reductions == "ordered" else 4e-3))
         assert e1 < tol and e2 < tol, (k, e1, e2)
     _log("backward_small[%s, %s] worst norm err %.2e" % (conv_math, reductions, worst))
     for key in g.files:
