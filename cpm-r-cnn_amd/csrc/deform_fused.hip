@@ -257,12 +257,25 @@ constexpr int DF_BT = 256;               // threads of the backward kernels: one
 // ---- data gradient ---------------------------------------------------------------------------------------------------
 // LDS: [dx window] [records] [ranks].  Wave w owns channels [16w, 16w+16) of the slab in the window: nobody else
 // touches them, and the LDS operations of one wave execute in order, so the window is updated with plain
-// read-add-write of float4s -- one round per bilinear corner, 16 pixels x 4 channel quads per instruction.  Two of the
-// 16 samples of a (tap, pixel row pair) may land in the SAME cell (offsets that differ by a pixel between neighbours);
-// a sample's rank = the number of earlier pixels of its 16 with the same cell (computed once per patch), and round j of
-// a corner updates the samples of rank j: distinct cells within a round by construction, as many rounds as the deepest
-// collision (one for a smooth offset field).  No LDS float atomics: ds_add_f32 was measured here at ~0.3 lane-adds per
-// clock and CU -- 930 us for a layer when every update went that way.
+// read-add-write of float4s, 16 pixels x 4 channel quads per instruction.  What that costs is the ROUND TRIP: a round
+// is a dependent ds_read_b128 -> add -> ds_write_b128 (round 5's ablation: with one round per bilinear corner the 144
+// rounds of a patch were 60 % of the kernel).  So the 16 pixels of an instruction are chosen such that their 2x2 corner
+// footprints do not overlap -- the patch's four PARITY classes (y & 1, x & 1): same-class pixels are two apart, and a
+// smooth offset field keeps their footprints apart -- and all four corners of a tap go in ONE round: four reads in
+// flight, four adds, four writes (layer3 of X-101, offsets within +-0.3 px: 201 -> 160 us; what remains is the LDS
+// instruction rate: eight waves x 8 b128 operations per round).  Offsets that do bring two footprints of a group
+// together are handled by ranks: a sample's rank is one more than the highest rank among the EARLIER samples of its
+// (tap, class) group whose footprint touches its own (a greedy colouring, computed once per patch), and round j of a
+// tap updates the samples of rank j: disjoint footprints within a round by construction, as many rounds as the deepest
+// chain (one for a smooth field).  Integer positions (no offsets) touch one cell each, distinct by construction: rank 0.
+// No LDS float atomics: ds_add_f32 was measured here at ~0.3 lane-adds per clock and CU -- 930 us for a layer when
+// every update went that way.
+template <bool DEFORM>
+__device__ __forceinline__ int df_class_px(int cls, int l) {          // pixel id (y * 8 + x) of slot l of parity class cls
+  if (!DEFORM) return cls * 16 + l;                                   // (no offsets: two rows of the patch, as the forward)
+  return (2 * (l >> 2) + (cls >> 1)) * DF_T + 2 * (l & 3) + (cls & 1);
+}
+
 template <int NS, bool DEFORM>
 __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __restrict__ dpre,
                                                                  const float* __restrict__ offset,
@@ -297,17 +310,29 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
     }
   }
   __syncthreads();
-  for (int idx = tid; idx < DF_PX * DF_TAPS; idx += DF_BT) {
-    const int mine = srec[idx].x;
+  // ranks: 16 lanes per (tap, class) group, sixteen groups at a time; pivot k hands its footprint and (final) rank to
+  // the later samples of its group
+  for (int grp = tid >> 4; grp < DF_TAPS * 4; grp += DF_BT / 16) {
+    const int tap = grp >> 2, cls = grp & 3, l = tid & 15;
+    const int idx = tap * DF_PX + df_class_px<DEFORM>(cls, l);
     int rank = 0;
-    if (mine >= 0)
-      for (int b = idx & ~15; b < idx; ++b) rank += srec[b].x == mine;
+    if (DEFORM) {
+      const int mine = srec[idx].x;
+      const int cell = mine >= 0 ? mine / DF_PITCH : 0;
+      const int cy = mine >= 0 ? cell / G.win_w : -100000, cx = cell - (cell / G.win_w) * G.win_w;
+#pragma unroll
+      for (int k = 0; k < 15; ++k) {
+        const int py = __shfl(cy, k, 16), px = __shfl(cx, k, 16), pr = __shfl(rank, k, 16);
+        const int dy = cy - py, dx_ = cx - px;
+        if (l > k && dy >= -1 && dy <= 1 && dx_ >= -1 && dx_ <= 1 && rank <= pr) rank = pr + 1;
+      }
+    }
     srank[idx] = (unsigned char)rank;
   }
   __syncthreads();
   const int coff = 16 * slice + 4 * lq;                         // the D rows of this lane: channels cs0 + 4*lq .. +3
   auto load_dpre = [&](int tile, f32x4 (&v)[NS]) {
-    const int px = tile * 16 + l15;
+    const int px = df_class_px<DEFORM>(tile & 3, l15);
     const int p = t.p0 + (px >> 3), q = t.q0 + (px & 7);
     const bool ok = tile < 4 && p < G.P && q < G.Q;
     const float* dp = dpre + (((int64_t)t.n * G.P + (ok ? p : 0)) * G.Q + (ok ? q : 0)) * G.C;
@@ -326,10 +351,11 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
     f32x4 gs[DF_TAPS];
     int4 recs[DF_TAPS];
     int ranks[DF_TAPS];
+    const int mypx = df_class_px<DEFORM>(tile, l15);                // tile = parity class
 #pragma unroll
     for (int tap = 0; tap < DF_TAPS; ++tap) {
-      recs[tap] = srec[tap * DF_PX + tile * 16 + l15];
-      ranks[tap] = srank[tap * DF_PX + tile * 16 + l15];
+      recs[tap] = srec[tap * DF_PX + mypx];
+      ranks[tap] = srank[tap * DF_PX + mypx];
       gs[tap] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
@@ -350,15 +376,22 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
       const float lh = __int_as_float(rec.y), lw = __int_as_float(rec.z);
       const float hh = 1.f - lh, hw = 1.f - lw;
       const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+      // all corners of the tap in one round per rank: the reads are in flight together; a zero corner weight adds
+      // nothing.  (Skipping a corner that weighs zero in EVERY lane -- integer positions: three of the four -- by a
+      // ballot per corner was measured: the branches keep the reads from being issued together, 160 -> 286 us.)
+      {
+        const bool mine = valid && inwin;
+        float* const sc = dwin + (mine ? rec.x : 0) + coff;
+        for (int j = 0; __builtin_amdgcn_ballot_w64(mine && rank >= j) != 0; ++j) {
+          if (mine && rank == j) {
+            f32x4 v[4];
 #pragma unroll
-      for (int k = 0; k < (DEFORM ? 4 : 1); ++k) {
-        // a zero corner weight adds nothing (integer positions: 3 of the 4 corners are skipped by the whole wave)
-        const bool on = valid && cw[k] != 0.f;
-        if (__builtin_amdgcn_ballot_w64(on) == 0) continue;
-        const f32x4 add = cw[k] * g;
-        float* sc = dwin + rec.x + ((k >> 1) * G.win_w + (k & 1)) * DF_PITCH + coff;
-        for (int j = 0; __builtin_amdgcn_ballot_w64(on && inwin && rank >= j) != 0; ++j) {
-          if (on && inwin && rank == j) *(f32x4*)sc = *(const f32x4*)sc + add;
+            for (int k = 0; k < (DEFORM ? 4 : 1); ++k)
+              v[k] = *(const f32x4*)(sc + ((k >> 1) * G.win_w + (k & 1)) * DF_PITCH);
+#pragma unroll
+            for (int k = 0; k < (DEFORM ? 4 : 1); ++k)
+              if (cw[k] != 0.f) *(f32x4*)(sc + ((k >> 1) * G.win_w + (k & 1)) * DF_PITCH) = v[k] + cw[k] * g;
+          }
           df_wave_fence();                     // the next round reads cells this one wrote (through other lanes)
         }
       }
@@ -371,7 +404,7 @@ __global__ __launch_bounds__(DF_BT, 2) void deform_bwd_dx_kernel(const float* __
         df_wave_fence();
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          const int4 fr = srec[tap * DF_PX + tile * 16 + 4 * j + lq];
+          const int4 fr = srec[tap * DF_PX + df_class_px<DEFORM>(tile, 4 * j + lq)];
           if (fr.x != -1) continue;
           const float val = tb[(4 * j + lq) * 16 + l15];
           const float flh = __int_as_float(fr.y), flw = __int_as_float(fr.z);
