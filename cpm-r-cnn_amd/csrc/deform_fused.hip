@@ -24,8 +24,9 @@
 //                    D[px][k] += sample[px][c] * W[c][k]                   -> affine / ReLU epilogue, y
 //   data gradient (4 waves, one per slice, so that a wave OWNS its channels of the dx window):
 //                    D[c][px]  = W[c][k] * dpre[k][px] (column gradient of one tap, in registers), then
-//                    dx window in LDS += corner weight * D by plain read-add-write in collision-free rounds (see the
-//                    kernel), flushed with one float atomic per touched window element; samples outside the window
+//                    dx window in LDS += corner weight * D by plain read-add-write, the four corners of a tap in one
+//                    round over 16 pixels with disjoint footprints (see the kernel), flushed with one float atomic per
+//                    touched window element; samples outside the window
 //                    add to memory directly, re-dealt so that an atomic instruction carries 64 contiguous bytes
 //   weight + offset gradient (4 waves; both need every sample's corners from the x window):
 //                    D[k][c] += dpre[k][px] * sample[px][c]: the sampled tile goes through a per-wave LDS buffer to
@@ -34,7 +35,7 @@
 //                    over the wave's channels by an MFMA against ones, over the slab's slices in LDS, over the slabs by
 //                    one float atomic per (pixel, tap, h|w)
 // Measured (tools/time_deform.py, layer3's 1024 x 50 x 84, offsets within +-1.5 px / +-20 px): forward 46 / 85 us
-// (columns + grouped GEMM: 113), data gradient 199 / 364 (GEMM + col2im: 291 / 444), weight + offset gradient 139 / 186
+// (columns + grouped GEMM: 113), data gradient 173 / 364 (162 at +-0.3 px; GEMM + col2im: 291 / 444), weight + offset gradient 139 / 186
 // (coord + weight GEMM: 146; but that path also needs the 155 MB of columns kept from the forward pass).
 #include <stdlib.h>
 
