@@ -1391,6 +1391,233 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+// ---- the same for the RoI heads' 7x7 maps: igemm3x3_roi_kernel -----------------------------------------------------
+// The grid head is eight 3x3 convolutions over 576 channels on R x 7 x 7 maps: GEMM rows are dense (M = 49 R), but a
+// map's neighbours are its own zero border, never the next RoI.  A workgroup owns 128 consecutive GEMM rows -- pixels
+// of at most FOUR RoIs -- and stages their 9x9 halos (324 halo rows, border cells and RoIs beyond the batch read as
+// zeros) once per 32-channel block; the nine taps are shifted views of it: the A side moves 324 rows per nine k-steps
+// instead of 9 x 128 (3.5x fewer loads, splits and LDS stores), the B side is igemm_kernel's.  ONE halo stage (41 KB) +
+// two B stages (32 KB): two workgroups per CU; the next block's halo waits in registers and is stored between two
+// barriers behind the block's last tap.  Forward and the stride-1 data gradient; conditions in roi_halo_eligible().
+constexpr int RH_S = 7, RH_HW = RH_S + 2, RH_CELLS = RH_HW * RH_HW, RH_PX = RH_S * RH_S;       // 9, 81, 49
+constexpr int RH_ROIS = 4, RH_ROWS = RH_ROIS * RH_CELLS;                                         // 324 halo rows
+
+template <int BN, bool BPRE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void igemm3x3_roi_kernel(IgemmArgs a) {
+  constexpr int BM = 128;
+  constexpr int WM = 2, WN = 2, WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int RPP = 32, BP = BN / RPP;
+  constexpr int AL = (RH_ROWS * 8 + 255) / 256;   // halo loads per thread per channel block (11)
+  constexpr int LDS_DW = RH_ROWS * 32 + 2 * BN * 32;
+  __shared__ __attribute__((aligned(16))) unsigned sm[LDS_DW];
+  constexpr int PA_HI = 0, PA_LO = RH_ROWS * 16, PB_HI = RH_ROWS * 32, PB_LO = PB_HI + 2 * BN * 16;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int tiles_n = (a.OCg + BN - 1) / BN;
+  int bid = blockIdx.x;
+  if (a.xcd_swizzle) {                                // contiguous logical ids per XCD: the N-tiles of a row block share an L2
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int r_first = m0 / RH_PX;
+
+  const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in, a.in_bytes), rs_wm = make_rsrc(a.wm, a.wm_bytes);
+  const int CB = a.Ctot / 32, T = CB * 9;
+
+  // ---- A: halo slots of this thread (halo row hp = RoI * 81 + cell, channel quad cq), fixed over the channel blocks
+  unsigned ha_off[AL];
+  int ha_lds[AL];
+#pragma unroll
+  for (int j = 0; j < AL; ++j) {
+    const int id = tid + 256 * j;
+    const int hp = id >> 3, cq = id & 7;
+    const int r = hp / RH_CELLS, c = hp - r * RH_CELLS;
+    const int hy = c / RH_HW, hx = c - hy * RH_HW;
+    const int n = r_first + r, iy = hy - 1, ix = hx - 1;
+    const bool ok = id < RH_ROWS * 8 && n < a.N && (unsigned)iy < (unsigned)RH_S && (unsigned)ix < (unsigned)RH_S;
+    ha_off[j] = ok ? (unsigned)(((n * RH_S + iy) * RH_S + ix) * a.Ctot + cq * 4) * 4u : B_INVALID;
+    ha_lds[j] = id < RH_ROWS * 8 ? hp * 16 + ((((cq >> 1) ^ ((hp >> 2) & 3)) << 2) | ((cq & 1) << 1)) : -1;
+    asm volatile("" : "+v"(ha_off[j]), "+v"(ha_lds[j]));
+  }
+  // ---- B: as in igemm_kernel
+  const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+  unsigned b_off[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int oc = n0 + i * RPP + lrow;
+    b_off[i] = oc < a.OCg ? (unsigned)(oc * 9 * a.CgR + lcol) * 4u : B_INVALID;
+    asm volatile("" : "+v"(b_off[i]));
+  }
+  const int w_sw = ((((lcol >> 3) ^ ((lrow >> 2) & 3)) << 2) | ((lcol >> 1) & 2));
+
+  float4 ha[AL], rb0[BP], rb1[BP];
+  auto load_a = [&](int cb) {
+#pragma unroll
+    for (int j = 0; j < AL; ++j) ha[j] = bload4(rs_in, ha_off[j] + (unsigned)cb * 128u);   // invalid base stays >= 2 GiB
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int j = 0; j < AL; ++j) {
+      if (ha_lds[j] < 0) continue;
+      uint2 hi, lo;
+      split4(ha[j], hi, lo);
+      *(uint2*)(sm + PA_HI + ha_lds[j]) = hi;
+      *(uint2*)(sm + PA_LO + ha_lds[j]) = lo;
+    }
+  };
+  auto load_b = [&](int t, float4 (&rb)[BP]) {
+    const int cb = t / 9, tap = t - cb * 9;
+    const int tr = tap / 3, ts = tap - tr * 3;
+    const unsigned wtap = (unsigned)(((a.r0 + tr * a.rstep) * a.S + a.s0 + ts * a.sstep) * a.CgR + cb * 32) * 4u;
+#pragma unroll
+    for (int i = 0; i < BP; ++i) rb[i] = bload4(rs_wm, b_off[i] + wtap);
+  };
+  auto store_b = [&](int buf, const float4 (&rb)[BP]) {
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      uint2 hi, lo;
+      if (BPRE) {
+        hi = make_uint2(__float_as_uint(rb[i].x), __float_as_uint(rb[i].y));
+        lo = make_uint2(__float_as_uint(rb[i].z), __float_as_uint(rb[i].w));
+      } else {
+        split4(rb[i], hi, lo);
+      }
+      const int o = (buf * BN + i * RPP + lrow) * 16 + w_sw;
+      *(uint2*)(sm + PB_HI + o) = hi;
+      *(uint2*)(sm + PB_LO + o) = lo;
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // the lane's A rows as halo rows of the centre tap; GEMM rows beyond M read an interior cell of the first halo
+  const int frow = lane & 31, khalf = lane >> 5;
+  int mh[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 32 + frow;
+    const int r = m / RH_PX, px = m - r * RH_PX;
+    const int y = px / RH_S, x = px - y * RH_S;
+    mh[i] = m < a.M ? (r - r_first) * RH_CELLS + (y + 1) * RH_HW + x + 1 : RH_HW + 1;
+  }
+  struct Frag { bf16x8 ah[TM], al[TM], bh[TN], bl[TN]; };
+  auto fetch = [&](int bbuf, int hoff, int sub, Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int h = mh[i] + hoff;
+      const int o = h * 16 + ((((sub * 2 + khalf) ^ ((h >> 2) & 3))) << 2);
+      f.ah[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_HI + o));
+      f.al[i] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PA_LO + o));
+    }
+    const int r_sw = (((sub * 2 + khalf) ^ ((frow >> 2) & 3)) << 2);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int o = (bbuf * BN + wn * WTN + j * 32 + frow) * 16 + r_sw;
+      f.bh[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_HI + o));
+      f.bl[j] = __builtin_bit_cast(bf16x8, *(const uint4*)(sm + PB_LO + o));
+    }
+  };
+  auto mfma3 = [&](const Frag& f) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[i], f.bh[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bl[j], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[i], f.bh[j], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  // prologue: halo of channel block 0, B tiles of steps 0 and 1
+  load_a(0);
+  load_b(0, rb0);
+  store_a();
+  store_b(0, rb0);
+  if (T > 1) load_b(1, rb1);
+  __syncthreads();
+
+  auto step = [&](int t, float4 (&lb)[BP], const float4 (&sb)[BP]) {
+    const int cb = t / 9, tap = t - cb * 9;
+    const int tr = tap / 3, ts = tap - tr * 3;
+    const int hoff = (a.ihadd + tr * a.hstep) * RH_HW + (a.iwadd + ts * a.wstep);
+    if (t + 2 < T) load_b(t + 2, lb);
+    if (tap == 4 && cb + 1 < CB) load_a(cb + 1);            // lands while the block's last taps run
+    Frag f0, f1;
+    fetch(t & 1, hoff, 0, f0);
+    fetch(t & 1, hoff, 1, f1);
+    mfma3(f0);
+    store_b((t + 1) & 1, sb);                               // B tile of step t+1 (stale re-store on the last step)
+    mfma3(f1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 4 * (TM + TN), 0);
+#pragma unroll
+    for (int m = 0; m < TM * TN * 6; ++m) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+      if (m % 6 == 5) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+    }
+    __syncthreads();
+    if (tap == 8 && cb + 1 < CB) {                          // every wave is done with this block's halo
+      store_a();
+      __syncthreads();
+    }
+  };
+  for (int t = 0; t < T; t += 2) {
+    step(t, rb0, rb1);
+    if (t + 1 < T) step(t + 1, rb1, rb0);
+  }
+
+  // ---- epilogue (rows are dense: GEMM row m is output row m)
+  const int ecol = lane & 31, erow0 = 4 * (lane >> 5);
+  float e_sc[TN], e_sh[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int oc = n0 + wn * WTN + j * 32 + ecol;
+    e_sc[j] = (a.scale && oc < a.OCg) ? a.scale[oc] : 1.f;
+    e_sh[j] = (a.shift && oc < a.OCg) ? a.shift[oc] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    float gate[16][TN], resv[16][TN];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const size_t orow = (size_t)(m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int oc = n0 + wn * WTN + j * 32 + ecol;
+        const bool ok = orow < (size_t)a.M && oc < a.OCg;
+        gate[e][j] = (a.mask && ok) ? a.mask[orow * a.OCtot + oc] : 1.f;
+        resv[e][j] = (a.res && ok) ? a.res[orow * a.OCtot + oc] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const size_t orow = (size_t)(m0 + wm * WTM + i * 32 + (e & 3) + 8 * (e >> 2) + erow0);
+      if (orow >= (size_t)a.M) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int oc = n0 + wn * WTN + j * 32 + ecol;
+        if (oc >= a.OCg) continue;
+        float v = acc[i][j][e];
+        if (a.scale) v *= e_sc[j];
+        if (a.shift) v += e_sh[j];
+        v += resv[e][j];
+        if (a.relu) v = fmaxf(v, 0.f);
+        if (a.mask) v = gate[e][j] > 0.f ? v : 0.f;
+        a.out[orow * a.OCtot + oc] = v;
+      }
+    }
+  }
+}
+
 // epilogue as a separate pass (after split-K atomics)
 __global__ void epilogue_kernel(float* __restrict__ out, const float* __restrict__ scale,
                                 const float* __restrict__ shift, const float* __restrict__ res, int64_t M, int OC,
@@ -2648,6 +2875,27 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// igemm3x3_roi_kernel: a dense 3x3 / stride 1 / pad 1 over 7x7 maps (forward, or the data gradient in gather form) whose
+// row blocks give the chip at least CPM_IGEMM_ROI_MIN workgroups without a reduction split
+static int64_t roi_halo_tiles(const IgemmArgs& a) {
+  if (!g_conv_split) return 0;
+  if (!(a.R == 3 && a.S == 3 && a.nr == 3 && a.ns == 3 && a.rstep == 1 && a.sstep == 1 && a.ihmul == 1 && a.iwmul == 1 &&
+        (a.hstep == 1 || a.hstep == -1) && (a.wstep == 1 || a.wstep == -1) && a.osh == 1 && a.osw == 1 && a.oah == 0 &&
+        a.oaw == 0 && a.groups == 1 && a.CgR == a.Ctot && a.Ctot % 32 == 0 && a.OHp == a.OH && a.OWp == a.OW &&
+        a.IH == RH_S && a.IW == RH_S && a.OH == RH_S && a.OW == RH_S && a.ihadd * a.hstep == -1 &&
+        a.iwadd * a.wstep == -1 && a.OCg >= 128 && a.in_bytes < 0x80000000u && (!a.res || a.res_mode == 0) && !a.slab))
+    return 0;
+  return (int64_t)cpm::cdiv(a.M, 128) * cpm::cdiv(a.OCg, 128);
+}
+// Measured (MI355X, tools/bench_conv.py --math w4, 576 -> 576 on R RoIs, us forward / data gradient; generic plan vs this
+// kernel): R = 105: 121 / 129 vs 162 / 151; 128: 128 / 136 vs 160 / 134; 192: 199 / 214 vs 216 / 200; 256: 233 / 240 vs
+// 227 / 235.  3.5x fewer A-side loads, splits and LDS stores buy nothing below two full residency rounds: what a k-step
+// waits for is not its A operand.  OFF by default (CPM_IGEMM_ROI_MIN=0); the tests switch it on.
+static int roi_halo_min() {          // read per call: the tests switch it (0 = off)
+  const int v = env_int("CPM_IGEMM_ROI_MIN", 0);
+  return v > 0 ? v : 0x7fffffff;
+}
+
 // tile + split-K choice: the biggest tile that still gives every CU two workgroups; thin problems take the small
 // tile and split the reduction until there are ~3 workgroups per CU (their K loops are latency bound otherwise)
 Plan plan_igemm(const IgemmArgs& a) {
@@ -2655,6 +2903,10 @@ Plan plan_igemm(const IgemmArgs& a) {
   static const int big_waves = env_int("CPM_IGEMM_BIG_WAVES", 4);      // 4: 2x2 waves, 8: 2x4 waves on 128x128
   Plan p;
   p.wm = 2; p.wn = 2; p.split = 1;
+  if (roi_halo_tiles(a) >= roi_halo_min()) {          // launch_igemm: igemm3x3_roi_kernel (no reduction split)
+    p.bm = 128; p.bn = 128;
+    return p;
+  }
   if (a.OCg <= 32) {
     // narrow outputs (RPN heads, DCN offset predictors, grouped columns): 128x32 tile, 3 workgroups per CU (LDS).
     // A thin grid with a long reduction (1024->18 3x3 on a stride-16 map: 33 tiles x 288 k-steps) splits the
@@ -2858,6 +3110,12 @@ int launch_igemm(IgemmArgs a, const Plan& p, hipStream_t s, int prof_kind) {
       else hipLaunchKernelGGL((igemm3x3_kernel<128>), dim3((unsigned)blocks), dim3(256), 0, s, a);
       return cpm::check_launch("conv igemm 3x3 (halo)");
     }
+  }
+  if (vec && a.split_k == 1 && !a.atomic_out && roi_halo_tiles(a) >= roi_halo_min()) {
+    const int64_t blocks = roi_halo_tiles(a);
+    if (a.b_presplit) hipLaunchKernelGGL((igemm3x3_roi_kernel<128, true>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm3x3_roi_kernel<128, false>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    return cpm::check_launch("conv igemm 3x3 (RoI halo)");
   }
   // Wave quantisation: the big tiles run 2 workgroups per CU (LDS), i.e. 512 at a time.  When the tile count is a
   // little over a multiple of 512 the last round would keep a few CUs busy for a whole tile time while the rest

@@ -922,6 +922,55 @@ def test_one_stage_igemm_equals_two_stage(case, monkeypatch):
         _hip.set_conv_math(prev)
 
 
+@pytest.mark.parametrize("case", [(70, 576, 576), (3, 64, 128), (131, 96, 200), (1, 32, 128), (46, 576, 576)],
+                         ids=["70x576", "3_rois", "ragged_channels", "one_roi", "row_block_ends_inside_a_roi"])
+def test_roi_halo_3x3_equals_generic_igemm(case, monkeypatch):
+    """igemm3x3_roi_kernel (the RoI heads' 3x3 convolutions on 7x7 maps with the 9x9 halos of a row block's RoIs staged
+    once per channel block; taken by grid size, CPM_IGEMM_ROI_MIN=1 forces it on every eligible launch) against
+    igemm_kernel in the split-bf16 arithmetic: forward with scale + bias + residual + ReLU, forward with bias only, plain
+    data gradient -- the same products, summed channel block by channel block instead of tap by tap (and without the
+    generic plan's reduction split): equal to 1e-5 of the tensor's scale -- and to the arithmetic's bound against torch-CPU.  Cases: RoI counts whose 128-row blocks begin and end inside RoIs, a block
+    that runs past the last RoI, output channels that are no multiple of the 128-column tile."""
+    from pet.lib.ops import _hip
+    from pet.lib.ops import conv as ops
+    N, C, K = case
+    prev = _hip.get_conv_math()
+    _hip.set_conv_math("bf16x3")
+    _hip.set_deterministic(True)
+    try:
+        x = rnd(N, C, 7, 7, seed=31)
+        w = rnd(K, C, 3, 3, seed=32, scale=0.05)
+        b = rnd(K, seed=33)
+        sc = rnd(K, seed=34).abs() + 0.5
+        res = rnd(N, K, 7, 7, seed=35)
+        yr = F.relu(F.conv2d(x, w, None, 1, 1) * sc.view(1, -1, 1, 1) + b.view(1, -1, 1, 1) + res)
+        yb = F.conv2d(x, w, b, 1, 1)
+        dy = rnd(N, K, 7, 7, seed=36)
+        xr = x.clone().requires_grad_(True)
+        F.conv2d(xr, w, None, 1, 1).backward(dy)
+        xd = x.cuda().contiguous(memory_format=CL)
+        wd = w.cuda().contiguous(memory_format=CL)
+        dyd = dy.cuda().contiguous(memory_format=CL)
+        resd = res.cuda().contiguous(memory_format=CL)
+        bd, scd = b.cuda(), sc.cuda()
+        got = {}
+        for mode in ("1", "0"):
+            monkeypatch.setenv("CPM_IGEMM_ROI_MIN", mode)
+            y = ops.conv2d_forward(xd, wd, scd, bd, resd, 0, True, 1, 1, 1, 1)
+            y2 = ops.conv2d_forward(xd, wd, None, bd, None, 0, False, 1, 1, 1, 1)
+            dx = ops.conv2d_backward_data(dyd, wd, (N, C, 7, 7), 1, 1, 1, 1)
+            got[mode] = (y, y2, dx)
+        assert relerr(got["1"][0], yr) < TOL and relerr(got["1"][1], yb) < TOL and relerr(got["1"][2], xr.grad) < TOL
+        for a, b_ in zip(got["1"], got["0"]):
+            assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max())
+        # the switch does what it says: with it off, a second run of the generic path is bit-identical to the first
+        monkeypatch.setenv("CPM_IGEMM_ROI_MIN", "0")
+        assert torch.equal(ops.conv2d_forward(xd, wd, None, bd, None, 0, False, 1, 1, 1, 1), got["0"][1])
+    finally:
+        _hip.set_deterministic(False)
+        _hip.set_conv_math(prev)
+
+
 PT_CASES = [
     # N, C, H, W, K, R, stride, pad, groups, res_mode (None: no residual)
     (3, 256, 20, 27, 320, 1, 1, 0, 1, 0),        # 1x1 on dense rows, ragged row and channel tiles, residual + affine + ReLU

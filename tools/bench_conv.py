@@ -39,6 +39,9 @@ LAYERS = [
     ("grid_conv_R192", 192, 576, 7, 7, 576, 3, 1, 1, 1, 21),
     ("grid_conv_R105", 105, 576, 7, 7, 576, 3, 1, 1, 1, 0),
     ("grid_conv_R34", 34, 576, 7, 7, 576, 3, 1, 1, 1, 0),
+    ("grid_conv_R128", 128, 576, 7, 7, 576, 3, 1, 1, 1, 0),
+    ("grid_conv_R160", 160, 576, 7, 7, 576, 3, 1, 1, 1, 0),
+    ("grid_conv_R256", 256, 576, 7, 7, 576, 3, 1, 1, 1, 0),
     ("fc6_R1024", 1024, 256, 7, 7, 1024, 7, 1, 0, 1, 2),
     ("fc7_R1024", 1024, 1024, 1, 1, 1024, 1, 1, 0, 1, 2),
     ("iou_fc1_R64", 64, 576, 7, 7, 1024, 7, 1, 0, 1, 1),
