@@ -112,7 +112,7 @@ class Generalized_RCNN(nn.Module):
     # take the host 4-5 ms, the device ~2.  For every padded input shape seen (up to CPM_EVAL_GRAPH_SHAPES, 8) the static
     # part is captured once -- two eager warm-up runs, then a capture on the same tensors -- and replayed afterwards: the
     # input is copied into the captured buffer, the outputs are the captured buffers (valid until the next replay of
-    # that shape; box_net hands them out, so it stays eager).  The captured kernels read parameters through their
+    # that shape; box_net, whose caller keeps the features across passes, returns copies).  The captured kernels read parameters through their
     # addresses, but the bf16x3 weight images of parameters OUTSIDE a flat optimizer are re-split by Python when a
     # parameter changes (ops.conv.w4_of): a graph is therefore keyed by the parameters' version counters too and
     # re-captured when they move.  CPM_EVAL_GRAPH=0: eager.
@@ -210,8 +210,17 @@ class Generalized_RCNN(nn.Module):
 
     def box_net(self, images, targets=None):
         images = to_image_list(images, cfg.TEST.SIZE_DIVISIBILITY)
-        feats = self._features(self.Norm(images.tensors))
-        proposals, _ = self.RPN(images, feats, targets)
+        x = self.Norm(images.tensors)
+        outs = None if (self.training or cfg.MODEL.RPN_ONLY) else self._eval_static(x)
+        if outs is not None:
+            # the caller keeps the features across passes (test-time augmentation: core/test.py collects them per
+            # pass): copies, not the graph's buffers
+            nf = nl = len(outs) // 3
+            feats = [o.clone() for o in outs[:nf]]
+            proposals, _ = self.RPN(images, feats, targets, head_out=(list(outs[nf:nf + nl]), list(outs[nf + nl:])))
+        else:
+            feats = self._features(x)
+            proposals, _ = self.RPN(images, feats, targets)
         if not cfg.MODEL.RPN_ONLY:
             _, result, _ = self._roi_heads()(feats, proposals, targets)
         else:

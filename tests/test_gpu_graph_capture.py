@@ -123,6 +123,24 @@ def test_test_time_forward_replays_the_static_part_as_a_graph_with_identical_det
                 for g, w in zip(got, want):
                     assert _same(g, w)
             assert not _same(eager_a[0], eager_b[0])
+            # box_net (the test driver's entry: its caller keeps the features across augmentation passes) hands out
+            # copies, not the graph's buffers: a second pass does not change what the first one returned
+            model.Norm = torch.nn.Identity()             # (a model built for testing normalises here; this one is fed normalised images)
+            monkeypatch.setenv("CPM_EVAL_GRAPH", "0")
+            feats_e, res_e = model.box_net([a[0]])
+            monkeypatch.setenv("CPM_EVAL_GRAPH", "1")
+            n_graphs = len(model._eval_graphs)
+            feats_a, res_a = model.box_net([a[0]])
+            assert len(model._eval_graphs) == n_graphs + 1          # (a list of images is batched NCHW: another key)
+            kept = [t.clone() for t in feats_a]
+            feats_b, _ = model.box_net([b[0]])
+            assert len(model._eval_graphs) == n_graphs + 1
+            assert all(torch.equal(t, k) for t, k in zip(feats_a, kept))
+            assert all(torch.equal(t, e) for t, e in zip(feats_a, feats_e))
+            assert not torch.equal(feats_a[0], feats_b[0])
+            for g, w in zip(_dets(res_a), _dets(res_e)):
+                assert _same(g, w)
+            del model.Norm
             # a parameter of the static part changes in place
             w = model.RPN.head.conv.weight
             w.mul_(1.5)                                  # (under no_grad: the version counter moves, as in copy_)
