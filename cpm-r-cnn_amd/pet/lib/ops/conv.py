@@ -1214,9 +1214,11 @@ class _ChainPlan(object):
     dozens of small allocations or ~150 ctypes field stores in front of the first launch would cost what the native
     loop saves."""
 
-    def __init__(self, chw, specs):
+    def __init__(self, chw, specs, infer=False):
         """specs: per layer (weight [K,C,R,S] or [K,C], bias, gamma or None, beta or None, stride, pad, gn_groups, eps,
-        relu)"""
+        relu).  infer: a forward-only table (test time: parameters without gradient sinks)"""
+        self.infer = infer
+        sink = (lambda t: 0) if infer else (lambda t: t._cpm_grad_sink.data_ptr())
         self.n = len(specs)
         self.table = (H.ChainLayer * self.n)()
         params, self.dgrad_keys = [], []
@@ -1227,12 +1229,12 @@ class _ChainPlan(object):
             L = self.table[i]
             L.conv = make_desc(1, c, h, wd, k, r, s, stride, pad, 1, 1)
             L.w, L.bias = w.data_ptr(), bias.data_ptr()
-            L.dw, L.dbias = w._cpm_grad_sink.data_ptr(), bias._cpm_grad_sink.data_ptr()
+            L.dw, L.dbias = sink(w), sink(bias)
             L.has_gn, L.relu = int(gamma is not None), int(bool(relu))
             layer_params = [w, bias]
             if gamma is not None:
                 L.gamma, L.beta = gamma.data_ptr(), beta.data_ptr()
-                L.dgamma, L.dbeta = gamma._cpm_grad_sink.data_ptr(), beta._cpm_grad_sink.data_ptr()
+                L.dgamma, L.dbeta = sink(gamma), sink(beta)
                 L.gn_groups, L.eps = int(gn_groups), float(eps)
                 layer_params += [gamma, beta]
             params += layer_params
@@ -1253,6 +1255,8 @@ class _ChainPlan(object):
         self.sizes = {}
 
     def _pointers(self):
+        if self.infer:
+            return tuple(p.data_ptr() for p in self.params)
         return tuple(p.data_ptr() for p in self.params) + tuple(p._cpm_grad_sink.data_ptr() for p in self.params)
 
     def stale(self):
@@ -1312,6 +1316,33 @@ class _ChainPlan(object):
         self.w4_key = state if all(v == iv for v, iv, _ in state) else None
 
 
+def _chain_forward(x, plan):
+    """the native forward loop of a chain (cpm_layer_chain_forward): (input as read, activation buffer, output)"""
+    H.require_gpu(x)
+    H.wait_pending_sgd(x.device)            # (the chain's parameters travel as raw pointers in its plan)
+    x_in = x
+    x = nhwc(x) if x.dim() == 4 else x.contiguous()
+    _side_copies((x_in, x))
+    n = x.shape[0]
+    fwd_floats, _, ws_bytes = plan.sizes_for(n)
+    fbuf = H.side_alloc(lambda: torch.empty((fwd_floats,), dtype=torch.float32, device=x.device))
+    if plan.flat_out:
+        y = H.side_alloc(lambda: torch.empty((n, plan.out_chw[0]), dtype=torch.float32, device=x.device))
+    else:
+        y = H.side_alloc(lambda: torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device,
+                                             memory_format=CL))
+    if not plan.infer:
+        for p_ in plan.params:
+            _note_use(p_)
+    plan.refresh_w4()
+    ws = H.workspace(ws_bytes, x.device)
+    with H.guard(x.device):
+        rc = H.lib().cpm_layer_chain_forward(plan.table, plan.n, n, H.ptr(x), H.ptr(fbuf), H.ptr(y), H.ptr(ws),
+                                             H.c_size_t(ws.numel()), H.stream())
+    H.check(rc, "layer_chain_forward")
+    return x, fbuf, y
+
+
 class _LayerChainFn(Function):
     """x -> L x [conv(w, b) -> (GroupNorm) -> (ReLU)]: the calls of _ConvFn / _GroupNormFn layer by layer, issued by one
     C loop per direction (cpm_layer_chain_*).  The parameters are not inputs of the node: each owns a slice of the flat
@@ -1319,27 +1350,7 @@ class _LayerChainFn(Function):
 
     @staticmethod
     def forward(ctx, x, plan):
-        H.require_gpu(x)
-        H.wait_pending_sgd(x.device)            # (the chain's parameters travel as raw pointers in its plan)
-        x_in = x
-        x = nhwc(x) if x.dim() == 4 else x.contiguous()
-        _side_copies((x_in, x))
-        n = x.shape[0]
-        fwd_floats, _, ws_bytes = plan.sizes_for(n)
-        fbuf = H.side_alloc(lambda: torch.empty((fwd_floats,), dtype=torch.float32, device=x.device))
-        if plan.flat_out:
-            y = H.side_alloc(lambda: torch.empty((n, plan.out_chw[0]), dtype=torch.float32, device=x.device))
-        else:
-            y = H.side_alloc(lambda: torch.empty((n,) + plan.out_chw, dtype=torch.float32, device=x.device,
-                                                 memory_format=CL))
-        for p_ in plan.params:
-            _note_use(p_)
-        plan.refresh_w4()
-        ws = H.workspace(ws_bytes, x.device)
-        with H.guard(x.device):
-            rc = H.lib().cpm_layer_chain_forward(plan.table, plan.n, n, H.ptr(x), H.ptr(fbuf), H.ptr(y), H.ptr(ws),
-                                                 H.c_size_t(ws.numel()), H.stream())
-        H.check(rc, "layer_chain_forward")
+        x, fbuf, y = _chain_forward(x, plan)
         ctx.plan = plan
         ctx.save_for_backward(x, fbuf, y)
         return y
@@ -1390,13 +1401,17 @@ def _sunk(p):
 
 def layer_chain(x, layers, owner):
     """Run `layers` = [(conv_or_linear_module, GroupNorm_module_or_None, relu), ...] on x as ONE autograd node with one
-    native call per direction (cpm_layer_chain_*) when training on the flat gradient buffer; returns None when the
+    native call per direction (cpm_layer_chain_*) when training on the flat gradient buffer -- and, forward only, under
+    no_grad (the test-time forward is bound by the host: 16 op calls per grid stage become one); returns None when the
     chain does not qualify (the caller then goes layer by layer).  `owner`: the module the plans are cached on."""
-    if not (_STACK and x.is_cuda and torch.is_grad_enabled() and x.requires_grad and x.shape[0] > 0):
+    infer = not torch.is_grad_enabled()     # test time: the same native loop, forward only, no gradient sinks needed
+    if not (_STACK and x.is_cuda and (infer or x.requires_grad) and x.shape[0] > 0):
+        return None
+    if infer and os.environ.get("CPM_CHAIN_INFER", "1") == "0":
         return None
     cache = owner.__dict__.setdefault("_cpm_chain_plans", {})
     chw = tuple(x.shape[1:]) if x.dim() == 4 else (x.shape[1], 1, 1)
-    key = (chw, len(layers))
+    key = (chw, len(layers), infer)
     plan = cache.get(key)
     if plan is not None and plan.stale():
         plan = None
@@ -1405,7 +1420,9 @@ def layer_chain(x, layers, owner):
         rc, rh, rw = chw                                 # the shape running through the chain: the native table only
         for i, (m, gn, relu) in enumerate(layers):       # holds pointers, so every layer is checked against it HERE
             w, b = m.weight, m.bias
-            if not (_sunk(w) and _sunk(b)) or (gn is not None and not (_sunk(gn.weight) and _sunk(gn.bias))):
+            if b is None or (gn is not None and gn.bias is None):
+                return None
+            if not infer and (not (_sunk(w) and _sunk(b)) or (gn is not None and not (_sunk(gn.weight) and _sunk(gn.bias)))):
                 return None
             if w.dim() == 4:
                 conv_like = hasattr(m, "stride")
@@ -1439,7 +1456,9 @@ def layer_chain(x, layers, owner):
                           gn.num_groups if gn is not None else 0, gn.eps if gn is not None else 0.0, relu))
         if len(cache) > 16:
             cache.clear()
-        plan = cache[key] = _ChainPlan(chw, specs)
+        plan = cache[key] = _ChainPlan(chw, specs, infer)
+    if infer:
+        return _chain_forward(x, plan)[2]
     return _LayerChainFn.apply(x, plan)
 
 
