@@ -161,6 +161,51 @@ def test_fused_kernels_equal_column_path_at_full_size(shape):
             assert float((a - b).abs().max() / b.abs().max()) < 2e-5
 
 
+@pytest.mark.parametrize("spread", [0.0, 0.6, 2.5])
+def test_fused_data_gradient_when_every_sample_lands_on_the_same_cells(spread):
+    """The data-gradient kernel updates its LDS window with the four corners of 16 pixels per round and relies on
+    ranks (a greedy colouring over footprint overlap within a (tap, parity class) group) to keep the footprints of a
+    round disjoint.  Worst case for that: offsets that send EVERY sample of the map to one point (+ a per-sample jitter
+    of `spread` pixels: 0 = one cell, rank chain of 15; 0.6 = neighbouring cells that overlap without being equal;
+    2.5 = a loose cluster) -- against the column-matrix path, entry by entry."""
+    import sys
+    import pet.lib.ops as ops
+    from pet.lib.ops import _hip
+    dc = sys.modules["pet.lib.ops.deform_conv"]
+    C, H, W, groups = 128, 24, 24, 8
+    g = torch.Generator().manual_seed(5)
+    x = _cl(torch.randn(1, C, H, W, generator=g))
+    w = _cl(torch.randn(C, C // groups, 3, 3, generator=g) * 0.1)
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
+    off = torch.zeros(1, 18, H, W)
+    for tap in range(9):
+        i, j = tap // 3, tap % 3
+        # the patch's samples meet near the patch centre (so that they stay inside its LDS window)
+        cy, cx = (ys // 8) * 8 + 3.3, (xs // 8) * 8 + 4.6
+        off[0, 2 * tap] = cy - (ys + i - 1) + (torch.rand(H, W, generator=g) - 0.5) * 2 * spread
+        off[0, 2 * tap + 1] = cx - (xs + j - 1) + (torch.rand(H, W, generator=g) - 0.5) * 2 * spread
+    off = _cl(off)
+    dy = _cl(torch.randn(1, C, H, W, generator=g))
+    prev_math = _hip.get_conv_math()
+    _hip.set_conv_math("f32")
+    res = []
+    try:
+        for on in (False, True):
+            was = dc.set_fused(on)
+            try:
+                xi, wi, oi = x.clone().requires_grad_(True), w.clone().requires_grad_(True), off.clone().requires_grad_(True)
+                y = ops.cols_conv(xi, oi, wi, None, None, 1, 1, 1, groups, 1, relu=False)
+                y.backward(dy)
+                res.append((y.detach(), xi.grad, wi.grad, oi.grad))
+            finally:
+                dc.set_fused(was)
+    finally:
+        _hip.set_conv_math(prev_math)
+    assert float(res[0][1].abs().max()) > 0
+    for a, b in zip(res[1], res[0]):
+        assert float((a - b).abs().max() / b.abs().max()) < 2e-5
+
+
 @pytest.mark.parametrize("shape", [FULL_SIZE[2], FULL_SIZE[0]])
 def test_deterministic_mode_gives_bit_identical_weight_gradients_on_x101_layers(shape, deterministic_reductions):
     """cpm_set_deterministic(1) / CPM_DETERMINISTIC=1 promise bit-identical weight gradients run to run
