@@ -263,8 +263,8 @@ constexpr int DF_BT = 256;               // threads of the backward kernels: one
 // rounds of a patch were 60 % of the kernel).  So the 16 pixels of an instruction are chosen such that their 2x2 corner
 // footprints do not overlap -- the patch's four PARITY classes (y & 1, x & 1): same-class pixels are two apart, and a
 // smooth offset field keeps their footprints apart -- and all four corners of a tap go in ONE round: four reads in
-// flight, four adds, four writes (layer3 of X-101, offsets within +-0.3 px: 201 -> 160 us; what remains is the LDS
-// instruction rate: eight waves x 8 b128 operations per round).  Offsets that do bring two footprints of a group
+// flight, four adds, four writes (layer3 of X-101, offsets within +-0.3 px: 201 -> 160 us; the LDS unit is then active
+// ~45 % of the kernel's cycles, profiles/round5_deform_pmc.txt).  Offsets that do bring two footprints of a group
 // together are handled by ranks: a sample's rank is one more than the highest rank among the EARLIER samples of its
 // (tap, class) group whose footprint touches its own (a greedy colouring, computed once per patch), and round j of a
 // tap updates the samples of rank j: disjoint footprints within a round by construction, as many rounds as the deepest
